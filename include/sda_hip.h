@@ -1,0 +1,180 @@
+/*
+ * sda_hip.h -- C ABI of libsda_hip.so: the MI355X (gfx950) kernels behind the
+ * posterior-sampling hot path of francois-rozet/sda.
+ *
+ * The reference has no FFI/plugin boundary of its own (it is pure Python on
+ * torch/ATen); its boundary is the nn.Module call protocol of sda/score.py and
+ * sda/nn.py.  Each entry point below therefore names the reference arithmetic
+ * (file:line under /root/reference) that it replaces.  The Python host side
+ * (sda_amd/score.py, sda_amd/nn.py) keeps the reference's class names, call
+ * signatures and state_dict keys and binds these symbols with ctypes
+ * (sda_amd/_lib.py); INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise
+ *   - strides are in ELEMENTS
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises, nothing allocates => every call is hipGraph-capturable
+ *   - return value: 0 on success, <0 = SDA_E_* (argument/shape not supported),
+ *     >0 = a hipError_t from the launch
+ *   - internal activations are PLANAR: [n][c][h][w] contiguous (1-D nets: h = 1)
+ */
+#ifndef SDA_HIP_H
+#define SDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDA_ABI_VERSION 1
+
+enum {
+    SDA_OK = 0,
+    SDA_E_BADARG = -1,      /* null pointer / non-positive size               */
+    SDA_E_UNSUPPORTED = -2, /* shape outside what the gfx950 kernels tile     */
+    SDA_E_LDS = -3          /* tile does not fit the 160 KiB LDS budget        */
+};
+
+/* activation ids: sda/utils.py:19-25 (ACTIVATIONS) */
+enum { SDA_ACT_NONE = 0, SDA_ACT_SILU = 1, SDA_ACT_RELU = 2, SDA_ACT_ELU = 3, SDA_ACT_GELU = 4, SDA_ACT_SELU = 5 };
+
+int sda_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ * Replaces nn.Conv1d/nn.Conv2d as used by sda/nn.py:113-129,131-142,148-176 (heads, tails,
+ * residue convs; padding = k//2; padding_mode zeros|circular; stride 1|2), and -- with
+ * transposed/flipped packed weights -- their backward-data (what torch.autograd.grad computes
+ * through them at sda/score.py:394).  Fused into the input loader (so no tensor is
+ * materialised for them):
+ *   - the sliding-window view of MCScoreNet.unfold           (sda/score.py:146-153)  [two-level batch stride]
+ *   - the broadcast context/forcing channel concat           (sda/score.py:87, experiments/kolmogorov/utils.py:45-46)
+ *   - the time modulation add + zuko LayerNorm over channels (sda/nn.py:28,137,163)   [mod, ln_mean, ln_rstd]
+ *   - the activation between the two residue convs           (sda/nn.py:139)          [act_in]
+ *   - nn.Upsample(nearest) before the tail conv              (sda/nn.py:164)          [up]
+ *   - zero insertion (transposed stride-2 conv, backward of sda/nn.py:152-159)        [zins]
+ * Fused into the epilogue: bias, multiply by act'(z) (backward through sda/nn.py:139),
+ * residual/skip add (sda/nn.py:28,202).
+ *
+ * out[n][co][oy][ox] = bias[co] + sum_{ci,dy,dx} W[dy*kw+dx][ci][co] * V(n, ci, oy*stride_h+dy-kh/2, ox*stride_w+dx-kw/2)
+ * V = virtual input: source x (and ctx channels) after  +mod -> LN -> act_in,  seen through
+ *     nearest-upsample `up` or zero-insertion `zins`, padded circularly or with zeros.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sda_conv_desc {
+    /* source tensor */
+    const float* x;
+    int64_t x_sn_outer, x_sn_inner; /* image n -> with m = n + x_n_off: (m / n_inner) * sn_outer + (m % n_inner) * sn_inner */
+    int32_t n_inner;                /* >=1; windows per trajectory for the unfold view, else 1 (use sn_inner=0) */
+    int32_t x_n_off;                /* image index offset applied before the n -> address map (chunked execution) */
+    int64_t x_sc, x_sy, x_sx;       /* channel / row / column strides */
+    int32_t cx;                     /* channels taken from x */
+    const float* ctx;               /* optional extra channels appended after cx: planar [cctx][hs][ws] */
+    int64_t ctx_sn;                 /* batch stride of ctx (0 = broadcast over n) */
+    int32_t cctx;
+    int32_t n;                      /* number of images */
+    int32_t hs, ws;                 /* source spatial size */
+    int32_t up_h, up_w;             /* >=1  nearest upsample of the source, per axis (1-D nets: up_h = 1) */
+    int32_t zins_h, zins_w;         /* >=1  zero insertion (virtual[y][x] = src[y/zh][x/zw] iff both divisible) */
+    /* loader transforms (all optional) */
+    const float* mod;               /* [*][cx] additive per-channel modulation */
+    int64_t mod_sn;                 /* per-image stride of mod (0 = shared) */
+    const float* ln_mean;           /* [n][hs*ws] channel-LayerNorm statistics of (x + mod) */
+    const float* ln_rstd;
+    int32_t act_in;                 /* SDA_ACT_* applied after LN */
+    /* filter */
+    int32_t kh, kw, stride_h, stride_w, circular;
+    const float* w;                 /* packed [kh*kw][cin_pad][cout_pad], see sda_pack_conv_weight */
+    int32_t cin_pad, cout_pad;
+    const float* bias;              /* [cout] or NULL */
+    /* output: planar contiguous [n][cout][ho][wo] */
+    float* out;
+    int32_t cout, ho, wo;
+    /* epilogue (tensors shaped like out) */
+    const float* dact_z;            /* out *= act'(dact_z)  (NULL = off) */
+    int32_t act_d;
+    const float* res;               /* out += res           (NULL = off) */
+    /* tiling: cout tile = 32*mt (mt in 1..4); weights must be packed with cout_pad % (32*mt) == 0 */
+    int32_t mt;
+} sda_conv_desc;
+
+int sda_conv_igemm(const sda_conv_desc* d, void* stream);
+/* bytes of dynamic LDS the launch would use (or <0 error), for planning / tests */
+int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);
+
+/* Repack torch-layout conv weights [cout][cin][kh][kw] for sda_conv_igemm.
+ *   transpose = 0: forward          dst[tap][ci][co]        = w[co][ci][dy][dx]
+ *   transpose = 1: backward-data    dst[tap'][co][ci]       = w[co][ci][dy][dx], tap' = (kh-1-dy)*kw + (kw-1-dx)
+ *                  (the packed "cin" axis is then the forward cout and vice versa)
+ * cin_keep: for transpose=1, only the first cin_keep forward input channels are produced (drops ctx grads).
+ * Rows/cols beyond the real sizes are zero filled. */
+int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int transpose, int cin_keep,
+                         float* dst, int k_pad, int m_pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * zuko.nn.LayerNorm(dim=-(spatial+1)) statistics: per pixel, over channels, of (x + mod).
+ * Call sites sda/nn.py:137,163; algorithm zuko==0.1.4 (not in tree): mean, var (unbiased),
+ * rstd = 1/sqrt(var+eps).  x planar [n][c][hw].  The normalisation itself is applied inside
+ * the consuming conv's loader (sda_conv_igemm) or sda_ln_apply.
+ * ------------------------------------------------------------------------------------------ */
+int sda_ln_stats(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, float eps, int unbiased,
+                 float* mean, float* rstd, void* stream);
+/* y = (x + mod - mean) * rstd   (materialised LN; used by tests and non-fused callers) */
+int sda_ln_apply(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, const float* mean,
+                 const float* rstd, float* y, void* stream);
+/* Backward of h = LN_c(x + mod) w.r.t. x (what autograd computes through sda/nn.py:137,163):
+ *   gx = (res ? res : 0) + rstd * (gh - mean_c(gh) - h * sum_c(gh*h)/(c-1|c))
+ * pool = 2: gh is given at 2x resolution ([n][c][2h][2w]) and 2x2-summed first (backward of nn.Upsample nearest,
+ * sda/nn.py:164).  pool_w_only = 1 for 1-D nets (h == 1). */
+int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+               const float* mean, const float* rstd, int unbiased, int pool, const float* res, float* gx,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TimeEmbedding + every block's `project` Linear in one go (sda/score.py:15-35, sda/nn.py:132-135):
+ *   feat = [cos(freqs*t), sin(freqs*t)]; emb = W2 silu(W0 feat + b0) + b2;  mod = Wp emb + bp
+ * t: [nt] ; emb out: [nt][e]; mod out: [nt][cp]  (cp = sum of block widths, Wp = rows concatenated)
+ * ------------------------------------------------------------------------------------------ */
+int sda_time_embed(const float* t, int nt, const float* freqs, int nf, const float* w0, const float* b0, int hidden,
+                   const float* w2, const float* b2, int e, float* emb, void* stream);
+int sda_linear_small(const float* x, int rows, int in_f, const float* w, const float* b, int out_f, float* y,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MCScoreNet.fold (sda/score.py:155-164): selective gather, NOT an overlap-add.
+ *   s: [b][nw][(2k+1)*c][hw] -> out: [b][nw+2k][c][hw]
+ * and the adjoints needed for the guidance gradient (sda/score.py:394):
+ *   fold_adjoint:   g_out [b][l][c][hw] -> g_s [b][nw][(2k+1)c][hw]  (zero where fold does not read)
+ *   unfold_adjoint: g_win [b][nw][(2k+1)c][hw] -> g_x [b][l][c][hw] (+= overlapping windows; the one place overlaps sum)
+ * ------------------------------------------------------------------------------------------ */
+int sda_fold(const float* s, int b, int nw, int k, int c, int hw, float* out, void* stream);
+int sda_fold_adjoint(const float* g_out, int b, int nw, int k, int c, int hw, float* g_s, void* stream);
+int sda_unfold_adjoint(const float* g_win, int b, int nw, int k, int c, int hw, int64_t win_sc_total, float* g_x,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Predictor-corrector updates of VPSDE.sample (sda/score.py:250-261).
+ *   predict:  x = r*x + c1*eps                                                (score.py:252-253)
+ *   sumsq:    partial[b][j] = sum over chunk j of eps[b]^2  (deterministic two-stage mean, score.py:259)
+ *   correct:  delta = tau / mean(eps^2); x = x - (delta*eps + sqrt(2 delta)*z)*sigma   (score.py:259-261)
+ * coef: device pointer to {r, c1} / {sigma} when coef_dev != NULL (graph replay), else the by-value scalars.
+ * ------------------------------------------------------------------------------------------ */
+int sda_pc_predict(float* x, const float* eps, int64_t numel, float r, float c1, const float* coef_dev, void* stream);
+int sda_sumsq_partial(const float* eps, int b, int64_t per_sample, float* partial, int nchunk, void* stream);
+int sda_pc_correct(float* x, const float* eps, const float* z, int b, int64_t per_sample, const float* partial,
+                   int nchunk, float tau, float sigma, const float* coef_dev, void* stream);
+
+/* Gaussian-guidance elementwise pieces (sda/score.py:387,396):
+ *   xhat = (x - sigma*eps)/mu ;   out = eps - (sigma/mu)*(ghat - sigma*vjp),  vjp = J_eps^T ghat
+ * coef_dev (optional): device {mu, sigma} overriding the by-value scalars (no host sync, graph replay). */
+int sda_denoise(const float* x, const float* eps, int64_t numel, float mu, float sigma, const float* coef_dev,
+                float* xhat, void* stream);
+int sda_guided_combine(const float* eps, const float* ghat, const float* vjp, int64_t numel, float mu, float sigma,
+                       const float* coef_dev, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDA_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libsda_hip.so (the C ABI declared in include/sda_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol does not resolve,
+loading raises -- nothing in sda_amd computes on the CPU or through the oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  -- must be imported first: the library binds to the HIP runtime torch loaded
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libsda_hip.so')
+
+ACT_IDS = {None: 0, 'none': 0, 'SiLU': 1, 'ReLU': 2, 'ELU': 3, 'GELU': 4, 'SELU': 5}
+
+c_fp = c_void_p  # device pointers travel as integers
+
+
+class ConvDesc(Structure):
+    """Mirror of `struct sda_conv_desc` (include/sda_hip.h) -- field order and types must match."""
+    _fields_ = [
+        ('x', c_fp),
+        ('x_sn_outer', c_int64), ('x_sn_inner', c_int64),
+        ('n_inner', c_int32),
+        ('x_n_off', c_int32),
+        ('x_sc', c_int64), ('x_sy', c_int64), ('x_sx', c_int64),
+        ('cx', c_int32),
+        ('ctx', c_fp),
+        ('ctx_sn', c_int64),
+        ('cctx', c_int32),
+        ('n', c_int32),
+        ('hs', c_int32), ('ws', c_int32),
+        ('up_h', c_int32), ('up_w', c_int32),
+        ('zins_h', c_int32), ('zins_w', c_int32),
+        ('mod', c_fp),
+        ('mod_sn', c_int64),
+        ('ln_mean', c_fp),
+        ('ln_rstd', c_fp),
+        ('act_in', c_int32),
+        ('kh', c_int32), ('kw', c_int32), ('stride_h', c_int32), ('stride_w', c_int32), ('circular', c_int32),
+        ('w', c_fp),
+        ('cin_pad', c_int32), ('cout_pad', c_int32),
+        ('bias', c_fp),
+        ('out', c_fp),
+        ('cout', c_int32), ('ho', c_int32), ('wo', c_int32),
+        ('dact_z', c_fp),
+        ('act_d', c_int32),
+        ('res', c_fp),
+        ('mt', c_int32),
+    ]
+
+
+# name -> (restype, argtypes); exactly the symbols include/sda_hip.h declares
+SIGNATURES = {
+    'sda_abi_version': (c_int, []),
+    'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
+    'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
+    'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
+    'sda_ln_stats': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_float, c_int, c_fp, c_fp, c_void_p]),
+    'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
+    'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_fp, c_fp,
+                           c_void_p]),
+    'sda_time_embed': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
+    'sda_linear_small': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
+    'sda_fold': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
+    'sda_fold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
+    'sda_unfold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int64, c_fp, c_void_p]),
+    'sda_pc_predict': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_void_p]),
+    'sda_sumsq_partial': (c_int, [c_fp, c_int, c_int64, c_fp, c_int, c_void_p]),
+    'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),
+    'sda_denoise': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
+    'sda_guided_combine': (c_int, [c_fp, c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
+}
+
+_lib = None
+
+
+class SdaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsda_hip.so and bind every declared symbol.  Raises (never falls back) if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdaHipError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run `python -m sda_amd.build` '
+            f'(or __graft_entry__.build()). sda_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SdaHipError(f'libsda_hip.so does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc < 0:
+            msg = {-1: 'bad argument', -2: 'unsupported shape', -3: 'tile exceeds LDS'}.get(rc, 'error')
+            raise SdaHipError(f'{what}: {msg} (SDA_E {rc})')
+        raise SdaHipError(f'{what}: HIP launch error {rc}')

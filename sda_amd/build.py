@@ -1,0 +1,79 @@
+"""Build the HIP libraries in-tree (gfx950 only).
+
+    python -m sda_amd.build            # libsda_hip.so  (the product: device kernels + C ABI)
+    python -m sda_amd.build --emu      # libsda_emu.so  (tests only: host replay of the conv tile algorithm)
+
+The objects are compiled with hipcc and linked WITHOUT an rpath to /opt/rocm: at run time the library must bind
+to the HIP runtime that PyTorch-ROCm already loaded (same soname libamdhip64.so.7), so that torch's streams and
+device pointers are valid inside these kernels.  `import torch` therefore always precedes loading (sda_amd/_lib.py).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+ARCH = 'gfx950'
+SOURCES = ['conv_igemm.hip', 'norm.hip', 'elementwise.hip', 'linear.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
+    hs.append(os.path.join(os.path.dirname(HERE), 'include', 'sda_hip.h'))
+    return hs
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    hdrs = _headers()
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _newer(obj, [sp] + hdrs):
+            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-c', sp, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
+    lib = os.path.join(LIBDIR, 'libsda_hip.so')
+    if force or _newer(lib, objs):
+        cmd = [HIPCC, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', lib] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return lib
+
+
+def build_emu(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, 'conv_igemm.hip')
+    lib = os.path.join(LIBDIR, 'libsda_emu.so')
+    if force or _newer(lib, [src] + _headers()):
+        subprocess.check_call([HIPCC, '--offload-host-only', '-DSDA_HOST_EMU', '-O2', '-std=c++17', '-fPIC',
+                               '-ffp-contract=off', '-shared', src, '-o', lib])
+    return lib
+
+
+if __name__ == '__main__':
+    force = '--force' in sys.argv
+    if '--emu' in sys.argv:
+        print(build_emu(force))
+    else:
+        print(build(force, verbose=True))

@@ -1,0 +1,491 @@
+// Implicit-GEMM convolution for gfx950 on the fp32 matrix cores.
+//
+//   D[co][pix] = sum_{tap,ci} W[tap][ci][co] * V[ci][pix + tap]        (M = cout, N = pixels, K = taps*cin)
+//
+// Design:
+//   * activations are PLANAR ([n][c][h][w]); a workgroup owns 128 output pixels (tn images x tr rows x tw cols,
+//     all powers of two) x one cout tile of 32*MT channels;
+//   * per K-stage (CK input channels) the workgroup stages the HALO TILE of those channels once into LDS
+//     ([ck][tn][in_rows][in_cols]) and the weight slab [tap][ck][cout-tile]; all kh*kw taps are then served
+//     from LDS -- the input is read from HBM once per cout tile, not once per tap;
+//   * the loader applies, on the fly: the sliding-window view (two-level batch stride), the context-channel
+//     concat, time-modulation add, channel LayerNorm, activation, nearest upsample, zero insertion and
+//     circular / zero padding -- none of these is ever materialised;
+//   * 4 wavefronts (64 lanes each); wave w owns pixels [32w, 32w+32) x all MT cout sub-tiles and issues
+//     v_mfma_f32_32x32x2_f32: A = W[co = lane&31][k = lane>>5]  (LDS, conflict-free: 32 consecutive floats),
+//                             B = V[k = lane>>5][pix = lane&31] (LDS, consecutive columns of the halo tile);
+//   * epilogue: D col = lane&31 = pixel, D row = (r&3) + 8*(r>>2) + 4*(lane>>5) = cout  => for each accumulator
+//     register 32 lanes store 128 contiguous bytes of one output-channel row.
+//
+// Everything that is index arithmetic lives in __host__ __device__ functions so that the very same code is
+// replayed on the CPU by the emulator at the bottom (built only into libsda_emu.so for tests/).
+#include "sda_common.hpp"
+
+#ifndef SDA_CONV_CK
+#define SDA_CONV_CK 8
+#endif
+#define SDA_CONV_BP 128
+#define SDA_CONV_THREADS 256
+#define SDA_CONV_MAXPOS 4
+
+struct ConvGeom {
+    int cin;             // cx + cctx
+    int hv, wv;          // virtual input size
+    int pad_h, pad_w;
+    int tn, tr, tw;      // tile: images x rows x cols (powers of two, product 128)
+    int tr_shift, tw_shift;
+    int tiles_x, tiles_y, tiles_n;
+    int n_pt, n_ct, grid;
+    int in_rows, in_cols, plane;   // halo tile per (channel, image)
+    int S;                         // positions per channel = tn * plane
+    int ntaps;
+    int bm;                        // cout tile = 32*mt
+    int nstage;
+    int64_t lds_bytes;
+};
+
+static inline int ilog2_pow2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+static int pick_pow2_tile(int extent, int budget) {
+    // largest power of two <= budget whose padded extent wastes <= 25 %; else the smallest that covers, else 1
+    int best = 1;
+    for (int t = budget; t >= 1; t >>= 1) {
+        long padded = (long)((extent + t - 1) / t) * t;
+        if (padded * 4 <= (long)extent * 5) { best = t; break; }
+    }
+    return best;
+}
+
+static int conv_plan(const sda_conv_desc* d, ConvGeom* g) {
+    if (!d || !d->x || !d->w || !d->out) return SDA_E_BADARG;
+    if (d->n <= 0 || d->cx <= 0 || d->cout <= 0 || d->hs <= 0 || d->ws <= 0 || d->ho <= 0 || d->wo <= 0) return SDA_E_BADARG;
+    if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1)) return SDA_E_UNSUPPORTED;
+    if (d->stride_h < 1 || d->stride_w < 1 || d->up_h < 1 || d->up_w < 1 || d->zins_h < 1 || d->zins_w < 1) return SDA_E_UNSUPPORTED;
+    if ((d->up_h > 1 || d->up_w > 1) && (d->zins_h > 1 || d->zins_w > 1)) return SDA_E_UNSUPPORTED;
+    if (d->mt < 1 || d->mt > 4) return SDA_E_UNSUPPORTED;
+    if (d->cctx > 0 && !d->ctx) return SDA_E_BADARG;
+    if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return SDA_E_BADARG;
+    if (d->n_inner < 1) return SDA_E_BADARG;
+    g->cin = d->cx + (d->cctx > 0 ? d->cctx : 0);
+    g->hv = d->hs * d->up_h * d->zins_h;
+    g->wv = d->ws * d->up_w * d->zins_w;
+    g->pad_h = d->kh / 2;
+    g->pad_w = d->kw / 2;
+    g->bm = 32 * d->mt;
+    if (d->cout_pad % g->bm || d->cout_pad < d->cout) return SDA_E_BADARG;
+    if (d->cin_pad % SDA_CONV_CK || d->cin_pad < g->cin) return SDA_E_BADARG;
+    g->tw = pick_pow2_tile(d->wo, SDA_CONV_BP);
+    g->tr = pick_pow2_tile(d->ho, SDA_CONV_BP / g->tw);
+    g->tn = SDA_CONV_BP / (g->tw * g->tr);
+    g->tw_shift = ilog2_pow2(g->tw);
+    g->tr_shift = ilog2_pow2(g->tr);
+    g->tiles_x = (d->wo + g->tw - 1) / g->tw;
+    g->tiles_y = (d->ho + g->tr - 1) / g->tr;
+    g->tiles_n = (d->n + g->tn - 1) / g->tn;
+    long npt = (long)g->tiles_x * g->tiles_y * g->tiles_n;
+    g->n_ct = d->cout_pad / g->bm;
+    // drop cout tiles that lie wholly beyond cout (packed padding)
+    while (g->n_ct > 1 && (g->n_ct - 1) * g->bm >= d->cout) --g->n_ct;
+    if (npt * g->n_ct > 0x7fffffffL) return SDA_E_UNSUPPORTED;
+    g->n_pt = (int)npt;
+    g->grid = g->n_pt * g->n_ct;
+    g->in_rows = (g->tr - 1) * d->stride_h + d->kh;
+    g->in_cols = (g->tw - 1) * d->stride_w + d->kw;
+    g->plane = g->in_rows * g->in_cols;
+    g->S = g->tn * g->plane;
+    if (g->S > SDA_CONV_MAXPOS * SDA_CONV_THREADS) return SDA_E_UNSUPPORTED;
+    g->ntaps = d->kh * d->kw;
+    g->nstage = d->cin_pad / SDA_CONV_CK;
+    g->lds_bytes = ((int64_t)g->ntaps * SDA_CONV_CK * g->bm + (int64_t)SDA_CONV_CK * g->S) * 4;
+    if (g->lds_bytes > 160 * 1024) return SDA_E_LDS;
+    return SDA_OK;
+}
+
+// ---------------------------------------------------------------- index helpers (host + device)
+
+// XCD-aware block remap: hardware places block b on XCD b % 8; give each XCD a contiguous range of logical
+// tiles so that the cout tiles of one pixel tile (and neighbouring halos) share that XCD's L2.  Bijective for any G.
+__host__ __device__ inline int conv_logical_block(int b, int G) {
+    int xcd = b & 7, slot = b >> 3;
+    int q = G >> 3, r = G & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+__host__ __device__ inline void conv_decode_block(const ConvGeom& g, int logical, int& ct, int& n0, int& oy0, int& ox0) {
+    ct = logical % g.n_ct;
+    int pt = logical / g.n_ct;
+    int txi = pt % g.tiles_x;
+    int r = pt / g.tiles_x;
+    int tyi = r % g.tiles_y;
+    int tni = r / g.tiles_y;
+    n0 = tni * g.tn;
+    oy0 = tyi * g.tr;
+    ox0 = txi * g.tw;
+}
+
+__host__ __device__ inline int conv_wrap(int v, int m) {
+    v %= m;
+    return v < 0 ? v + m : v;
+}
+
+struct ConvPos {
+    int64_t xoff;   // element offset of channel 0 of this position inside x, or -1 if the tap reads padding / nothing
+    int64_t coff;   // offset inside ctx (channel 0 of the context block)
+    int64_t stat;   // index into ln_mean / ln_rstd
+    int nimg;
+};
+
+// halo position `pos` (0..S) of the tile -> where it comes from
+__host__ __device__ inline ConvPos conv_decode_pos(const sda_conv_desc& d, const ConvGeom& g, int pos, int n0, int oy0, int ox0) {
+    ConvPos r;
+    r.xoff = -1; r.coff = 0; r.stat = 0; r.nimg = 0;
+    int tni = pos / g.plane;
+    int rem = pos - tni * g.plane;
+    int ry = rem / g.in_cols;
+    int rx = rem - ry * g.in_cols;
+    int n = n0 + tni;
+    if (n >= d.n) return r;
+    int vy = oy0 * d.stride_h + ry - g.pad_h;
+    int vx = ox0 * d.stride_w + rx - g.pad_w;
+    if (d.circular) {
+        vy = conv_wrap(vy, g.hv);
+        vx = conv_wrap(vx, g.wv);
+    } else if (vy < 0 || vy >= g.hv || vx < 0 || vx >= g.wv) {
+        return r;
+    }
+    if ((vy % d.zins_h) || (vx % d.zins_w)) return r;      // zero insertion: only multiples carry data
+    const int sy = vy / (d.zins_h * d.up_h);                 // (one of zins / up is 1 per axis)
+    const int sx = vx / (d.zins_w * d.up_w);
+    const int ng = n + d.x_n_off;
+    int64_t nbase = (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
+    r.xoff = nbase + (int64_t)sy * d.x_sy + (int64_t)sx * d.x_sx;
+    r.coff = (int64_t)n * d.ctx_sn + (int64_t)sy * d.ws + sx;
+    r.stat = (int64_t)n * d.hs * d.ws + (int64_t)sy * d.ws + sx;
+    r.nimg = n;
+    return r;
+}
+
+// value of virtual-input channel c at a decoded position, after modulation / LayerNorm / activation
+__host__ __device__ inline float conv_load_value(const sda_conv_desc& d, const ConvGeom& g, const ConvPos& ps, int c,
+                                                 float mean, float rstd) {
+    if (ps.xoff < 0 || c >= g.cin) return 0.f;
+    float v;
+    if (c < d.cx) {
+        v = d.x[ps.xoff + (int64_t)c * d.x_sc];
+        if (d.mod) v += d.mod[(int64_t)ps.nimg * d.mod_sn + c];
+        if (d.ln_mean) v = (v - mean) * rstd;
+    } else {
+        v = d.ctx[ps.coff + (int64_t)(c - d.cx) * d.hs * d.ws];
+    }
+    if (d.act_in) v = sda_act(d.act_in, v);
+    return v;
+}
+
+// LDS offset (in floats, inside one channel plane set) of the (dy=0,dx=0) tap of output pixel p of the tile
+__host__ __device__ inline int conv_pix_lds_base(const sda_conv_desc& d, const ConvGeom& g, int p) {
+    int tx = p & (g.tw - 1);
+    int ty = (p >> g.tw_shift) & (g.tr - 1);
+    int tni = p >> (g.tw_shift + g.tr_shift);
+    return (tni * g.in_rows + ty * d.stride_h) * g.in_cols + tx * d.stride_w;
+}
+
+// output element offset of pixel p, channel 0; -1 if the pixel is outside the tensor
+__host__ __device__ inline int64_t conv_pix_out_base(const sda_conv_desc& d, const ConvGeom& g, int p, int n0, int oy0, int ox0) {
+    int tx = p & (g.tw - 1);
+    int ty = (p >> g.tw_shift) & (g.tr - 1);
+    int tni = p >> (g.tw_shift + g.tr_shift);
+    int n = n0 + tni, oy = oy0 + ty, ox = ox0 + tx;
+    if (n >= d.n || oy >= d.ho || ox >= d.wo) return -1;
+    return ((int64_t)n * d.cout * d.ho + oy) * d.wo + ox;
+}
+
+__host__ __device__ inline void conv_epilogue_store(const sda_conv_desc& d, int64_t obase, int co, float acc) {
+    if (obase < 0 || co >= d.cout) return;
+    int64_t off = obase + (int64_t)co * d.ho * d.wo;
+    float v = acc;
+    if (d.bias) v += d.bias[co];
+    if (d.dact_z) v *= sda_dact(d.act_d, d.dact_z[off]);
+    if (d.res) v += d.res[off];
+    d.out[off] = v;
+}
+
+// D-fragment row of accumulator register r for v_mfma_f32_32x32x2_f32 (col = lane & 31)
+__host__ __device__ inline int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------- the kernel
+#ifndef SDA_HOST_EMU
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NPOS>
+__global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_conv_desc d, const ConvGeom g) {
+    constexpr int CK = SDA_CONV_CK;
+    constexpr int BM = MT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_w = smem;                          // [ntaps][CK][BM]
+    float* s_in = smem + g.ntaps * CK * BM;     // [CK][S]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+
+    int ct, n0, oy0, ox0;
+    conv_decode_block(g, conv_logical_block(blockIdx.x, gridDim.x), ct, n0, oy0, ox0);
+    const int co0 = ct * BM;
+
+    // per-thread halo positions (fixed for the whole kernel; only the channel slab changes per stage)
+    ConvPos ps[NPOS];
+    float pmean[NPOS], prstd[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        int pos = tid + i * SDA_CONV_THREADS;
+        ps[i].xoff = -1; ps[i].coff = 0; ps[i].stat = 0; ps[i].nimg = 0;
+        pmean[i] = 0.f; prstd[i] = 1.f;
+        if (pos < g.S) {
+            ps[i] = conv_decode_pos(d, g, pos, n0, oy0, ox0);
+            if (d.ln_mean && ps[i].xoff >= 0) {
+                pmean[i] = d.ln_mean[ps[i].stat];
+                prstd[i] = d.ln_rstd[ps[i].stat];
+            }
+        }
+    }
+
+    const int pix = wave * 32 + l31;
+    const int pixbase = conv_pix_lds_base(d, g, pix);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    for (int st = 0; st < g.nstage; ++st) {
+        const int c0 = st * CK;
+        // ---- stage the weight slab: [tap][ck][BM] <- w[tap][c0+ck][co0 .. co0+BM)
+        {
+            constexpr int ROW4 = BM / 4;
+            const int total4 = g.ntaps * CK * ROW4;
+            for (int f = tid; f < total4; f += SDA_CONV_THREADS) {
+                int row = f / ROW4;
+                int c4 = f - row * ROW4;
+                int tap = row / CK;
+                int ck = row - tap * CK;
+                const float* src = d.w + ((int64_t)tap * d.cin_pad + c0 + ck) * d.cout_pad + co0 + c4 * 4;
+                *reinterpret_cast<f32x4*>(s_w + row * BM + c4 * 4) = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+        // ---- stage the input halo tile with every loader-side fusion applied
+        {
+            float v[NPOS][CK];
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i)
+#pragma unroll
+                for (int ck = 0; ck < CK; ++ck) v[i][ck] = conv_load_value(d, g, ps[i], c0 + ck, pmean[i], prstd[i]);
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) {
+                int pos = tid + i * SDA_CONV_THREADS;
+                if (pos < g.S) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck) s_in[ck * g.S + pos] = v[i][ck];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over all taps of this channel slab
+        {
+            int dy = 0, dx = 0;
+            for (int tap = 0; tap < g.ntaps; ++tap) {
+                const int toff = dy * g.in_cols + dx + pixbase;
+                const float* wrow = s_w + tap * CK * BM + l31;
+#pragma unroll
+                for (int k2 = 0; k2 < CK / 2; ++k2) {
+                    const int ck = 2 * k2 + khalf;
+                    const float b = s_in[ck * g.S + toff];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = wrow[ck * BM + m * 32];
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+                    }
+                }
+                if (++dx == d.kw) { dx = 0; ++dy; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int64_t obase = conv_pix_out_base(d, g, pix, n0, oy0, ox0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) conv_epilogue_store(d, obase, co0 + m * 32 + mfma32_row(r, lane), acc[m][r]);
+}
+
+template <int MT, int NPOS>
+static int conv_launch_t(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    auto kern = conv_igemm_kernel<MT, NPOS>;
+    if (g.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)g.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(SDA_CONV_THREADS), (size_t)g.lds_bytes, stream, *d, g);
+    return sda_launch_status();
+}
+
+template <int MT>
+static int conv_launch_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    int npos = (g.S + SDA_CONV_THREADS - 1) / SDA_CONV_THREADS;
+    if (npos <= 2) return conv_launch_t<MT, 2>(d, g, stream);
+    return conv_launch_t<MT, SDA_CONV_MAXPOS>(d, g, stream);
+}
+
+extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
+    ConvGeom g;
+    int rc = conv_plan(d, &g);
+    if (rc != SDA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->mt) {
+        case 1: return conv_launch_m<1>(d, g, s);
+        case 2: return conv_launch_m<2>(d, g, s);
+        case 3: return conv_launch_m<3>(d, g, s);
+        default: return conv_launch_m<4>(d, g, s);
+    }
+}
+
+extern "C" int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d) {
+    ConvGeom g;
+    int rc = conv_plan(d, &g);
+    return rc != SDA_OK ? (int64_t)rc : g.lds_bytes;
+}
+
+// ---------------------------------------------------------------- weight repack (device side, one-off per layer)
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int transpose,
+                                        int cin_keep, float* __restrict__ dst, int k_pad, int m_pad) {
+    const int64_t total = (int64_t)kh * kw * k_pad * m_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int mm = (int)(i % m_pad);
+        int64_t r = i / m_pad;
+        int kk = (int)(r % k_pad);
+        int tap = (int)(r / k_pad);
+        int dy = tap / kw, dx = tap % kw;
+        float v = 0.f;
+        if (!transpose) {
+            int ci = kk, co = mm;
+            if (ci < cin && co < cout) v = w[(((int64_t)co * cin + ci) * kh + dy) * kw + dx];
+        } else {
+            int co = kk, ci = mm;
+            int sdy = kh - 1 - dy, sdx = kw - 1 - dx;
+            if (ci < cin_keep && ci < cin && co < cout) v = w[(((int64_t)co * cin + ci) * kh + sdy) * kw + sdx];
+        }
+        dst[i] = v;
+    }
+}
+
+extern "C" int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int transpose, int cin_keep,
+                                    float* dst, int k_pad, int m_pad, void* stream) {
+    if (!w || !dst || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || k_pad <= 0 || m_pad <= 0) return SDA_E_BADARG;
+    int64_t total = (int64_t)kh * kw * k_pad * m_pad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kh, kw,
+                       transpose, cin_keep, dst, k_pad, m_pad);
+    return sda_launch_status();
+}
+
+#endif  // !SDA_HOST_EMU
+
+// ---------------------------------------------------------------- CPU emulator (tests only; libsda_emu.so)
+#ifdef SDA_HOST_EMU
+#include <vector>
+// Replays conv_igemm_kernel<MT,*> on the host with HOST pointers: same planner, same index helpers, same staging
+// order, same MFMA lane<->element maps (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D row = mfma32_row(r,l), col = l&31).
+extern "C" int sda_conv_igemm_emulate(const sda_conv_desc* dp) {
+    ConvGeom g;
+    int rc = conv_plan(dp, &g);
+    if (rc != SDA_OK) return rc;
+    const sda_conv_desc& d = *dp;
+    constexpr int CK = SDA_CONV_CK;
+    const int BM = g.bm, MT = d.mt;
+    std::vector<float> s_w((size_t)g.ntaps * CK * BM), s_in((size_t)CK * g.S);
+    std::vector<float> acc((size_t)SDA_CONV_THREADS * MT * 16);
+    for (int b = 0; b < g.grid; ++b) {
+        int ct, n0, oy0, ox0;
+        conv_decode_block(g, conv_logical_block(b, g.grid), ct, n0, oy0, ox0);
+        const int co0 = ct * BM;
+        std::fill(acc.begin(), acc.end(), 0.f);
+        for (int st = 0; st < g.nstage; ++st) {
+            const int c0 = st * CK;
+            for (int tid = 0; tid < SDA_CONV_THREADS; ++tid) {
+                const int ROW4 = BM / 4, total4 = g.ntaps * CK * ROW4;
+                for (int f = tid; f < total4; f += SDA_CONV_THREADS) {
+                    int row = f / ROW4, c4 = f - row * ROW4, tap = row / CK, ck = row - tap * CK;
+                    const float* src = d.w + ((int64_t)tap * d.cin_pad + c0 + ck) * d.cout_pad + co0 + c4 * 4;
+                    for (int q = 0; q < 4; ++q) s_w[(size_t)row * BM + c4 * 4 + q] = src[q];
+                }
+                for (int pos = tid; pos < g.S; pos += SDA_CONV_THREADS) {
+                    ConvPos ps = conv_decode_pos(d, g, pos, n0, oy0, ox0);
+                    float mean = 0.f, rstd = 1.f;
+                    if (d.ln_mean && ps.xoff >= 0) { mean = d.ln_mean[ps.stat]; rstd = d.ln_rstd[ps.stat]; }
+                    for (int ck = 0; ck < CK; ++ck) s_in[(size_t)ck * g.S + pos] = conv_load_value(d, g, ps, c0 + ck, mean, rstd);
+                }
+            }
+            for (int wave = 0; wave < 4; ++wave) {
+                int dy = 0, dx = 0;
+                for (int tap = 0; tap < g.ntaps; ++tap) {
+                    for (int k2 = 0; k2 < CK / 2; ++k2) {
+                        for (int m = 0; m < MT; ++m) {
+                            float A[32][2], B[2][32];
+                            for (int lane = 0; lane < 64; ++lane) {
+                                int l31 = lane & 31, kh_ = lane >> 5, ck = 2 * k2 + kh_;
+                                int pix = wave * 32 + l31;
+                                int toff = dy * g.in_cols + dx + conv_pix_lds_base(d, g, pix);
+                                B[kh_][l31] = s_in[(size_t)ck * g.S + toff];
+                                A[l31][kh_] = s_w[((size_t)tap * CK + ck) * BM + m * 32 + l31];
+                            }
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int r = 0; r < 16; ++r) {
+                                    int i = mfma32_row(r, lane), j = lane & 31;
+                                    float& c = acc[((size_t)(wave * 64 + lane) * MT + m) * 16 + r];
+                                    c = fmaf(A[i][0], B[0][j], c);
+                                    c = fmaf(A[i][1], B[1][j], c);
+                                }
+                        }
+                    }
+                    if (++dx == d.kw) { dx = 0; ++dy; }
+                }
+            }
+        }
+        for (int tid = 0; tid < SDA_CONV_THREADS; ++tid) {
+            int lane = tid & 63, wave = tid >> 6, pix = wave * 32 + (lane & 31);
+            int64_t obase = conv_pix_out_base(d, g, pix, n0, oy0, ox0);
+            for (int m = 0; m < MT; ++m)
+                for (int r = 0; r < 16; ++r)
+                    conv_epilogue_store(d, obase, co0 + m * 32 + mfma32_row(r, lane), acc[((size_t)tid * MT + m) * 16 + r]);
+        }
+    }
+    return SDA_OK;
+}
+
+extern "C" void sda_pack_conv_weight_host(const float* w, int cout, int cin, int kh, int kw, int transpose, int cin_keep,
+                                          float* dst, int k_pad, int m_pad) {
+    const int64_t total = (int64_t)kh * kw * k_pad * m_pad;
+    for (int64_t i = 0; i < total; ++i) {
+        int mm = (int)(i % m_pad);
+        int64_t r = i / m_pad;
+        int kk = (int)(r % k_pad), tap = (int)(r / k_pad), dy = tap / kw, dx = tap % kw;
+        float v = 0.f;
+        if (!transpose) {
+            if (kk < cin && mm < cout) v = w[(((int64_t)mm * cin + kk) * kh + dy) * kw + dx];
+        } else {
+            int sdy = kh - 1 - dy, sdx = kw - 1 - dx;
+            if (mm < cin_keep && mm < cin && kk < cout) v = w[(((int64_t)kk * cin + mm) * kh + sdy) * kw + sdx];
+        }
+        dst[i] = v;
+    }
+}
+#endif  // SDA_HOST_EMU

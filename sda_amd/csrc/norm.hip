@@ -1,0 +1,159 @@
+// Channel LayerNorm (zuko.nn.LayerNorm(dim=-(spatial+1)); call sites sda/nn.py:137,163) on PLANAR tensors.
+//
+// x: [n][c][hw].  One thread owns one pixel; consecutive lanes own consecutive pixels, so every channel-plane
+// access of a wavefront is one contiguous 256-byte segment.  These kernels are HBM-bound: algorithmic bytes are
+//   ln_stats : read x once (second pass re-reads through L2/MALL)                   = c*hw*4 B / image
+//   ln_bwd   : read gh (x4 when pooling) + x twice (2nd pass cached), write gx
+// The normalisation itself is never materialised in the network path: sda_conv_igemm's loader applies
+// (x + mod - mean) * rstd while it stages the halo tile.  sda_ln_apply exists for tests / unfused callers.
+#include "sda_common.hpp"
+
+#define LN_THREADS 256
+
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
+                                                              const float* __restrict__ mod, int64_t mod_sn, float eps,
+                                                              int unbiased, float* __restrict__ mean,
+                                                              float* __restrict__ rstd) {
+    const int64_t idx = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
+    if (idx >= npix) return;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const float* xp = x + n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    // pass 1: mean
+    float s = 0.f;
+    for (int k = 0; k < c; ++k) {
+        float v = xp[(int64_t)k * hw];
+        if (mp) v += mp[k];
+        s += v;
+    }
+    const float m = s / (float)c;
+    // pass 2: centred second moment (two-pass, as torch.var_mean does; no E[x^2]-m^2 cancellation)
+    float q = 0.f;
+    for (int k = 0; k < c; ++k) {
+        float v = xp[(int64_t)k * hw];
+        if (mp) v += mp[k];
+        const float dlt = v - m;
+        q += dlt * dlt;
+    }
+    const float var = q / (float)(unbiased ? c - 1 : c);
+    mean[idx] = m;
+    rstd[idx] = 1.0f / sqrtf(var + eps);
+}
+
+extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, float eps,
+                            int unbiased, float* mean, float* rstd, void* stream) {
+    if (!x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return SDA_E_BADARG;
+    if (unbiased && c < 2) return SDA_E_UNSUPPORTED;
+    const int64_t npix = (int64_t)n * hw;
+    const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
+    if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
+                       mod, mod_sn, eps, unbiased, mean, rstd);
+    return sda_launch_status();
+}
+
+__global__ __launch_bounds__(LN_THREADS) void ln_apply_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
+                                                              const float* __restrict__ mod, int64_t mod_sn,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ y) {
+    const int64_t idx = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
+    if (idx >= npix) return;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const int64_t base = n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    const float m = mean[idx], r = rstd[idx];
+    for (int k = 0; k < c; ++k) {
+        float v = x[base + (int64_t)k * hw];
+        if (mp) v += mp[k];
+        y[base + (int64_t)k * hw] = (v - m) * r;
+    }
+}
+
+extern "C" int sda_ln_apply(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, const float* mean,
+                            const float* rstd, float* y, void* stream) {
+    if (!x || !mean || !rstd || !y || n <= 0 || c <= 0 || hw <= 0) return SDA_E_BADARG;
+    const int64_t npix = (int64_t)n * hw;
+    const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
+    if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
+                       mod, mod_sn, mean, rstd, y);
+    return sda_launch_status();
+}
+
+// Backward of h = (u - mean(u)) * rstd, u = x + mod, w.r.t. x (channel axis, per pixel):
+//   gx_j = rstd * ( gh_j - mean_c(gh) - h_j * sum_c(gh * h) / (c-1 | c) )      (+ res_j)
+// POOL: gh lives at (2h x 2w) [or (h x 2w) for 1-D nets] and is summed over each 2x2 (1x2) cell first
+// (= backward of nn.Upsample(nearest), sda/nn.py:164).
+template <int POOL_H, int POOL_W>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restrict__ gh, const float* __restrict__ x,
+                                                            int64_t npix, int c, int h, int w,
+                                                            const float* __restrict__ mod, int64_t mod_sn,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int unbiased,
+                                                            const float* __restrict__ res, float* __restrict__ gx) {
+    const int64_t idx = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
+    if (idx >= npix) return;
+    const int hw = h * w;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const int py = p / w, px = p - py * w;
+    const int64_t xbase = n * (int64_t)c * hw + p;
+    const int gw = w * POOL_W;
+    const int64_t ghw = (int64_t)hw * POOL_H * POOL_W;
+    const int64_t gbase = n * (int64_t)c * ghw + (int64_t)(py * POOL_H) * gw + px * POOL_W;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    const float m = mean[idx], r = rstd[idx];
+
+    auto load_g = [&](int k) -> float {
+        const float* g = gh + gbase + (int64_t)k * ghw;
+        float v = g[0];
+        if (POOL_W == 2) v += g[1];
+        if (POOL_H == 2) { v += g[gw]; if (POOL_W == 2) v += g[gw + 1]; }
+        return v;
+    };
+
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < c; ++k) {
+        float u = x[xbase + (int64_t)k * hw];
+        if (mp) u += mp[k];
+        const float hh = (u - m) * r;
+        const float g = load_g(k);
+        s1 += g;
+        s2 += g * hh;
+    }
+    const float a = s1 / (float)c;
+    const float b = s2 / (float)(unbiased ? c - 1 : c);
+    for (int k = 0; k < c; ++k) {
+        float u = x[xbase + (int64_t)k * hw];
+        if (mp) u += mp[k];
+        const float hh = (u - m) * r;
+        float v = r * (load_g(k) - a - hh * b);
+        if (res) v += res[xbase + (int64_t)k * hw];
+        gx[xbase + (int64_t)k * hw] = v;
+    }
+}
+
+extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+                          const float* mean, const float* rstd, int unbiased, int pool, const float* res, float* gx,
+                          void* stream) {
+    if (!gh || !x || !mean || !rstd || !gx || n <= 0 || c <= 0 || h <= 0 || w <= 0) return SDA_E_BADARG;
+    if (pool != 1 && pool != 2) return SDA_E_UNSUPPORTED;
+    const int64_t npix = (int64_t)n * h * w;
+    const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
+    if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    dim3 grid((unsigned)blocks), block(LN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (pool == 1) {
+        hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                           unbiased, res, gx);
+    } else if (h == 1) {   // 1-D net: only the length axis was upsampled
+        hipLaunchKernelGGL((ln_bwd_kernel<1, 2>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                           unbiased, res, gx);
+    } else {
+        hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                           unbiased, res, gx);
+    }
+    return sda_launch_status();
+}

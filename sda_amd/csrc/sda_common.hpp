@@ -1,0 +1,47 @@
+// Shared device helpers for libsda_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sda_hip.h"
+
+#define SDA_WAVE 64
+
+static inline int sda_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SDA_OK : (int)e;
+}
+
+// ---- activations (sda/utils.py:19-25) and their derivatives w.r.t. the pre-activation ----
+__host__ __device__ __forceinline__ float sda_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__host__ __device__ __forceinline__ float sda_act(int a, float v) {
+    switch (a) {
+        case SDA_ACT_SILU: return v * sda_sigmoid(v);
+        case SDA_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SDA_ACT_ELU:  return v > 0.f ? v : expm1f(v);
+        case SDA_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case SDA_ACT_SELU: return 1.0507009873554804934193349852946f *
+                                  (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
+        default: return v;
+    }
+}
+
+__host__ __device__ __forceinline__ float sda_dact(int a, float z) {
+    switch (a) {
+        case SDA_ACT_SILU: { float s = sda_sigmoid(z); return s * (1.0f + z * (1.0f - s)); }
+        case SDA_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case SDA_ACT_ELU:  return z > 0.f ? 1.f : expf(z);
+        case SDA_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) +
+                                  z * 0.39894228040143267794f * expf(-0.5f * z * z);
+        case SDA_ACT_SELU: return 1.0507009873554804934193349852946f *
+                                  (z > 0.f ? 1.f : 1.6732632423543772848170429916717f * expf(z));
+        default: return 1.f;
+    }
+}
+
+// 64-wide wavefront sum (CDNA wave = 64 lanes)
+__device__ __forceinline__ float sda_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, SDA_WAVE);
+    return v;
+}

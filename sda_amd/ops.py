@@ -1,0 +1,228 @@
+"""Thin torch-tensor wrappers over the C ABI (include/sda_hip.h).
+
+Every function launches a hand-written gfx950 kernel on the CURRENT torch stream.  There is no CPU path:
+tensors must live on a HIP device (`_dev()` raises otherwise).
+"""
+import ctypes
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT_IDS, ConvDesc
+
+CONV_CK = 8          # K-stage depth of conv_igemm (SDA_CONV_CK)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.SdaHipError('sda_amd ops run on MI355X only: got a CPU tensor (there is no CPU fallback)')
+        if t.dtype != torch.float32:
+            raise _lib.SdaHipError(f'sda_amd ops are fp32: got {t.dtype}')
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pick_mt(cout: int) -> int:
+    """cout tile = 32*mt; choose the mt in 1..4 that wastes the fewest padded output channels (ties: larger)."""
+    best, best_pad = 1, None
+    for mt in (4, 3, 2, 1):
+        pad = round_up(cout, 32 * mt)
+        if best_pad is None or pad < best_pad:
+            best, best_pad = mt, pad
+    return best
+
+
+def conv_out_size(size_v: int, k: int, stride: int) -> int:
+    return (size_v + 2 * (k // 2) - k) // stride + 1
+
+
+def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_inner=0, n_inner=1, x_n_off=0,
+                   w_ptr, cin_pad, cout_pad, cout, kh, kw, out_ptr, ho, wo, mt,
+                   stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
+                   ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
+                   act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None) -> ConvDesc:
+    d = ConvDesc()
+    d.x = x_ptr
+    d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
+    d.x_sc, d.x_sy, d.x_sx = x_sc, x_sy, x_sx
+    d.cx = cx
+    d.ctx, d.ctx_sn, d.cctx = ctx_ptr, ctx_sn, cctx
+    d.n, d.hs, d.ws = n, hs, ws
+    d.up_h, d.up_w, d.zins_h, d.zins_w = up_h, up_w, zins_h, zins_w
+    d.mod, d.mod_sn = mod_ptr, mod_sn
+    d.ln_mean, d.ln_rstd = ln_mean_ptr, ln_rstd_ptr
+    d.act_in = act_in
+    d.kh, d.kw, d.stride_h, d.stride_w, d.circular = kh, kw, stride_h, stride_w, int(bool(circular))
+    d.w, d.cin_pad, d.cout_pad = w_ptr, cin_pad, cout_pad
+    d.bias = bias_ptr
+    d.out, d.cout, d.ho, d.wo = out_ptr, cout, ho, wo
+    d.dact_z, d.act_d = dact_z_ptr, act_d
+    d.res = res_ptr
+    d.mt = mt
+    return d
+
+
+def conv_igemm(desc: ConvDesc):
+    lib = _lib.load()
+    _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
+
+
+class PackedConv:
+    """A conv layer's weights repacked for sda_conv_igemm (forward or backward-data form)."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor], transpose: bool = False, cin_keep: Optional[int] = None):
+        _dev(weight, bias)
+        lib = _lib.load()
+        w = weight.detach().contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        ks = tuple(w.shape[2:])
+        self.kh, self.kw = (1, ks[0]) if len(ks) == 1 else ks
+        if transpose:
+            keep = cin if cin_keep is None else cin_keep
+            self.k_real, self.m_real = cout, keep          # contraction over forward cout, produces forward cin
+        else:
+            keep = cin
+            self.k_real, self.m_real = cin, cout
+        self.mt = pick_mt(self.m_real)
+        self.k_pad = round_up(self.k_real, CONV_CK)
+        self.m_pad = round_up(self.m_real, 32 * self.mt)
+        self.packed = torch.empty(self.kh * self.kw * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
+        _lib.check(lib.sda_pack_conv_weight(w.data_ptr(), cout, cin, self.kh, self.kw, int(transpose), keep,
+                                            self.packed.data_ptr(), self.k_pad, self.m_pad, _stream()),
+                   'sda_pack_conv_weight')
+        self.bias = None if (bias is None or transpose) else bias.detach().contiguous()
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm pieces
+
+def ln_stats(x: Tensor, mod: Optional[Tensor], mod_sn: int, eps: float, unbiased: bool, mean: Tensor, rstd: Tensor):
+    """x: planar [n][c][hw] contiguous."""
+    _dev(x, mod, mean, rstd)
+    n, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    _lib.check(_lib.load().sda_ln_stats(x.data_ptr(), n, c, hw, _ptr(mod), mod_sn, eps, int(unbiased),
+                                        mean.data_ptr(), rstd.data_ptr(), _stream()), 'sda_ln_stats')
+
+
+def ln_apply(x: Tensor, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: Tensor, y: Tensor):
+    _dev(x, mod, mean, rstd, y)
+    n, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    _lib.check(_lib.load().sda_ln_apply(x.data_ptr(), n, c, hw, _ptr(mod), mod_sn, mean.data_ptr(), rstd.data_ptr(),
+                                        y.data_ptr(), _stream()), 'sda_ln_apply')
+
+
+def ln_bwd(gh: Tensor, x: Tensor, h: int, w: int, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: Tensor,
+           unbiased: bool, pool: int, res: Optional[Tensor], gx: Tensor):
+    _dev(gh, x, mod, mean, rstd, res, gx)
+    n, c = x.shape[0], x.shape[1]
+    _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
+                                      rstd.data_ptr(), int(unbiased), pool, _ptr(res), gx.data_ptr(), _stream()),
+               'sda_ln_bwd')
+
+
+# ------------------------------------------------------------------------------------------ time embedding
+
+def time_embed(t: Tensor, freqs: Tensor, w0: Tensor, b0: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    _dev(t, freqs, w0, b0, w2, b2)
+    nt = t.numel()
+    e = w2.shape[0]
+    emb = torch.empty(nt, e, device=t.device, dtype=torch.float32)
+    _lib.check(_lib.load().sda_time_embed(t.data_ptr(), nt, freqs.data_ptr(), freqs.numel(), w0.data_ptr(), b0.data_ptr(),
+                                          w0.shape[0], w2.data_ptr(), b2.data_ptr(), e, emb.data_ptr(), _stream()),
+               'sda_time_embed')
+    return emb
+
+
+def linear_small(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    _dev(x, w, b)
+    rows, in_f = x.shape
+    out_f = w.shape[0]
+    y = torch.empty(rows, out_f, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().sda_linear_small(x.data_ptr(), rows, in_f, w.data_ptr(), b.data_ptr(), out_f, y.data_ptr(),
+                                            _stream()), 'sda_linear_small')
+    return y
+
+
+# ------------------------------------------------------------------------------------------ fold / unfold adjoints
+
+def fold(s: Tensor, b: int, nw: int, k: int, c: int, hw: int, out: Tensor):
+    _dev(s, out)
+    _lib.check(_lib.load().sda_fold(s.data_ptr(), b, nw, k, c, hw, out.data_ptr(), _stream()), 'sda_fold')
+
+
+def fold_adjoint(g_out: Tensor, b: int, nw: int, k: int, c: int, hw: int, g_s: Tensor):
+    _dev(g_out, g_s)
+    _lib.check(_lib.load().sda_fold_adjoint(g_out.data_ptr(), b, nw, k, c, hw, g_s.data_ptr(), _stream()),
+               'sda_fold_adjoint')
+
+
+def unfold_adjoint(g_win: Tensor, b: int, nw: int, k: int, c: int, hw: int, win_c_total: int, g_x: Tensor):
+    _dev(g_win, g_x)
+    _lib.check(_lib.load().sda_unfold_adjoint(g_win.data_ptr(), b, nw, k, c, hw, win_c_total, g_x.data_ptr(), _stream()),
+               'sda_unfold_adjoint')
+
+
+# ------------------------------------------------------------------------------------------ PC updates / guidance
+
+def pc_predict(x: Tensor, eps: Tensor, r: float, c1: float, coef_dev: Optional[Tensor] = None):
+    _dev(x, eps, coef_dev)
+    _lib.check(_lib.load().sda_pc_predict(x.data_ptr(), eps.data_ptr(), x.numel(), r, c1, _ptr(coef_dev), _stream()),
+               'sda_pc_predict')
+
+
+SUMSQ_CHUNKS = 64
+
+
+def sumsq_partial(eps: Tensor, b: int, partial: Tensor):
+    _dev(eps, partial)
+    per = eps.numel() // b
+    _lib.check(_lib.load().sda_sumsq_partial(eps.data_ptr(), b, per, partial.data_ptr(), SUMSQ_CHUNKS, _stream()),
+               'sda_sumsq_partial')
+
+
+def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: float, sigma: float,
+               coef_dev: Optional[Tensor] = None):
+    _dev(x, eps, z, partial, coef_dev)
+    per = x.numel() // b
+    _lib.check(_lib.load().sda_pc_correct(x.data_ptr(), eps.data_ptr(), z.data_ptr(), b, per, partial.data_ptr(),
+                                          SUMSQ_CHUNKS, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
+
+
+def _coef(mu, sigma):
+    """python floats travel by value; 0-dim device tensors travel as a device {mu, sigma} pair (no host sync)."""
+    if isinstance(mu, Tensor) or isinstance(sigma, Tensor):
+        dev = mu.device if isinstance(mu, Tensor) else sigma.device
+        pair = torch.stack([torch.as_tensor(mu, dtype=torch.float32, device=dev).reshape(()),
+                            torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(())])
+        return 0.0, 0.0, pair
+    return float(mu), float(sigma), None
+
+
+def denoise(x: Tensor, eps: Tensor, mu, sigma, xhat: Tensor):
+    _dev(x, eps, xhat)
+    m, s, pair = _coef(mu, sigma)
+    _lib.check(_lib.load().sda_denoise(x.data_ptr(), eps.data_ptr(), x.numel(), m, s, _ptr(pair), xhat.data_ptr(),
+                                       _stream()), 'sda_denoise')
+
+
+def guided_combine(eps: Tensor, ghat: Tensor, vjp: Optional[Tensor], mu, sigma, out: Tensor):
+    _dev(eps, ghat, vjp, out)
+    m, s, pair = _coef(mu, sigma)
+    _lib.check(_lib.load().sda_guided_combine(eps.data_ptr(), ghat.data_ptr(), _ptr(vjp), eps.numel(), m, s, _ptr(pair),
+                                              out.data_ptr(), _stream()), 'sda_guided_combine')
