@@ -1,0 +1,510 @@
+"""Executor of the modulated residual U-Net on MI355X: forward and backward-data (VJP w.r.t. the input).
+
+It sequences the gfx950 kernels of libsda_hip.so for the reference's ``UNet.forward`` (sda/nn.py:184-206) and for
+the gradient torch.autograd would propagate through it at sda/score.py:394 (guidance needs d/dx only -- no weight
+gradients are ever formed).
+
+Layout: every internal activation is PLANAR ``[n][c][h][w]`` fp32 (1-D nets: ``h = 1``).  Per residual block the
+forward runs three kernels and materialises two tensors:
+
+    stats(a)                     -> mean, rstd              (channel LayerNorm statistics of a + mod)
+    conv1(LN(a + mod)) + b1      -> z                       (LN + modulation applied inside the conv loader)
+    conv2(act(z)) + b2 + a       -> a'                      (activation in the loader, residual in the epilogue)
+
+so only ``a`` (block input) and ``z`` (pre-activation) are saved for the VJP, which is again three kernels:
+
+    conv2^T(g) * act'(z)         -> gz
+    conv1^T(gz)                  -> gh
+    g + LN_bwd(gh; a, mod, mean, rstd) -> g'
+
+The image axis is processed in chunks sized from free HBM (288 GB on MI355X); when a VJP is requested for more
+images than can keep their activations resident, the forward is recomputed chunk by chunk inside the backward
+("activation memory under guidance").
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from ._lib import SdaHipError
+from .ops import PackedConv, conv_out_size, make_conv_desc
+
+# fraction of currently-unallocated HBM one chunk's activations may occupy
+CHUNK_HBM_FRACTION = 0.45
+_warned_training = False
+
+
+@dataclass
+class Source:
+    """How the first convolution reads its input: a strided view (possibly the sliding-window view of a
+    trajectory, score.py:146-153) plus optional broadcast context channels (score.py:87)."""
+    x: Tensor
+    n: int
+    cx: int
+    hs: int
+    ws: int
+    sn_outer: int
+    sc: int
+    sy: int
+    sx: int
+    sn_inner: int = 0
+    n_inner: int = 1
+    ctx: Optional[Tensor] = None
+    cctx: int = 0
+    ctx_sn: int = 0
+
+
+def planar_source(a: Tensor) -> dict:
+    n, c, h, w = a.shape
+    return dict(x_ptr=a.data_ptr(), n=n, cx=c, hs=h, ws=w, x_sn_outer=c * h * w, x_sc=h * w, x_sy=w, x_sx=1)
+
+
+class _ConvCache:
+    """Packed (forward / backward-data) weights of one nn.ConvNd, rebuilt when the parameter changes."""
+
+    def __init__(self, conv: nn.Module):
+        if conv.dilation != (1,) * len(conv.dilation) or conv.groups != 1:
+            raise NotImplementedError('dilated / grouped convolutions have no gfx950 kernel')
+        if conv.padding_mode not in ('zeros', 'circular'):
+            raise NotImplementedError(f"padding_mode={conv.padding_mode!r} (supported: 'zeros', 'circular')")
+        ks = conv.kernel_size
+        if any(k % 2 == 0 for k in ks):
+            raise NotImplementedError('even kernel sizes are not supported')
+        self.conv = conv
+        self.kh, self.kw = (1, ks[0]) if len(ks) == 1 else ks
+        st = conv.stride
+        self.sh, self.sw = (1, st[0]) if len(st) == 1 else st
+        self.circular = conv.padding_mode == 'circular'
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self._key = None
+        self._fwd = None
+        self._bwd = {}
+
+    def _sync(self):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, str(w.device), None if self.conv.bias is None else self.conv.bias._version)
+        if key != self._key:
+            self._key, self._fwd, self._bwd = key, None, {}
+
+    def fwd(self) -> PackedConv:
+        self._sync()
+        if self._fwd is None:
+            self._fwd = PackedConv(self.conv.weight, self.conv.bias, transpose=False)
+        return self._fwd
+
+    def bwd(self, cin_keep: Optional[int] = None) -> PackedConv:
+        self._sync()
+        if cin_keep not in self._bwd:
+            self._bwd[cin_keep] = PackedConv(self.conv.weight, None, transpose=True, cin_keep=cin_keep)
+        return self._bwd[cin_keep]
+
+
+def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, circular: bool, stride=(1, 1), up=(1, 1),
+                zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
+                ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
+                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0):
+    d = make_conv_desc(**src, w_ptr=pk.packed.data_ptr(), cin_pad=pk.k_pad, cout_pad=pk.m_pad, cout=pk.m_real,
+                       kh=pk.kh, kw=pk.kw, out_ptr=out.data_ptr(), ho=ho, wo=wo, mt=pk.mt,
+                       stride_h=stride[0], stride_w=stride[1], circular=circular, up_h=up[0], up_w=up[1],
+                       zins_h=zins[0], zins_w=zins[1],
+                       ctx_ptr=None if ctx is None else ctx.data_ptr(), cctx=cctx, ctx_sn=ctx_sn,
+                       mod_ptr=None if mod is None else mod.data_ptr(), mod_sn=mod_sn,
+                       ln_mean_ptr=None if ln is None else ln[0].data_ptr(),
+                       ln_rstd_ptr=None if ln is None else ln[1].data_ptr(),
+                       act_in=act_in, bias_ptr=None if bias is None else bias.data_ptr(),
+                       dact_z_ptr=None if dact_z is None else dact_z.data_ptr(), act_d=act_d,
+                       res_ptr=None if res is None else res.data_ptr())
+    ops.conv_igemm(d)
+
+
+class _Block:
+    def __init__(self, block, width: int, mod_off: int):
+        from .nn import LayerNorm, activation_id
+        residue = block.residue
+        if not (len(residue) == 4 and isinstance(residue[0], LayerNorm)):
+            raise NotImplementedError('unexpected residue structure')
+        self.ln = residue[0]
+        self.conv1 = _ConvCache(residue[1])
+        self.act = activation_id(residue[2])
+        self.conv2 = _ConvCache(residue[3])
+        self.project = block.project[0]
+        self.width = width
+        self.mod_off = mod_off
+
+
+class _Level:
+    pass
+
+
+class UNetEngine:
+    def __init__(self, unet):
+        from .nn import LN_UNBIASED
+        if unet.spatial not in (1, 2):
+            raise NotImplementedError('spatial=3 U-Nets have no gfx950 kernels (no reference experiment uses them)')
+        self.unet = unet
+        self.unbiased = LN_UNBIASED
+        self.depth = len(unet.hidden_blocks)
+        D = self.depth
+        self.levels: List[_Level] = []
+        off = 0
+        for lvl in range(D):
+            lev = _Level()
+            lev.C = unet.hidden_channels[lvl]
+            j = D - 1 - lvl                                  # tails / ascent are stored deepest first (nn.py:179-182)
+            head = unet.heads[lvl] if lvl == 0 else unet.heads[lvl][0]
+            lev.head = _ConvCache(head)
+            if lvl == 0:
+                lev.tail = _ConvCache(unet.tails[j])
+                lev.tail_ln = None
+            else:
+                lev.tail_ln = unet.tails[j][0]
+                lev.tail = _ConvCache(unet.tails[j][2])
+            lev.descent, lev.ascent = [], []
+            for blk in unet.descent[lvl]:
+                lev.descent.append(_Block(blk, lev.C, off)); off += lev.C
+            for blk in unet.ascent[j]:
+                lev.ascent.append(_Block(blk, lev.C, off)); off += lev.C
+            self.levels.append(lev)
+        self.mod_total = off
+        self._proj_key = None
+        self._proj = None
+        st = unet.stride
+        self.sh, self.sw = (1, st[0]) if len(st) == 1 else st
+
+    # -------------------------------------------------------------------------------- modulation vectors
+    def _blocks(self):
+        for lev in self.levels:
+            yield from lev.descent
+            yield from lev.ascent
+
+    def projection(self):
+        """All blocks' ``project`` Linears concatenated row-wise: one small kernel gives every modulation vector."""
+        key = tuple((b.project.weight.data_ptr(), b.project.weight._version, b.project.bias._version) for b in self._blocks())
+        if key != self._proj_key:
+            blocks = sorted(self._blocks(), key=lambda b: b.mod_off)
+            w = torch.cat([b.project.weight.detach() for b in blocks], dim=0).contiguous()
+            bias = torch.cat([b.project.bias.detach() for b in blocks], dim=0).contiguous()
+            self._proj_key, self._proj = key, (w, bias)
+        return self._proj
+
+    def modulation(self, emb: Tensor) -> Tensor:
+        """emb: (T, mod_features) -> (T, mod_total)."""
+        w, b = self.projection()
+        return ops.linear_small(emb.contiguous(), w, b)
+
+    # -------------------------------------------------------------------------------- memory planning
+    def bytes_per_image(self, hs: int, ws: int, save: bool) -> int:
+        total, h, w = 0, hs, ws
+        for lvl, lev in enumerate(self.levels):
+            if lvl > 0:
+                h = conv_out_size(h, lev.head.kh, lev.head.sh)
+                w = conv_out_size(w, lev.head.kw, lev.head.sw)
+            plane = lev.C * h * w * 4
+            nblk = len(lev.descent) + len(lev.ascent)
+            total += plane * ((2 * nblk + 4) if save else 5)
+        return total
+
+    def chunk_size(self, n: int, hs: int, ws: int, save: bool, device) -> int:
+        total = torch.cuda.get_device_properties(device).total_memory
+        avail = max(total - torch.cuda.memory_allocated(device), total // 8)
+        per = max(self.bytes_per_image(hs, ws, save), 1)
+        return int(max(1, min(n, (avail * CHUNK_HBM_FRACTION) // per)))
+
+    # -------------------------------------------------------------------------------- forward
+    def _mod_for(self, blk: _Block, mod_all: Optional[Tensor], lo: int, per_image: bool):
+        if mod_all is None:
+            return None, 0
+        row = mod_all[lo:] if per_image else mod_all
+        return row[:, blk.mod_off:], (self.mod_total if per_image else 0)
+
+    def _block_fwd(self, blk: _Block, a: Tensor, mod_all, lo, per_image, saved):
+        n, c, h, w = a.shape
+        dev = a.device
+        mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
+        mean = torch.empty(n * h * w, device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ops.ln_stats(a, mod, mod_sn, blk.ln.eps, self.unbiased, mean, rstd)
+        z = torch.empty_like(a)
+        c1 = blk.conv1
+        pk = c1.fwd()
+        launch_conv(pk, planar_source(a), z, h, w, circular=c1.circular, bias=pk.bias, mod=mod, mod_sn=mod_sn,
+                    ln=(mean, rstd))
+        y = torch.empty_like(a)
+        c2 = blk.conv2
+        pk = c2.fwd()
+        launch_conv(pk, planar_source(z), y, h, w, circular=c2.circular, bias=pk.bias, act_in=blk.act, res=a)
+        if saved is not None:
+            saved.append((a, mean, rstd, z))
+        return y
+
+    def forward_chunk(self, src: Source, lo: int, hi: int, mod_all: Optional[Tensor], per_image: bool, out: Tensor,
+                      save: bool):
+        """Images [lo, hi) of ``src`` -> ``out`` (n, out_channels, h, w).  Returns what the VJP needs (or None)."""
+        n = hi - lo
+        dev = out.device
+        L, D = self.levels, self.depth
+        saved = dict(blocks={}, tails={}, dims=[]) if save else None
+        skips, dims = [], []
+        a, h, w = None, src.hs, src.ws
+        for lvl, lev in enumerate(L):
+            hd = lev.head
+            pk = hd.fwd()
+            if lvl == 0:
+                ho, wo = conv_out_size(h, hd.kh, hd.sh), conv_out_size(w, hd.kw, hd.sw)
+                a = torch.empty(n, lev.C, ho, wo, device=dev, dtype=torch.float32)
+                sdesc = dict(x_ptr=src.x.data_ptr(), n=n, cx=src.cx, hs=src.hs, ws=src.ws, x_sn_outer=src.sn_outer,
+                             x_sn_inner=src.sn_inner, n_inner=src.n_inner, x_n_off=lo, x_sc=src.sc, x_sy=src.sy,
+                             x_sx=src.sx)
+                ctx = src.ctx
+                if ctx is not None and src.ctx_sn:
+                    ctx = ctx[lo * src.ctx_sn:]
+                launch_conv(pk, sdesc, a, ho, wo, circular=hd.circular, stride=(hd.sh, hd.sw), bias=pk.bias, ctx=ctx,
+                            cctx=src.cctx, ctx_sn=src.ctx_sn)
+            else:
+                ho, wo = conv_out_size(h, hd.kh, hd.sh), conv_out_size(w, hd.kw, hd.sw)
+                a2 = torch.empty(n, lev.C, ho, wo, device=dev, dtype=torch.float32)
+                launch_conv(pk, planar_source(a), a2, ho, wo, circular=hd.circular, stride=(hd.sh, hd.sw), bias=pk.bias)
+                a = a2
+            h, w = ho, wo
+            dims.append((h, w))
+            for bi, blk in enumerate(lev.descent):
+                rec = [] if save else None
+                a = self._block_fwd(blk, a, mod_all, lo, per_image, rec)
+                if save:
+                    saved['blocks'][('d', lvl, bi)] = rec[0]
+            skips.append(a)
+        skips.pop()
+        for lvl in reversed(range(D)):
+            lev = L[lvl]
+            for bi, blk in enumerate(lev.ascent):
+                rec = [] if save else None
+                a = self._block_fwd(blk, a, mod_all, lo, per_image, rec)
+                if save:
+                    saved['blocks'][('a', lvl, bi)] = rec[0]
+            tl = lev.tail
+            pk = tl.fwd()
+            if lvl > 0:
+                hu, wu = dims[lvl - 1]
+                uh, uw = L[lvl].head.sh, L[lvl].head.sw
+                if (h * uh, w * uw) != (hu, wu):
+                    raise SdaHipError(f'U-Net level {lvl}: upsampled size {(h * uh, w * uw)} != skip size {(hu, wu)} '
+                                      f'(spatial sizes must be divisible by the strides, as in the reference)')
+                mean = torch.empty(n * h * w, device=dev, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                ops.ln_stats(a, None, 0, lev.tail_ln.eps, self.unbiased, mean, rstd)
+                t = torch.empty(n, L[lvl - 1].C, hu, wu, device=dev, dtype=torch.float32)
+                launch_conv(pk, planar_source(a), t, hu, wu, circular=tl.circular, up=(uh, uw), bias=pk.bias,
+                            ln=(mean, rstd), res=skips.pop())
+                if save:
+                    saved['tails'][lvl] = (a, mean, rstd)
+                a, h, w = t, hu, wu
+            else:
+                launch_conv(pk, planar_source(a), out, h, w, circular=tl.circular, bias=pk.bias)
+        if save:
+            saved['dims'] = dims
+        return saved
+
+    # -------------------------------------------------------------------------------- backward-data
+    def _block_bwd(self, blk: _Block, g: Tensor, rec, mod_all, lo, per_image):
+        a, mean, rstd, z = rec
+        n, c, h, w = a.shape
+        mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
+        gz = torch.empty_like(a)
+        c2 = blk.conv2
+        launch_conv(c2.bwd(), planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act)
+        gh = torch.empty_like(a)
+        c1 = blk.conv1
+        launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular)
+        gx = torch.empty_like(a)
+        ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, 1, g, gx)
+        return gx
+
+    def backward_chunk(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
+        """g_out: (n, out_channels, h, w) -> g_in: (n, src.cx, hs, ws)   (context-channel gradients are not formed)."""
+        L, D = self.levels, self.depth
+        dims = saved['dims']
+        n = g_out.shape[0]
+        dev = g_out.device
+        h, w = dims[0]
+        tl = L[0].tail
+        g = torch.empty(n, L[0].C, h, w, device=dev, dtype=torch.float32)
+        launch_conv(tl.bwd(), planar_source(g_out), g, h, w, circular=tl.circular)
+        g_skip = {}
+        for lvl in range(D):
+            lev = L[lvl]
+            if lvl > 0:
+                # g: gradient of (tail_lvl(a) + skip_{lvl-1}) at level lvl-1 resolution
+                g_skip[lvl - 1] = g
+                hu, wu = dims[lvl - 1]
+                h, w = dims[lvl]
+                uh, uw = lev.head.sh, lev.head.sw
+                if (uh, uw) not in ((2, 2), (1, 2)):
+                    raise NotImplementedError('VJP through Upsample is implemented for scale factor 2')
+                tl = lev.tail
+                ghup = torch.empty(n, lev.C, hu, wu, device=dev, dtype=torch.float32)
+                launch_conv(tl.bwd(), planar_source(g), ghup, hu, wu, circular=tl.circular)
+                a, mean, rstd = saved['tails'][lvl]
+                g = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
+                ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, 2, None, g)
+            for bi in reversed(range(len(lev.ascent))):
+                g = self._block_bwd(lev.ascent[bi], g, saved['blocks'][('a', lvl, bi)], mod_all, lo, per_image)
+        for lvl in reversed(range(D)):
+            lev = L[lvl]
+            for bi in reversed(range(len(lev.descent))):
+                g = self._block_bwd(lev.descent[bi], g, saved['blocks'][('d', lvl, bi)], mod_all, lo, per_image)
+            hd = lev.head
+            if lvl > 0:
+                hu, wu = dims[lvl - 1]
+                if hd.circular and ((hd.sh > 1 and hu % hd.sh) or (hd.sw > 1 and wu % hd.sw)):
+                    raise NotImplementedError('VJP of a strided circular conv needs sizes divisible by the stride')
+                g2 = torch.empty(n, L[lvl - 1].C, hu, wu, device=dev, dtype=torch.float32)
+                launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw),
+                            res=g_skip.pop(lvl - 1))
+                g = g2
+            else:
+                launch_conv(hd.bwd(cin_keep=src.cx), planar_source(g), g_in, src.hs, src.ws, circular=hd.circular,
+                            zins=(hd.sh, hd.sw))
+
+
+# ------------------------------------------------------------------------------------------ autograd glue
+
+class _UNetFunction(torch.autograd.Function):
+    """out[n] = UNet(src[n], mod) with a hand-written VJP w.r.t. ``x`` only."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, engine: UNetEngine, src: Source, mod_all, per_image: bool, out_channels: int):
+        need = ctx.needs_input_grad[0]
+        dev = x.device
+        n = src.n
+        # output spatial size of level 0
+        hd = engine.levels[0].head
+        ho, wo = conv_out_size(src.hs, hd.kh, hd.sh), conv_out_size(src.ws, hd.kw, hd.sw)
+        out = torch.empty(n, out_channels, ho, wo, device=dev, dtype=torch.float32)
+        ctx.engine, ctx.src, ctx.mod_all, ctx.per_image = engine, src, mod_all, per_image
+        ctx.saved_acts = None
+        ctx.x_shape = x.shape
+        if need:
+            chunk_save = engine.chunk_size(n, src.hs, src.ws, True, dev)
+            if chunk_save >= n:
+                ctx.saved_acts = engine.forward_chunk(src, 0, n, mod_all, per_image, out, True)
+                return out
+        chunk = engine.chunk_size(n, src.hs, src.ws, False, dev)
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            engine.forward_chunk(src, lo, hi, mod_all, per_image, out[lo:hi], False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: Tensor):
+        engine, src = ctx.engine, ctx.src
+        g_out = g_out.contiguous()
+        n = src.n
+        dev = g_out.device
+        g_in = torch.empty(n, src.cx, src.hs, src.ws, device=dev, dtype=torch.float32)
+        if ctx.saved_acts is not None:
+            engine.backward_chunk(ctx.saved_acts, g_out, src, 0, ctx.mod_all, ctx.per_image, g_in)
+        else:   # recompute chunk by chunk (activations of all images do not fit HBM at once)
+            chunk = engine.chunk_size(n, src.hs, src.ws, True, dev)
+            scratch = torch.empty(min(chunk, n), g_out.shape[1], g_out.shape[2], g_out.shape[3], device=dev,
+                                  dtype=torch.float32)
+            for lo in range(0, n, chunk):
+                hi = min(n, lo + chunk)
+                saved = engine.forward_chunk(src, lo, hi, ctx.mod_all, ctx.per_image, scratch[:hi - lo], True)
+                engine.backward_chunk(saved, g_out[lo:hi], src, lo, ctx.mod_all, ctx.per_image, g_in[lo:hi])
+                del saved
+        return g_in.reshape(ctx.x_shape), None, None, None, None, None
+
+
+def run_unet(unet, src: Source, emb: Tensor, grad_anchor: Tensor) -> Tensor:
+    """Common entry: ``emb`` (T, mod_features) with T in {1, n}; returns (n, out_channels, h, w)."""
+    global _warned_training
+    engine = unet.engine()
+    T = emb.shape[0]
+    if T not in (1, src.n):
+        raise SdaHipError(f'time embedding batch {T} does not broadcast against {src.n} images')
+    per_image = T != 1
+    mod_all = engine.modulation(emb) if engine.mod_total > 0 else None
+    if torch.is_grad_enabled() and not grad_anchor.requires_grad and not _warned_training:
+        if any(p.requires_grad for p in unet.parameters()):
+            _warned_training = True
+            import warnings
+            warnings.warn('sda_amd implements the sampling hot path: gradients flow to the network INPUT only; '
+                          'parameter gradients (training) are out of scope and are not computed.')
+    return _UNetFunction.apply(grad_anchor, engine, src, mod_all, per_image, unet.out_channels)
+
+
+def source_from_tensor(x: Tensor, spatial: int):
+    """(…, C, *spatial) strided tensor -> (Source fields, n).  Collapses the batch dims without copying if possible."""
+    dims = spatial + 1
+    batch = x.shape[:-dims]
+    n = 1
+    for b in batch:
+        n *= b
+    # try to express the batch dims with a single stride
+    xv = x
+    if len(batch) != 1:
+        try:
+            xv = x.view(n, *x.shape[-dims:])
+        except RuntimeError:
+            xv = x.reshape(n, *x.shape[-dims:])     # copies only when the batch dims are not collapsible
+    c = xv.shape[1]
+    if spatial == 1:
+        hs, ws = 1, xv.shape[2]
+        sy, sx = 0, xv.stride(2)
+    else:
+        hs, ws = xv.shape[2], xv.shape[3]
+        sy, sx = xv.stride(2), xv.stride(3)
+    return xv, Source(x=xv, n=n, cx=c, hs=hs, ws=ws, sn_outer=xv.stride(0) if n > 1 else 0, sc=xv.stride(1), sy=sy, sx=sx)
+
+
+def attach_context(src: Source, c: Optional[Tensor], spatial: int):
+    """Context channels (score.py:87): broadcast over the batch when possible, else one block per image."""
+    if c is None:
+        return
+    dims = spatial + 1
+    cc = c.shape[-dims]
+    per = 1
+    for s in c.shape[-dims:]:
+        per *= s
+    if tuple(c.shape[-spatial:]) != ((src.ws,) if spatial == 1 else (src.hs, src.ws)):
+        raise SdaHipError('context spatial shape does not match x')
+    if c.numel() == per:
+        src.ctx, src.cctx, src.ctx_sn = c.reshape(-1).contiguous(), cc, 0
+    else:
+        full = c.expand(*src.x.shape[:1], *c.shape[-dims:]) if c.dim() == dims + 1 else None
+        if full is None or full.shape[0] != src.n:
+            raise SdaHipError('context batch shape must be broadcast-free or match the flattened batch of x')
+        src.ctx, src.cctx, src.ctx_sn = full.contiguous().reshape(-1), cc, per
+
+
+def unet_apply(unet, x: Tensor, y: Tensor) -> Tensor:
+    """``UNet.forward(x, y)`` (nn.py:184-206): x (N, C, *spatial), y (N|1, mod_features)."""
+    ops._dev(x, y)
+    xv, src = source_from_tensor(x, unet.spatial)
+    out = run_unet(unet, src, y.reshape(-1, y.shape[-1]), x)
+    return out if unet.spatial == 2 else out[:, :, 0]
+
+
+def block_forward_standalone(block, x: Tensor, y: Tensor) -> Tensor:
+    """``ModResidualBlock.forward`` outside a U-Net (nn.py:27-28): same three kernels as inside the engine."""
+    ops._dev(x, y)
+    spatial = x.dim() - 2
+    if spatial not in (1, 2):
+        raise NotImplementedError
+    xs = x.contiguous()
+    a = xs if spatial == 2 else xs.unsqueeze(2)
+    n, c = a.shape[:2]
+    eng = UNetEngine.__new__(UNetEngine)
+    from .nn import LN_UNBIASED
+    eng.unbiased, eng.mod_total = LN_UNBIASED, c
+    blk = _Block(block, c, 0)
+    lin = blk.project
+    mod = ops.linear_small(y.reshape(-1, y.shape[-1]).contiguous(), lin.weight.detach().contiguous(),
+                           lin.bias.detach().contiguous())
+    if mod.shape[0] not in (1, n):
+        raise SdaHipError('modulation batch does not broadcast')
+    out = eng._block_fwd(blk, a.contiguous(), mod, 0, mod.shape[0] != 1, None)
+    return out if spatial == 2 else out[:, :, 0]

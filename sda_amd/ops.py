@@ -82,12 +82,17 @@ def conv_igemm(desc: ConvDesc):
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 
+def pack_conv_weight(w: Tensor, cout: int, cin: int, kh: int, kw: int, transpose: bool, keep: int, dst: Tensor,
+                     k_pad: int, m_pad: int):
+    _lib.check(_lib.load().sda_pack_conv_weight(w.data_ptr(), cout, cin, kh, kw, int(transpose), keep, dst.data_ptr(),
+                                                k_pad, m_pad, _stream()), 'sda_pack_conv_weight')
+
+
 class PackedConv:
     """A conv layer's weights repacked for sda_conv_igemm (forward or backward-data form)."""
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor], transpose: bool = False, cin_keep: Optional[int] = None):
         _dev(weight, bias)
-        lib = _lib.load()
         w = weight.detach().contiguous()
         cout, cin = w.shape[0], w.shape[1]
         ks = tuple(w.shape[2:])
@@ -102,9 +107,7 @@ class PackedConv:
         self.k_pad = round_up(self.k_real, CONV_CK)
         self.m_pad = round_up(self.m_real, 32 * self.mt)
         self.packed = torch.empty(self.kh * self.kw * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
-        _lib.check(lib.sda_pack_conv_weight(w.data_ptr(), cout, cin, self.kh, self.kw, int(transpose), keep,
-                                            self.packed.data_ptr(), self.k_pad, self.m_pad, _stream()),
-                   'sda_pack_conv_weight')
+        pack_conv_weight(w, cout, cin, self.kh, self.kw, transpose, keep, self.packed, self.k_pad, self.m_pad)
         self.bias = None if (bias is None or transpose) else bias.detach().contiguous()
 
 

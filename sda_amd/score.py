@@ -1,0 +1,409 @@
+r"""Score modules -- MI355X host-side mirror of the reference's ``sda/score.py``.
+
+Same classes, constructor / ``forward`` / ``sample`` signatures, attributes and ``state_dict`` keys as the
+reference (sda/score.py:15-396), so ``experiments/{lorenz,kolmogorov}`` run with ``import sda_amd as sda``.
+What differs is where the arithmetic happens: the score evaluation (U-Net, window unfold/fold), the
+predictor-corrector updates and the guidance glue run as hand-written gfx950 kernels (libsda_hip.so);
+torch is used for device memory, the RNG streams (same calls in the same order as the reference) and for
+differentiating a user-supplied observation operator ``A``.  No CPU path exists: CPU tensors raise.
+"""
+
+import math
+from typing import Callable, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Size, Tensor
+from tqdm import tqdm
+
+from . import ops
+from ._lib import SdaHipError
+from .engine import Source, attach_context, run_unet, source_from_tensor
+from .nn import *  # noqa: F401,F403  (the reference re-exports its nn module the same way, score.py:12)
+from .nn import ResMLP, UNet
+
+
+def broadcast(*tensors: Tensor, ignore: Union[int, list] = 0):
+    r"""Broadcasts tensors together except their last ``ignore`` dims (zuko.utils.broadcast; shape-only)."""
+    if type(ignore) is int:
+        ignore = [ignore] * len(tensors)
+    split = [t.dim() - i for t, i in zip(tensors, ignore)]
+    common = torch.broadcast_shapes(*(t.shape[:s] for t, s in zip(tensors, split)))
+    return [torch.broadcast_to(t, common + t.shape[s:]) for t, s in zip(tensors, split)]
+
+
+class TimeEmbedding(nn.Sequential):
+    r"""[cos(pi j t), sin(pi j t)]_{j=1..16} -> Linear(32,256) -> SiLU -> Linear(256, features)  (score.py:15-35)."""
+
+    def __init__(self, features: int):
+        super().__init__(nn.Linear(32, 256), nn.SiLU(), nn.Linear(256, features))
+        self.register_buffer('freqs', torch.pi * torch.arange(1, 16 + 1))
+
+    def forward(self, t: Tensor) -> Tensor:
+        ops._dev(t)
+        shape = t.shape
+        emb = ops.time_embed(t.reshape(-1).contiguous(), self.freqs, self[0].weight.detach(), self[0].bias.detach(),
+                             self[2].weight.detach(), self[2].bias.detach())
+        return emb.reshape(*shape, -1)
+
+
+class ScoreNet(nn.Module):
+    r"""Score network on flat feature vectors: ResMLP over cat(x, emb(t)[, c])  (score.py:38-63)."""
+
+    def __init__(self, features: int, context: int = 0, embedding: int = 16, **kwargs):
+        super().__init__()
+        self.embedding = TimeEmbedding(embedding)
+        self.network = ResMLP(features + context + embedding, features, **kwargs)
+
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        emb = self.embedding(t)
+        if c is None:
+            x, emb = broadcast(x, emb, ignore=1)
+            feats = torch.cat((x, emb), dim=-1)
+        else:
+            x, emb, c = broadcast(x, emb, c, ignore=1)
+            feats = torch.cat((x, emb, c), dim=-1)
+        return self.network(feats)
+
+
+class ScoreUNet(nn.Module):
+    r"""U-Net score network (score.py:66-93): context channels concatenated, batch dims flattened, t embedded."""
+
+    def __init__(self, channels: int, context: int = 0, embedding: int = 64, **kwargs):
+        super().__init__()
+        self.embedding = TimeEmbedding(embedding)
+        self.network = UNet(channels + context, channels, embedding, **kwargs)
+
+    def _context(self, c: Optional[Tensor]) -> Optional[Tensor]:
+        """Hook for subclasses that inject their own context (e.g. the Kolmogorov forcing channel)."""
+        return c
+
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        c = self._context(c)
+        ops._dev(x, t, c)
+        spatial = self.network.spatial
+        xv, src = source_from_tensor(x, spatial)
+        attach_context(src, c, spatial)
+        emb = self.embedding(t.reshape(-1))
+        out = run_unet(self.network, src, emb, x)
+        return out.reshape(x.shape)
+
+
+class MCScoreWrapper(nn.Module):
+    r"""Disguises a `ScoreUNet` as a score network for a Markov chain (score.py:96-110).
+
+    The (B, L, C) <-> (B, C, L) transposes stay views: the first convolution reads the trajectory through its
+    strides."""
+
+    def __init__(self, score: nn.Module):
+        super().__init__()
+        self.score = score
+
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        return self.score(x.transpose(1, 2), t, c).transpose(1, 2)
+
+
+class _MCScoreFunction(torch.autograd.Function):
+    """fold(kernel(unfold(x))) for a U-Net kernel without materialising the unfolded tensor (score.py:134-164).
+
+    Forward: the head convolution reads windows straight out of x through a two-level batch stride; the tail's output
+    goes through the selective-gather ``fold`` kernel.  Backward: fold adjoint -> U-Net VJP -> overlapping-window
+    unfold adjoint (the one place overlaps sum)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, kernel: 'ScoreUNet', order: int, emb: Tensor, c: Optional[Tensor]):
+        unet = kernel.network
+        engine = unet.engine()
+        B, L, C = x.shape[0], x.shape[1], x.shape[2]
+        H, W = (1, x.shape[3]) if unet.spatial == 1 else (x.shape[3], x.shape[4])
+        hw = H * W
+        nw = L - 2 * order
+        wl = 2 * order + 1
+        if nw < 1:
+            raise SdaHipError(f'trajectory of length {L} is shorter than the window {wl}')
+        src = Source(x=x, n=B * nw, cx=wl * C, hs=H, ws=W, sn_outer=L * C * hw, sn_inner=C * hw, n_inner=nw, sc=hw,
+                     sy=W, sx=1)
+        attach_context(src, c, unet.spatial)
+        T = emb.shape[0]
+        if T not in (1, src.n):
+            raise SdaHipError(f'time embedding batch {T} does not broadcast against {src.n} windows')
+        per_image = T != 1
+        mod_all = engine.modulation(emb) if engine.mod_total > 0 else None
+        need = ctx.needs_input_grad[0]
+        dev = x.device
+        s = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
+        ctx.saved_acts = None
+        chunk_save = engine.chunk_size(src.n, H, W, True, dev) if need else 0
+        if need and chunk_save >= src.n:
+            ctx.saved_acts = engine.forward_chunk(src, 0, src.n, mod_all, per_image, s, True)
+        else:
+            chunk = engine.chunk_size(src.n, H, W, False, dev)
+            for lo in range(0, src.n, chunk):
+                hi = min(src.n, lo + chunk)
+                engine.forward_chunk(src, lo, hi, mod_all, per_image, s[lo:hi], False)
+        out = torch.empty_like(x)
+        ops.fold(s, B, nw, order, C, hw, out)
+        ctx.engine, ctx.src, ctx.mod_all, ctx.per_image = engine, src, mod_all, per_image
+        ctx.geom = (B, nw, order, C, H, W)
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        engine, src = ctx.engine, ctx.src
+        B, nw, order, C, H, W = ctx.geom
+        hw, wl = H * W, 2 * order + 1
+        dev = g.device
+        g = g.contiguous()
+        g_s = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
+        ops.fold_adjoint(g, B, nw, order, C, hw, g_s)
+        g_win = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
+        if ctx.saved_acts is not None:
+            engine.backward_chunk(ctx.saved_acts, g_s, src, 0, ctx.mod_all, ctx.per_image, g_win)
+        else:
+            chunk = engine.chunk_size(src.n, H, W, True, dev)
+            scratch = torch.empty(min(chunk, src.n), wl * C, H, W, device=dev, dtype=torch.float32)
+            for lo in range(0, src.n, chunk):
+                hi = min(src.n, lo + chunk)
+                saved = engine.forward_chunk(src, lo, hi, ctx.mod_all, ctx.per_image, scratch[:hi - lo], True)
+                engine.backward_chunk(saved, g_s[lo:hi], src, lo, ctx.mod_all, ctx.per_image, g_win[lo:hi])
+                del saved
+        g_x = torch.empty(B, nw + 2 * order, C, H, W, device=dev, dtype=torch.float32)
+        ops.unfold_adjoint(g_win, B, nw, order, C, hw, wl * C, g_x)
+        return g_x.reshape(ctx.x_shape), None, None, None, None
+
+
+class _FoldFunction(torch.autograd.Function):
+    """``MCScoreNet.fold`` (score.py:155-164) as a HIP gather with its adjoint."""
+
+    @staticmethod
+    def forward(ctx, s: Tensor, order: int):
+        s = s.contiguous()
+        B, nw = s.shape[0], s.shape[1]
+        wl = 2 * order + 1
+        C = s.shape[2] // wl
+        rest = s.shape[3:]
+        hw = 1
+        for r in rest:
+            hw *= r
+        out = torch.empty(B, nw + 2 * order, C, *rest, device=s.device, dtype=torch.float32)
+        ops.fold(s, B, nw, order, C, hw, out)
+        ctx.geom = (B, nw, order, C, hw, s.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        B, nw, order, C, hw, shape = ctx.geom
+        g_s = torch.empty(shape, device=g.device, dtype=torch.float32)
+        ops.fold_adjoint(g.contiguous(), B, nw, order, C, hw, g_s)
+        return g_s, None
+
+
+class MCScoreNet(nn.Module):
+    r"""Score network for a Markov chain: the score of a long trajectory composed from scores over windows of
+    ``2*order+1`` frames (score.py:113-164).  ``kernel`` is reassignable, as the reference's drivers do."""
+
+    def __init__(self, features: int, context: int = 0, order: int = 1, **kwargs):
+        super().__init__()
+        self.order = order
+        build = ScoreUNet if kwargs.get('spatial', 0) > 0 else ScoreNet
+        self.kernel = build(features * (2 * order + 1), context, **kwargs)
+
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        kernel = self.kernel
+        fused = isinstance(kernel, ScoreUNet) and type(kernel).forward is ScoreUNet.forward \
+            and x.dim() == kernel.network.spatial + 3
+        if fused:
+            ops._dev(x, t)
+            ctx_c = kernel._context(c)
+            ops._dev(ctx_c)
+            emb = kernel.embedding(t.reshape(-1))
+            xin = x if x.is_contiguous() else x.contiguous()
+            return _MCScoreFunction.apply(xin, kernel, self.order, emb, ctx_c)
+        # generic kernel (ScoreNet, or a user subclass overriding forward): unfold as a view + one gather copy
+        s = kernel(self.unfold(x, self.order), t, c)
+        return self.fold(s, self.order)
+
+    @staticmethod
+    def unfold(x: Tensor, order: int) -> Tensor:
+        r"""(B, L, C, ...) -> (B, L-2k, (2k+1)C, ...)."""
+        x = x.unfold(1, 2 * order + 1, 1)
+        x = x.movedim(-1, 2)
+        return x.flatten(2, 3)
+
+    @staticmethod
+    def fold(x: Tensor, order: int) -> Tensor:
+        r"""Selective gather back to (B, L, C, ...): first window's leading slots, every centre, last window's
+        trailing slots.  Not an overlap-add."""
+        ops._dev(x)
+        return _FoldFunction.apply(x, order)
+
+
+class VPSDE(nn.Module):
+    r"""Noise scheduler for the variance preserving SDE, :math:`\mu = \alpha`, :math:`\sigma^2 = 1-\alpha^2+\eta^2`,
+    and the predictor-corrector sampler (score.py:167-276)."""
+
+    def __init__(self, eps: nn.Module, shape: Size, alpha: str = 'cos', eta: float = 1e-3):
+        super().__init__()
+        self.eps = eps
+        self.shape = shape
+        self.dims = tuple(range(-len(shape), 0))
+        self.eta = eta
+        if alpha == 'lin':
+            self.alpha = lambda t: 1 - (1 - eta) * t
+        elif alpha == 'cos':
+            self.alpha = lambda t: torch.cos(math.acos(math.sqrt(eta)) * t) ** 2
+        elif alpha == 'exp':
+            self.alpha = lambda t: torch.exp(math.log(eta) * t**2)
+        else:
+            raise ValueError()
+        self.register_buffer('device', torch.empty(()))
+
+    def mu(self, t: Tensor) -> Tensor:
+        return self.alpha(t)
+
+    def sigma(self, t: Tensor) -> Tensor:
+        return (1 - self.alpha(t) ** 2 + self.eta ** 2).sqrt()
+
+    def forward(self, x: Tensor, t: Tensor, train: bool = False) -> Tensor:
+        r"""Samples from the perturbation kernel p(x(t) | x)."""
+        t = t.reshape(t.shape + (1,) * len(self.shape))
+        eps = torch.randn_like(x)
+        x = self.mu(t) * x + self.sigma(t) * eps
+        return (x, eps) if train else x
+
+    #: optional ``callable(step, correction) -> Tensor`` replacing ``randn_like`` for the corrector noise, and an
+    #: optional initial draw; both exist so that parity tests can inject the reference's CPU noise (RNG).
+    noise_source: Optional[Callable[[int, int], Tensor]] = None
+    initial_noise: Optional[Tensor] = None
+
+    def sample(self, shape: Size = (), c: Tensor = None, steps: int = 64, corrections: int = 0,
+               tau: float = 1.0) -> Tensor:
+        r"""Samples from p(x(0)) with ``steps`` predictor steps and ``corrections`` Langevin corrections each."""
+        shape = tuple(shape)
+        if self.initial_noise is not None:
+            x = self.initial_noise.to(self.device).clone()
+        else:
+            x = torch.randn(shape + tuple(self.shape)).to(self.device)      # host RNG then H2D, as the reference
+        x = x.reshape(-1, *self.shape).contiguous()
+        ops._dev(x)
+        nb = x.shape[0]
+
+        # the schedule is evaluated once on the host in fp32 with the reference's own formulas (score.py:246-253)
+        time_cpu = torch.linspace(1, 0, steps + 1)
+        dt = 1 / steps
+        t_next = time_cpu[:-1] - dt
+        mu_t, mu_n = self.mu(time_cpu[:-1]), self.mu(t_next)
+        sg_t, sg_n = self.sigma(time_cpu[:-1]), self.sigma(t_next)
+        r_all = mu_n / mu_t
+        c1_all = sg_n - r_all * sg_t
+        r_all, c1_all, sg_n = r_all.tolist(), c1_all.tolist(), sg_n.tolist()
+        time = time_cpu.to(self.device)
+        partial = torch.empty(nb * ops.SUMSQ_CHUNKS, device=x.device, dtype=torch.float32)
+
+        with torch.no_grad():
+            for i, t in enumerate(tqdm(time[:-1], ncols=88)):
+                # predictor: x <- r x + (sigma' - r sigma) eps(x, t)
+                ops.pc_predict(x, self.eps(x, t, c).contiguous(), r_all[i], c1_all[i])
+                # corrector: Langevin steps with delta = tau / mean(eps^2)
+                for j in range(corrections):
+                    z = torch.randn_like(x) if self.noise_source is None else self.noise_source(i, j).to(x)
+                    eps = self.eps(x, t - dt, c).contiguous()
+                    ops.sumsq_partial(eps, nb, partial)
+                    ops.pc_correct(x, eps, z.contiguous(), nb, partial, tau, sg_n[i])
+        return x.reshape(shape + tuple(self.shape))
+
+    def loss(self, x: Tensor, c: Tensor = None, w: Tensor = None) -> Tensor:
+        raise NotImplementedError('training (the denoising loss, score.py:265-276) is outside the sampling hot path')
+
+
+class SubVPSDE(VPSDE):
+    r"""sub-VP SDE: :math:`\sigma = 1 - \alpha^2 + \eta` (score.py:279-288)."""
+
+    def sigma(self, t: Tensor) -> Tensor:
+        return 1 - self.alpha(t) ** 2 + self.eta
+
+
+class SubSubVPSDE(VPSDE):
+    r"""sub-sub-VP SDE: :math:`\sigma = 1 - \alpha + \eta` (score.py:291-302)."""
+
+    def sigma(self, t: Tensor) -> Tensor:
+        return 1 - self.alpha(t) + self.eta
+
+
+def _eps_with_vjp(sde: VPSDE, x: Tensor, t: Tensor, c, detach: bool):
+    """eps = sde.eps(x) and a closure computing J_eps^T g (None when detached)."""
+    if detach:
+        with torch.no_grad():
+            return sde.eps(x, t, c) if c is not None else sde.eps(x, t), None
+    with torch.enable_grad():
+        xg = x.detach().requires_grad_(True)
+        eps = sde.eps(xg, t, c) if c is not None else sde.eps(xg, t)
+
+    def vjp(g: Tensor) -> Tensor:
+        out, = torch.autograd.grad(eps, xg, g)
+        return out
+    return eps, vjp
+
+
+class DPSGaussianScore(nn.Module):
+    r"""Diffusion posterior sampling guidance for p(y|x) = N(y | A(x), Sigma)  (score.py:305-344).
+    Returns :math:`-\sigma(t) s(x(t), t | y)`.  Note ``err`` is summed over the whole batch, as in the reference."""
+
+    def __init__(self, y: Tensor, A: Callable[[Tensor], Tensor], sde: VPSDE, zeta: float = 1.0):
+        super().__init__()
+        self.register_buffer('y', y)
+        self.A = A
+        self.sde = sde
+        self.zeta = zeta
+
+    def forward(self, x: Tensor, t: Tensor) -> Tensor:
+        mu, sigma = self.sde.mu(t), self.sde.sigma(t)
+        eps, vjp = _eps_with_vjp(self.sde, x, t, None, False)
+        eps_d = eps.detach().contiguous()
+        xhat = torch.empty_like(eps_d)
+        ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
+        with torch.enable_grad():
+            xhat.requires_grad_(True)
+            err = (self.y - self.A(xhat)).square().sum()
+        ghat, = torch.autograd.grad(err, xhat)
+        ghat = (ghat * (-self.zeta / err.detach().sqrt())).contiguous()      # d/dxhat of the DPS potential
+        out = torch.empty_like(eps_d)
+        ops.guided_combine(eps_d, ghat, vjp(ghat).contiguous(), mu, sigma, out)
+        return out
+
+
+class GaussianScore(nn.Module):
+    r"""Likelihood guidance for Gaussian inverse problems, p(y|x) = N(y | A(x), std^2 + gamma (sigma/mu)^2)
+    (score.py:347-396).  Returns :math:`-\sigma(t) s(x(t), t | y)`.
+
+    ``x_hat = (x - sigma eps)/mu`` and the final combination are HIP kernels; ``A`` (an arbitrary callable) is
+    differentiated by torch at ``x_hat``, and the chain rule back to ``x`` goes through the hand-written U-Net VJP:
+    ``s = g/mu - (sigma/mu) J_eps^T g`` with ``g = d log p / d x_hat``."""
+
+    def __init__(self, y: Tensor, A: Callable[[Tensor], Tensor], std: Union[float, Tensor], sde: VPSDE,
+                 gamma: Union[float, Tensor] = 1e-2, detach: bool = False):
+        super().__init__()
+        self.register_buffer('y', y)
+        self.register_buffer('std', torch.as_tensor(std))
+        self.register_buffer('gamma', torch.as_tensor(gamma))
+        self.A = A
+        self.sde = sde
+        self.detach = detach
+
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        mu, sigma = self.sde.mu(t), self.sde.sigma(t)
+        eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
+        eps_d = eps.detach().contiguous()
+        xhat = torch.empty_like(eps_d)
+        ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
+        with torch.enable_grad():
+            xhat.requires_grad_(True)
+            err = self.y - self.A(xhat)
+            var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
+            log_p = -(err ** 2 / var).sum() / 2
+        ghat, = torch.autograd.grad(log_p, xhat)
+        ghat = ghat.contiguous()
+        out = torch.empty_like(eps_d)
+        ops.guided_combine(eps_d, ghat, None if vjp is None else vjp(ghat).contiguous(), mu, sigma, out)
+        return out

@@ -1,0 +1,31 @@
+r"""Helpers on the sampling path (subset of the reference's ``sda/utils.py``: ACTIVATIONS and the run config
+json, sda/utils.py:19-42).  Training loop, datasets and metrics are out of scope."""
+
+import json
+import random
+from pathlib import Path
+from typing import Any, Dict, Sequence
+
+import torch
+
+ACTIVATIONS = {
+    'ReLU': torch.nn.ReLU,
+    'ELU': torch.nn.ELU,
+    'GELU': torch.nn.GELU,
+    'SELU': torch.nn.SELU,
+    'SiLU': torch.nn.SiLU,
+}
+
+
+def random_config(configs: Dict[str, Sequence[Any]]) -> Dict[str, Any]:
+    return {key: random.choice(values) for key, values in configs.items()}
+
+
+def save_config(config: Dict[str, Any], path: Path) -> None:
+    with open(Path(path) / 'config.json', mode='x') as f:
+        json.dump(config, f)
+
+
+def load_config(path: Path) -> Dict[str, Any]:
+    with open(Path(path) / 'config.json', mode='r') as f:
+        return json.load(f)

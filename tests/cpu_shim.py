@@ -1,0 +1,134 @@
+"""TEST-ONLY host shim: lets the *Python orchestration* of sda_amd (engine forward / VJP sequencing, autograd
+Functions, guidance chain rule, the PC loop) execute on CPU tensors so it can be checked against the golden
+fixtures without a GPU.
+
+The shim monkeypatches `sda_amd.ops` inside a test:
+  * convolutions go through libsda_emu.so -- the host replay of the gfx950 conv tile algorithm (same planner and
+    index helpers as the device kernel);
+  * the small streaming kernels are replaced by a few lines of torch each.
+Nothing here is reachable from the product: sda_amd itself has no CPU path and raises on CPU tensors.
+"""
+import ctypes
+
+import torch
+
+from sda_amd import build as sbuild
+from sda_amd import engine as E
+from sda_amd import ops
+from sda_amd._lib import ConvDesc
+
+_ACT = {1: torch.nn.functional.silu, 2: torch.relu, 3: torch.nn.functional.elu, 4: torch.nn.functional.gelu,
+        5: torch.nn.functional.selu}
+
+
+def install(monkeypatch):
+    emu = ctypes.CDLL(sbuild.build_emu())
+    emu.sda_conv_igemm_emulate.restype = ctypes.c_int
+    emu.sda_conv_igemm_emulate.argtypes = [ctypes.POINTER(ConvDesc)]
+    emu.sda_pack_conv_weight_host.restype = None
+
+    def _dev(*ts):
+        for t in ts:
+            assert t is None or t.dtype == torch.float32
+
+    def conv_igemm(desc):
+        rc = emu.sda_conv_igemm_emulate(ctypes.byref(desc))
+        assert rc == 0, f'emulator rc={rc}'
+
+    def pack(w, cout, cin, kh, kw, transpose, keep, dst, k_pad, m_pad):
+        emu.sda_pack_conv_weight_host(ctypes.c_void_p(w.data_ptr()), cout, cin, kh, kw, int(transpose), keep,
+                                      ctypes.c_void_p(dst.data_ptr()), k_pad, m_pad)
+
+    def _u(x, mod, mod_sn):
+        n, c = x.shape[:2]
+        xv = x.reshape(n, c, -1)
+        if mod is None:
+            return xv
+        # mod is a (possibly offset / strided) view: rows of `mod_sn` floats (or one shared row)
+        rows = []
+        base = mod.reshape(-1) if mod.is_contiguous() else None
+        for i in range(n):
+            r = mod[i if mod_sn else 0]
+            rows.append(r[:c])
+        return xv + torch.stack(rows)[:, :, None]
+
+    def ln_stats(x, mod, mod_sn, eps, unbiased, mean, rstd):
+        u = _u(x, mod, mod_sn)
+        var, m = torch.var_mean(u, dim=1, unbiased=bool(unbiased))
+        mean.copy_(m.reshape(-1))
+        rstd.copy_((1 / torch.sqrt(var + eps)).reshape(-1))
+
+    def ln_apply(x, mod, mod_sn, mean, rstd, y):
+        u = _u(x, mod, mod_sn)
+        n = u.shape[0]
+        y.copy_(((u - mean.reshape(n, 1, -1)) * rstd.reshape(n, 1, -1)).reshape(y.shape))
+
+    def ln_bwd(gh, x, h, w, mod, mod_sn, mean, rstd, unbiased, pool, res, gx):
+        n, c = x.shape[:2]
+        u = _u(x, mod, mod_sn)
+        hh = (u - mean.reshape(n, 1, -1)) * rstd.reshape(n, 1, -1)
+        g = gh
+        if pool == 2:
+            if h == 1:
+                g = gh.reshape(n, c, 1, w, 2).sum(-1)
+            else:
+                g = gh.reshape(n, c, h, 2, w, 2).sum((-1, -3))
+        g = g.reshape(n, c, -1)
+        a = g.mean(1, keepdim=True)
+        b = (g * hh).sum(1, keepdim=True) / (c - 1 if unbiased else c)
+        out = rstd.reshape(n, 1, -1) * (g - a - hh * b)
+        if res is not None:
+            out = out + res.reshape(n, c, -1)
+        gx.copy_(out.reshape(gx.shape))
+
+    def time_embed(t, freqs, w0, b0, w2, b2):
+        ang = t.reshape(-1, 1) * freqs
+        f = torch.cat((ang.cos(), ang.sin()), -1)
+        return torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(f, w0, b0)), w2, b2)
+
+    def linear_small(x, w, b):
+        return torch.nn.functional.linear(x, w, b)
+
+    from oracle import sda_oracle as O
+
+    def fold(s, b, nw, k, c, hw, out):
+        out.copy_(O.fold(s.reshape(b, nw, (2 * k + 1) * c, hw), k).reshape(out.shape))
+
+    def fold_adjoint(g_out, b, nw, k, c, hw, g_s):
+        with torch.enable_grad():
+            s = torch.zeros(b, nw, (2 * k + 1) * c, hw, requires_grad=True)
+            gs, = torch.autograd.grad(O.fold(s, k), s, g_out.reshape(b, nw + 2 * k, c, hw))
+        g_s.copy_(gs.reshape(g_s.shape))
+
+    def unfold_adjoint(g_win, b, nw, k, c, hw, tot, g_x):
+        with torch.enable_grad():
+            x = torch.zeros(b, nw + 2 * k, c, hw, requires_grad=True)
+            gx, = torch.autograd.grad(O.unfold(x, k), x, g_win.reshape(b, nw, tot, hw)[:, :, :(2 * k + 1) * c])
+        g_x.copy_(gx.reshape(g_x.shape))
+
+    def pc_predict(x, eps, r, c1, coef_dev=None):
+        x.copy_(r * x + c1 * eps)
+
+    def sumsq_partial(eps, b, partial):
+        partial.zero_()
+        partial.reshape(b, -1)[:, 0] = eps.reshape(b, -1).square().sum(1)
+
+    def pc_correct(x, eps, z, b, partial, tau, sigma, coef_dev=None):
+        per = x.numel() // b
+        delta = (tau / (partial.reshape(b, -1).sum(1) / per)).reshape(b, *([1] * (x.dim() - 1)))
+        x.copy_(x - (delta * eps + torch.sqrt(2 * delta) * z) * sigma)
+
+    def denoise(x, eps, mu, sigma, xhat):
+        xhat.copy_((x - sigma * eps) / mu)
+
+    def guided_combine(eps, ghat, vjp, mu, sigma, out):
+        v = 0 if vjp is None else sigma * vjp
+        out.copy_(eps - (sigma / mu) * (ghat - v))
+
+    for name, fn in dict(_dev=_dev, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
+                         ln_bwd=ln_bwd, time_embed=time_embed, linear_small=linear_small, fold=fold,
+                         fold_adjoint=fold_adjoint, unfold_adjoint=unfold_adjoint, pc_predict=pc_predict,
+                         sumsq_partial=sumsq_partial, pc_correct=pc_correct, denoise=denoise,
+                         guided_combine=guided_combine).items():
+        monkeypatch.setattr(ops, name, fn)
+    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: n)

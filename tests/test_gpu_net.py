@@ -1,0 +1,228 @@
+"""GPU: the HIP score path through the reference-mirroring Python API, against (a) fixtures produced by the
+reference's own code (tests/golden) and (b) the CPU oracle on seeded inputs.  fp32; tolerance 1e-4 relative to the
+tensor scale (BASELINE.json north_star: rtol = 1e-4), looser only where stated and why."""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import sda_oracle as O
+from tests.util import (assert_close, build_mcscore2d_tiny, build_unet1d_tiny, build_unet1d_two_level, load_golden,
+                        oracle_eps_from_module, rel_err)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from sda_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _A(x):
+    return x[..., ::2, :, ::2, ::2]
+
+
+def test_golden_unet1d_wrapper(dev):
+    g, grp = load_golden('unet1d_tiny')
+    net = build_unet1d_tiny()
+    net.load_state_dict(grp['sd'])
+    net.to(dev)
+    with torch.no_grad():
+        out = net(g['x'].to(dev), g['t'].to(dev))
+    assert out.shape == g['out'].shape
+    assert_close(out.cpu(), g['out'], TOL)
+
+
+def test_golden_unet1d_two_level_per_sample_time(dev):
+    g, grp = load_golden('unet1d_two_level')
+    net = build_unet1d_two_level()
+    net.load_state_dict(grp['sd'])
+    net.to(dev)
+    with torch.no_grad():
+        out = net(g['x'].to(dev), g['t'].to(dev))
+    assert_close(out.cpu(), g['out'], TOL)
+
+
+def test_golden_mcscore2d_fused_and_generic(dev):
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    net.to(dev)
+    x, t = g['x'].to(dev), g['t'].to(dev)
+    with torch.no_grad():
+        out = net(x, t)
+    assert_close(out.cpu(), g['out'], TOL, what='fused unfold/fold path')
+
+    # a user-style subclass overriding forward (as experiments/kolmogorov/utils.py does) takes the generic path
+    from sda_amd.score import MCScoreNet, ScoreUNet
+
+    class UserLocal(ScoreUNet):
+        def __init__(self, channels, size, **kw):
+            super().__init__(channels, 1, **kw)
+            self.register_buffer('forcing', torch.zeros(1, size, size))
+
+        def forward(self, x, t, c=None):
+            return super().forward(x, t, self.forcing)
+
+    net2 = MCScoreNet(2, order=1)
+    net2.kernel = UserLocal(6, 8, embedding=8, hidden_channels=(4, 8), hidden_blocks=(1, 1), kernel_size=3,
+                            activation=nn.SiLU, spatial=2, padding_mode='circular')
+    net2.load_state_dict(grp['sd'])
+    net2.to(dev)
+    with torch.no_grad():
+        out2 = net2(x, t)
+    assert_close(out2.cpu(), g['out'], TOL, what='generic path')
+
+
+def test_golden_guided_score_grad_and_dps(dev):
+    from sda_amd.score import DPSGaussianScore, GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    inner = VPSDE(net, shape=())
+    gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2).to(dev)
+    x, t = g['x'].to(dev), g['t_guided'].to(dev)
+    with torch.no_grad():
+        plain = net(x, t)
+    guided = gs(x, t)
+    assert_close(plain.cpu(), g['plain'], TOL)
+    assert_close(guided.cpu(), g['guided'], TOL)
+    sigma = inner.sigma(g['t_guided'])
+    assert_close(((plain - guided) / sigma.to(dev)).cpu(), g['grad_logp'], 2e-3)   # cancellation-limited fixture
+    dps = DPSGaussianScore(g['y_obs'], A=_A, sde=inner, zeta=1.0).to(dev)
+    assert_close(dps(x, t).cpu(), g['dps'], TOL)
+
+
+def test_golden_guided_pc_steps_injected_noise(dev):
+    from sda_amd.score import GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=VPSDE(net, shape=()), gamma=1e-2)
+    sde = VPSDE(gs, shape=(5, 2, 8, 8)).to(dev)
+    steps, corr, tau = int(g['pc_args'][0]), int(g['pc_args'][1]), float(g['pc_args'][2])
+    zs = g['pc_noise']
+    sde.initial_noise = g['pc_x_init']
+    sde.noise_source = lambda i, j: zs[i * corr + j]
+    x = sde.sample((2,), steps=steps, corrections=corr, tau=tau)
+    assert x.shape == g['pc_x_final'].shape
+    assert_close(x.cpu(), g['pc_x_final'], 1e-3)       # 8 guided evals deep (same bound the oracle meets on CPU)
+
+
+def test_golden_unguided_sampling_lorenz(dev):
+    from sda_amd.score import VPSDE
+    g, _ = load_golden('sample_unguided_lorenz')
+    _, grp = load_golden('unet1d_tiny')
+    net = build_unet1d_tiny()
+    net.load_state_dict(grp['sd'])
+    sde = VPSDE(net, shape=(16, 3)).to(dev)
+    steps, corr, tau = int(g['args'][0]), int(g['args'][1]), float(g['args'][2])
+    zs = g['noise']
+    sde.initial_noise = g['x_init']
+    sde.noise_source = lambda i, j: zs[i * corr + j]
+    x = sde.sample((3,), steps=steps, corrections=corr, tau=tau)
+    assert_close(x.cpu(), g['x_final'], TOL)
+
+
+def _midsize_net(dev, seed=0):
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(seed)
+    net = make_score(window=5, embedding=32, hidden_channels=(16, 32, 64), hidden_blocks=(2, 2, 2), size=16)
+    return net
+
+
+def test_vjp_against_oracle_autograd_fp64(dev):
+    """J^T g of the whole MC score (fold . U-Net . unfold) vs torch autograd through the fp64 oracle."""
+    net = _midsize_net(dev)
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    net.to(dev)
+    torch.manual_seed(1)
+    x = torch.randn(2, 7, 2, 16, 16)
+    t = torch.tensor(0.43)
+    g = torch.randn_like(x)
+    xo = x.double().requires_grad_(True)
+    eo = eps_o(xo, t.double(), torch.float64)
+    ref, = torch.autograd.grad(eo, xo, g.double())
+    xd = x.to(dev).requires_grad_(True)
+    out = net(xd, t.to(dev))
+    vjp, = torch.autograd.grad(out, xd, g.to(dev))
+    assert_close(out.detach().cpu(), eo.detach(), TOL, what='eps')
+    assert_close(vjp.cpu(), ref, TOL, what='vjp')
+
+
+def test_chunked_equals_unchunked_and_recompute(dev, monkeypatch):
+    from sda_amd import engine as E
+    net = _midsize_net(dev).to(dev)
+    torch.manual_seed(2)
+    x = torch.randn(3, 9, 2, 16, 16, device=dev)
+    t = torch.tensor(0.7, device=dev)
+    g = torch.randn_like(x)
+    xg = x.clone().requires_grad_(True)
+    out = net(xg, t)
+    vjp, = torch.autograd.grad(out, xg, g)
+    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: 4)
+    xg2 = x.clone().requires_grad_(True)
+    out2 = net(xg2, t)
+    vjp2, = torch.autograd.grad(out2, xg2, g)
+    assert torch.equal(out, out2)
+    assert torch.equal(vjp, vjp2)
+
+
+def test_k64_single_window_vs_oracle(dev):
+    """The real Kolmogorov net (22.9 M parameters, kolmogorov/train.py:15-22) on one trajectory window."""
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(3)
+    net = make_score(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    net.to(dev)
+    x = torch.randn(1, 6, 2, 64, 64)
+    t = torch.tensor(0.35)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev))
+        ref = eps_o(x, t)
+    assert_close(out.cpu(), ref, TOL)
+
+
+def test_lorenz_global_config1_vs_oracle(dev):
+    from sda_amd.experiments.lorenz import make_global_score
+    torch.manual_seed(4)
+    net = make_global_score()
+    eps_o = oracle_eps_from_module(net, 'wrap1d')
+    net.to(dev)
+    x = torch.randn(4, 65, 3)
+    t = torch.tensor(0.9)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev))
+    assert_close(out.cpu(), eps_o(x, t), TOL)
+    # guided, strided observation as experiments/lorenz/eval.py:72-81
+    from sda_amd.score import GaussianScore, VPSDE
+    A = lambda x: x[..., ::8, :1]
+    y = torch.randn(4, 9, 1)
+    gs = GaussianScore(y, A=A, std=0.5, sde=VPSDE(net, shape=()), gamma=3e-2).to(dev)
+    out = gs(x.to(dev), t.to(dev))
+    ref = O.gaussian_score(lambda xx, tt: eps_o(xx, tt), O.Schedule(), y, A, 0.5, 3e-2, x, t)
+    assert_close(out.cpu(), ref, TOL)
+
+
+def test_size_independent_properties_full_size(dev):
+    """Config-3 shapes (K64 net, 64x64, L=32) are too slow for the CPU oracle; check what must hold at any size:
+    fold(unfold) round trip through the HIP gathers, finiteness, determinism, and VJP linearity."""
+    from sda_amd.experiments.kolmogorov import make_score
+    from sda_amd.score import MCScoreNet
+    torch.manual_seed(5)
+    net = make_score(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3)).to(dev)
+    x = torch.randn(2, 32, 2, 64, 64, device=dev)
+    t = torch.tensor(0.5, device=dev)
+    assert torch.equal(MCScoreNet.fold(MCScoreNet.unfold(x, 2).contiguous(), 2), x)
+    xg = x.clone().requires_grad_(True)
+    out = net(xg, t)
+    assert torch.isfinite(out).all()
+    with torch.no_grad():
+        assert torch.equal(net(x, t), out.detach())
+    g1, g2 = torch.randn_like(x), torch.randn_like(x)
+    v1, = torch.autograd.grad(out, xg, g1, retain_graph=True)
+    v2, = torch.autograd.grad(out, xg, g2, retain_graph=True)
+    v12, = torch.autograd.grad(out, xg, 2 * g1 - 3 * g2)
+    assert rel_err(v12, 2 * v1 - 3 * v2) < 1e-4

@@ -1,0 +1,214 @@
+"""GPU: every C-ABI kernel against torch / the oracle on seeded inputs (fp32, tolerance 1e-4 scale-relative as
+BASELINE.json's north_star states; typical measured error is ~1e-6)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sda_oracle as O
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from sda_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def hip_conv(x, w, b, ho, wo, dev, transpose=False, cin_keep=None, **kw):
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    xd = x.to(dev).contiguous()
+    pk = ops.PackedConv(w.to(dev), None if b is None else b.to(dev), transpose=transpose, cin_keep=cin_keep)
+    out = torch.full((xd.shape[0], pk.m_real, ho, wo), float('nan'), device=dev)
+    opts = {}
+    for k, v in kw.items():
+        opts[k] = v.to(dev).contiguous() if torch.is_tensor(v) else v
+    if 'ln' in kw:
+        opts['ln'] = tuple(t.to(dev).contiguous() for t in kw['ln'])
+    launch_conv(pk, planar_source(xd), out, ho, wo, bias=pk.bias, **opts)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    return out.cpu()
+
+
+def ref_conv(x, w, b, stride, circular):
+    return O._conv(x, w, b, w.dim() - 2, stride, 'circular' if circular else 'zeros')
+
+
+@pytest.mark.parametrize('circular', [False, True])
+@pytest.mark.parametrize('shape', [(3, 5, 8, 8, 7), (2, 11, 64, 64, 96), (2, 96, 32, 32, 96), (1, 192, 16, 16, 384),
+                                   (1, 4, 5, 12, 3), (2, 96, 64, 64, 10)])
+def test_conv2d_stride1(dev, circular, shape):
+    n, cin, h, w_, cout = shape
+    torch.manual_seed(0)
+    x, w, b = torch.randn(n, cin, h, w_), torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5), torch.randn(cout)
+    out = hip_conv(x, w, b, h, w_, dev, circular=circular)
+    assert_close(out, ref_conv(x, w, b, 1, circular), TOL)
+
+
+@pytest.mark.parametrize('circular', [False, True])
+def test_conv2d_stride2(dev, circular):
+    torch.manual_seed(1)
+    x, w, b = torch.randn(3, 96, 64, 64), torch.randn(192, 96, 3, 3) * 0.03, torch.randn(192)
+    out = hip_conv(x, w, b, 32, 32, dev, circular=circular, stride=(2, 2))
+    assert_close(out, ref_conv(x, w, b, 2, circular), TOL)
+
+
+@pytest.mark.parametrize('circular', [False, True])
+def test_upsample_ln_fused(dev, circular):
+    torch.manual_seed(3)
+    x, w, b = torch.randn(2, 192, 16, 16) * 2 + 0.3, torch.randn(96, 192, 3, 3) * 0.03, torch.randn(96)
+    skip = torch.randn(2, 96, 32, 32)
+    hin = O.layer_norm(x, dim=1)
+    up = hin.repeat_interleave(2, -1).repeat_interleave(2, -2)
+    var, mean = torch.var_mean(x, dim=1, unbiased=True, keepdim=True)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    out = hip_conv(x, w, b, 32, 32, dev, circular=circular, up=(2, 2), ln=(mean.reshape(2, -1), rstd.reshape(2, -1)), res=skip)
+    assert_close(out, ref_conv(up, w, b, 1, circular) + skip, TOL)
+
+
+@pytest.mark.parametrize('circular', [False, True])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_backward_data(dev, circular, stride):
+    torch.manual_seed(4)
+    x = torch.randn(2, 24, 16, 16, requires_grad=True)
+    w = torch.randn(40, 24, 3, 3) * 0.1
+    y = ref_conv(x, w, None, stride, circular)
+    g = torch.randn_like(y)
+    gx_ref, = torch.autograd.grad(y, x, g)
+    out = hip_conv(g, w, None, 16, 16, dev, transpose=True, circular=circular, zins=(stride, stride))
+    assert_close(out, gx_ref, TOL)
+
+
+def test_conv1d_paths(dev):
+    torch.manual_seed(6)
+    for length in (16, 65, 128):
+        x, w, b = torch.randn(5, 3, length), torch.randn(64, 3, 3), torch.randn(64)
+        out = hip_conv(x.unsqueeze(2), w, b, 1, length, dev, circular=False)
+        assert_close(out[:, :, 0], F.conv1d(x, w, b, padding=1), TOL)
+    x = torch.randn(3, 4, 20, requires_grad=True)
+    w = torch.randn(6, 4, 3)
+    y = F.conv1d(x, w, None, stride=2, padding=1)
+    g = torch.randn_like(y)
+    gx_ref, = torch.autograd.grad(y, x, g)
+    out = hip_conv(g.unsqueeze(2), w, None, 1, 20, dev, transpose=True, circular=False, zins=(1, 2))
+    assert_close(out[:, :, 0], gx_ref, TOL)
+
+
+@pytest.mark.parametrize('act', ['SiLU', 'GELU', 'ELU', 'ReLU', 'SELU'])
+def test_loader_mod_ln_act_and_epilogue(dev, act):
+    from sda_amd._lib import ACT_IDS
+    torch.manual_seed(10)
+    n, c, h, w_ = 3, 24, 16, 16
+    x, mod = torch.randn(n, c, h, w_) * 2 + 0.5, torch.randn(n, c)
+    wgt, b = torch.randn(20, c, 3, 3) * 0.1, torch.randn(20)
+    u = x + mod[:, :, None, None]
+    var, mean = torch.var_mean(u, dim=1, unbiased=True, keepdim=True)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    ref = ref_conv(O.activation(act)(O.layer_norm(u, dim=1)), wgt, b, 1, True)
+    out = hip_conv(x, wgt, b, h, w_, dev, circular=True, mod=mod, mod_sn=c, ln=(mean.reshape(n, -1), rstd.reshape(n, -1)),
+                   act_in=ACT_IDS[act])
+    assert_close(out, ref, TOL)
+    z = torch.randn(n, 20, h, w_, requires_grad=True)
+    res = torch.randn(n, 20, h, w_)
+    dz, = torch.autograd.grad(O.activation(act)(z).sum(), z)
+    out = hip_conv(x, wgt, None, h, w_, dev, circular=True, dact_z=z.detach(), act_d=ACT_IDS[act], res=res)
+    assert_close(out, ref_conv(x, wgt, None, 1, True) * dz + res, TOL)
+
+
+def test_ln_stats_apply_bwd(dev):
+    from sda_amd import ops
+    torch.manual_seed(11)
+    for (n, c, h, w_), pool in (((3, 24, 8, 8), 1), ((2, 96, 16, 16), 2), ((4, 16, 1, 20), 2), ((2, 8, 1, 33), 1)):
+        x = (torch.randn(n, c, h, w_) * 3 + 1).requires_grad_(True)
+        mod = torch.randn(n, c)
+        xd, md = x.detach().to(dev), mod.to(dev)
+        mean = torch.empty(n * h * w_, device=dev); rstd = torch.empty_like(mean)
+        ops.ln_stats(xd, md, c, 1e-5, True, mean, rstd)
+        y = torch.empty_like(xd)
+        ops.ln_apply(xd, md, c, mean, rstd, y)
+        href = O.layer_norm(x + mod[:, :, None, None], dim=1)
+        assert_close(y.cpu(), href, TOL, what='ln_apply')
+        # backward (optionally through a nearest upsample)
+        if pool == 2:
+            hup = href.repeat_interleave(2, -1)
+            if h > 1:
+                hup = hup.repeat_interleave(2, -2)
+        else:
+            hup = href
+        g = torch.randn_like(hup)
+        res = torch.randn(n, c, h, w_)
+        gx_ref, = torch.autograd.grad(hup, x, g)
+        gx = torch.empty_like(xd)
+        ops.ln_bwd(g.to(dev), xd, h, w_, md, c, mean, rstd, True, pool, res.to(dev), gx)
+        assert_close(gx.cpu(), gx_ref + res, TOL, what=f'ln_bwd pool={pool}')
+
+
+def test_time_embed_and_projection(dev):
+    from sda_amd import ops
+    torch.manual_seed(12)
+    sd = O.init_time_embedding(torch.Generator().manual_seed(3), 'e.', 64)
+    t = torch.rand(7)
+    ref = O.time_embedding(sd, 'e.', t)
+    emb = ops.time_embed(t.to(dev), sd['e.freqs'].to(dev), sd['e.0.weight'].to(dev), sd['e.0.bias'].to(dev),
+                         sd['e.2.weight'].to(dev), sd['e.2.bias'].to(dev))
+    assert_close(emb.cpu(), ref, TOL)
+    w, b = torch.randn(300, 64), torch.randn(300)
+    y = ops.linear_small(emb, w.to(dev), b.to(dev))
+    assert_close(y.cpu(), F.linear(ref, w, b), TOL)
+
+
+def test_fold_and_adjoints(dev):
+    from sda_amd import ops
+    torch.manual_seed(13)
+    for k, L in ((1, 5), (2, 9), (2, 5), (3, 7)):
+        B, C, H, W = 2, 3, 4, 6
+        nw, wl = L - 2 * k, 2 * k + 1
+        s = torch.randn(B, nw, wl * C, H, W, requires_grad=True)
+        ref = O.fold(s, k)
+        out = torch.empty(B, L, C, H, W, device=dev)
+        ops.fold(s.detach().to(dev).contiguous(), B, nw, k, C, H * W, out)
+        assert torch.equal(out.cpu(), ref.detach())
+        g = torch.randn_like(ref)
+        gs_ref, = torch.autograd.grad(ref, s, g)
+        gs = torch.empty(B, nw, wl * C, H, W, device=dev)
+        ops.fold_adjoint(g.to(dev), B, nw, k, C, H * W, gs)
+        assert torch.equal(gs.cpu(), gs_ref)
+        x = torch.randn(B, L, C, H, W, requires_grad=True)
+        u = O.unfold(x, k)
+        gu = torch.randn_like(u)
+        gx_ref, = torch.autograd.grad(u, x, gu)
+        gx = torch.empty(B, L, C, H, W, device=dev)
+        ops.unfold_adjoint(gu.to(dev).contiguous(), B, nw, k, C, H * W, wl * C, gx)
+        assert_close(gx.cpu(), gx_ref, 1e-6)
+
+
+def test_pc_updates_and_guidance_glue(dev):
+    from sda_amd import ops
+    torch.manual_seed(14)
+    b, per = 3, 5000
+    x, eps, z = torch.randn(b, per), torch.randn(b, per), torch.randn(b, per)
+    xd = x.to(dev).clone()
+    ops.pc_predict(xd, eps.to(dev), 1.25, -0.37)
+    assert_close(xd.cpu(), 1.25 * x + (-0.37) * eps, 1e-6)
+    partial = torch.empty(b * ops.SUMSQ_CHUNKS, device=dev)
+    ops.sumsq_partial(eps.to(dev), b, partial)
+    assert_close(partial.reshape(b, -1).sum(1).cpu(), eps.square().sum(1), 1e-5)
+    xd = x.to(dev).clone()
+    ops.pc_correct(xd, eps.to(dev), z.to(dev), b, partial, 0.5, 0.8)
+    delta = 0.5 / eps.square().mean(dim=1, keepdim=True)
+    assert_close(xd.cpu(), x - (delta * eps + torch.sqrt(2 * delta) * z) * 0.8, 1e-5)
+    xh = torch.empty(b, per, device=dev)
+    ops.denoise(x.to(dev), eps.to(dev), 0.7, 0.6, xh)
+    assert_close(xh.cpu(), (x - 0.6 * eps) / 0.7, 1e-6)
+    mu_t, sg_t = torch.tensor(0.7, device=dev), torch.tensor(0.6, device=dev)
+    xh2 = torch.empty(b, per, device=dev)
+    ops.denoise(x.to(dev), eps.to(dev), mu_t, sg_t, xh2)
+    assert torch.equal(xh, xh2)
+    out = torch.empty(b, per, device=dev)
+    ops.guided_combine(eps.to(dev), z.to(dev), x.to(dev), 0.7, 0.6, out)
+    assert_close(out.cpu(), eps - 0.6 * (z / 0.7 - (0.6 / 0.7) * x), 1e-5)

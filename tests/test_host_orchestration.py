@@ -1,0 +1,140 @@
+"""CPU: the Python orchestration of sda_amd (engine forward / VJP sequencing, autograd glue, guidance chain rule,
+PC loop, reference-compatible API) executed on CPU tensors through the TEST-ONLY shim of tests/cpu_shim.py
+(convolutions = host replay of the gfx950 tile algorithm), checked against the fixtures the reference's own code
+produced.  The device kernels themselves are covered by the -m gpu tests."""
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import cpu_shim
+from tests.util import (assert_close, build_mcscore2d_tiny, build_unet1d_tiny, build_unet1d_two_level, load_golden,
+                        oracle_eps_from_module)
+
+TOL = 2e-5
+
+
+@pytest.fixture(autouse=True)
+def shim(monkeypatch):
+    cpu_shim.install(monkeypatch)
+    # isinstance(x.is_cuda) gates in score.py
+    yield
+
+
+def _A(x):
+    return x[..., ::2, :, ::2, ::2]
+
+
+def test_unet1d_wrapper_golden():
+    g, grp = load_golden('unet1d_tiny')
+    net = build_unet1d_tiny()
+    net.load_state_dict(grp['sd'])
+    with torch.no_grad():
+        out = net(g['x'], g['t'])
+    assert_close(out, g['out'], TOL)
+
+
+def test_unet1d_two_level_per_sample_time_golden():
+    g, grp = load_golden('unet1d_two_level')
+    net = build_unet1d_two_level()
+    net.load_state_dict(grp['sd'])
+    with torch.no_grad():
+        out = net(g['x'], g['t'])
+    assert_close(out, g['out'], TOL)
+
+
+def test_mcscore2d_fused_golden_and_vjp():
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    with torch.no_grad():
+        out = net(g['x'], g['t'])
+    assert_close(out, g['out'], TOL)
+    # VJP against autograd through the oracle
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    torch.manual_seed(0)
+    gg = torch.randn_like(g['x'])
+    xo = g['x'].clone().requires_grad_(True)
+    ref, = torch.autograd.grad(eps_o(xo, g['t']), xo, gg)
+    xs = g['x'].clone().requires_grad_(True)
+    got, = torch.autograd.grad(net(xs, g['t']), xs, gg)
+    assert_close(got, ref, 5e-5)
+
+
+def test_guided_and_dps_golden():
+    from sda_amd.score import DPSGaussianScore, GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    inner = VPSDE(net, shape=())
+    gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2)
+    assert_close(gs(g['x'], g['t_guided']), g['guided'], 5e-5)
+    dps = DPSGaussianScore(g['y_obs'], A=_A, sde=inner, zeta=1.0)
+    assert_close(dps(g['x'], g['t_guided']), g['dps'], 5e-5)
+    gsd = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2, detach=True)
+    assert gsd(g['x'], g['t_guided']).shape == g['guided'].shape
+
+
+def test_guided_pc_steps_golden():
+    from sda_amd.score import GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=VPSDE(net, shape=()), gamma=1e-2)
+    sde = VPSDE(gs, shape=(5, 2, 8, 8))
+    steps, corr, tau = int(g['pc_args'][0]), int(g['pc_args'][1]), float(g['pc_args'][2])
+    zs = g['pc_noise']
+    sde.initial_noise = g['pc_x_init']
+    sde.noise_source = lambda i, j: zs[i * corr + j]
+    x = sde.sample((2,), steps=steps, corrections=corr, tau=tau)
+    assert_close(x, g['pc_x_final'], 1e-3)
+
+
+def test_unguided_sampling_golden():
+    from sda_amd.score import VPSDE
+    g, _ = load_golden('sample_unguided_lorenz')
+    _, grp = load_golden('unet1d_tiny')
+    net = build_unet1d_tiny()
+    net.load_state_dict(grp['sd'])
+    sde = VPSDE(net, shape=(16, 3))
+    zs = g['noise']
+    sde.initial_noise = g['x_init']
+    sde.noise_source = lambda i, j: zs[i * 2 + j]
+    x = sde.sample((3,), steps=8, corrections=2, tau=0.25)
+    assert_close(x, g['x_final'], 1e-4)
+
+
+def test_chunked_recompute_path(monkeypatch):
+    from sda_amd import engine as E
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    torch.manual_seed(1)
+    gg = torch.randn_like(g['x'])
+    xs = g['x'].clone().requires_grad_(True)
+    out = net(xs, g['t'])
+    v, = torch.autograd.grad(out, xs, gg)
+    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: 2)
+    xs2 = g['x'].clone().requires_grad_(True)
+    out2 = net(xs2, g['t'])
+    v2, = torch.autograd.grad(out2, xs2, gg)
+    assert torch.equal(out, out2) and torch.equal(v, v2)
+
+
+def test_generic_kernel_path_user_subclass():
+    from sda_amd.score import MCScoreNet, ScoreUNet
+    g, grp = load_golden('mcscore2d_tiny')
+
+    class UserLocal(ScoreUNet):
+        def __init__(self, channels, size, **kw):
+            super().__init__(channels, 1, **kw)
+            self.register_buffer('forcing', torch.zeros(1, size, size))
+
+        def forward(self, x, t, c=None):
+            return super().forward(x, t, self.forcing)
+
+    net = MCScoreNet(2, order=1)
+    net.kernel = UserLocal(6, 8, embedding=8, hidden_channels=(4, 8), hidden_blocks=(1, 1), kernel_size=3,
+                           activation=nn.SiLU, spatial=2, padding_mode='circular')
+    net.load_state_dict(grp['sd'])
+    with torch.no_grad():
+        assert_close(net(g['x'], g['t']), g['out'], TOL)

@@ -36,3 +36,54 @@ def assert_close(a, b, rtol=1e-4, atol=None, what=''):
     tol = rtol * scale + (atol or 0.0)
     err = (a - b).abs().max().item()
     assert err <= tol, f'{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})'
+
+
+# ---------------------------------------------------------------------------- model builders shared by GPU tests
+def build_unet1d_tiny():
+    import torch.nn as nn
+    from sda_amd.score import MCScoreWrapper, ScoreUNet
+    return MCScoreWrapper(ScoreUNet(3, embedding=8, hidden_channels=(8,), hidden_blocks=(1,), activation=nn.SiLU, spatial=1))
+
+
+def build_unet1d_two_level():
+    import torch.nn as nn
+    from sda_amd.score import ScoreUNet
+    return ScoreUNet(3, embedding=8, hidden_channels=(8, 16), hidden_blocks=(1, 2), activation=nn.SiLU, spatial=1)
+
+
+def build_mcscore2d_tiny():
+    import torch.nn as nn
+    from sda_amd.experiments.kolmogorov import LocalScoreUNet
+    from sda_amd.score import MCScoreNet
+    net = MCScoreNet(2, order=1)
+    net.kernel = LocalScoreUNet(channels=6, size=8, embedding=8, hidden_channels=(4, 8), hidden_blocks=(1, 1),
+                                kernel_size=3, activation=nn.SiLU, spatial=2, padding_mode='circular')
+    return net
+
+
+def oracle_eps_from_module(module, kind):
+    """An oracle (CPU) eps(x, t) sharing the weights of a sda_amd module."""
+    from oracle import sda_oracle as O
+    sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    if kind == 'mc2d':
+        k = module.kernel
+        net = k.network
+        cfg = O.UNetConfig(net.in_channels, net.out_channels, net.mod_features, net.hidden_channels, net.hidden_blocks,
+                           net.kernel_size[0], net.stride[0], 'SiLU', 2, 'circular')
+        order = module.order
+
+        def eps(x, t, dtype=None):
+            s = sd if dtype is None else O.cast_sd(sd, dtype)
+            kern = lambda xx, tt, c=None: O.score_unet(s, 'kernel.', cfg, xx, tt, s['kernel.forcing'])
+            return O.mc_score_net(kern, order, x, t)
+        return eps
+    if kind == 'wrap1d':
+        net = module.score.network
+        cfg = O.UNetConfig(net.in_channels, net.out_channels, net.mod_features, net.hidden_channels, net.hidden_blocks,
+                           net.kernel_size[0], net.stride[0], 'SiLU', 1, 'zeros')
+
+        def eps(x, t, dtype=None):
+            s = sd if dtype is None else O.cast_sd(sd, dtype)
+            return O.mc_score_wrapper(lambda xx, tt, c=None: O.score_unet(s, 'score.', cfg, xx, tt, c), x, t)
+        return eps
+    raise ValueError(kind)
