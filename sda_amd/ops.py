@@ -77,8 +77,38 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     return d
 
 
+class ConvProfile:
+    """Live timing of the dominant kernel for bench.py's roofline leg: when installed as ``ops.conv_profile`` every
+    conv_igemm launch is bracketed by HIP events on the launch stream and its ALGORITHMIC flops are recorded
+    (2 * n * out-pixels * cout * cin * taps over the real channels; zero-inserted taps are not counted)."""
+
+    def __init__(self):
+        self.records = []          # (start_event, stop_event, flops)
+
+    def flops(self, d: ConvDesc) -> float:
+        pixels = d.ho * d.wo / (d.zins_h * d.zins_w)
+        return 2.0 * d.n * pixels * d.cout * (d.cx + d.cctx) * d.kh * d.kw
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), total_ms=ms, total_flops=fl)
+
+
+conv_profile: Optional[ConvProfile] = None
+
+
 def conv_igemm(desc: ConvDesc):
     lib = _lib.load()
+    prof = conv_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
+        e1.record()
+        prof.records.append((e0, e1, prof.flops(desc)))
+        return
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 

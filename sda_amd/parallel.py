@@ -1,0 +1,84 @@
+"""Multi-GPU posterior sampling: independent trajectories shard across ranks (one process per GPU,
+``torch.distributed`` backend "nccl" = RCCL over xGMI), no communication inside the diffusion loop, one all-gather
+of the final samples.
+
+The reference has no distributed code at all (its only parallelism is Slurm job arrays,
+experiments/lorenz/eval.py:42); this module is what a data-parallel launch of ``VPSDE.sample`` needs:
+  * a deterministic batch partition,
+  * per-rank noise that is a slice of the single-process noise stream, so 1-GPU and N-GPU runs draw the same samples,
+  * the final gather.
+``DPSGaussianScore`` couples the batch through one scalar (score.py:339-342) and is therefore replicas-only.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of ``range(total)``: the first ``total % world`` ranks get one extra."""
+    base, extra = divmod(total, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sharded_initial_noise(batch: int, event: tuple, seed: int, rank: int, world_size: int) -> Tensor:
+    """This rank's rows of the (batch, *event) initial draw the single-process sampler would make with
+    ``torch.manual_seed(seed); torch.randn(batch, *event)`` (host RNG, as score.py:243)."""
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = shard_range(batch, rank, world_size)
+    full = torch.randn((batch,) + tuple(event), generator=gen)
+    return full[lo:hi].clone()
+
+
+class ShardedNoise:
+    """Corrector noise ``z`` for this rank's rows: draw i of the stream is ``randn(batch, *event)`` from a generator
+    seeded identically on every rank; each rank keeps only its slice, so the union over ranks equals the
+    single-process stream draw for draw."""
+
+    def __init__(self, batch: int, event: tuple, seed: int, rank: int, world_size: int, device):
+        self.batch, self.event = batch, tuple(event)
+        self.lo, self.hi = shard_range(batch, rank, world_size)
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.device = device
+
+    def __call__(self, step: int, correction: int) -> Tensor:
+        full = torch.randn((self.batch,) + self.event, generator=self.gen, device=self.device)
+        return full[self.lo:self.hi]
+
+
+def all_gather_samples(local: Tensor, batch: int) -> Tensor:
+    """Concatenate every rank's samples along dim 0 (ranks may hold unequal shares).  One collective, after the loop."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    sizes = [shard_range(batch, r, ws) for r in range(ws)]
+    biggest = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+
+
+def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64, corrections: int = 0, tau: float = 1.0,
+                   seed: int = 0, gather: bool = True) -> Tensor:
+    """``sde.sample((batch,), ...)`` with the batch split over the ranks of the default process group."""
+    rank, ws = world()
+    lo, hi = shard_range(batch, rank, ws)
+    event = tuple(sde.shape)
+    sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, ws)
+    if corrections > 0:
+        sde.noise_source = ShardedNoise(batch, event, seed + 1, rank, ws, sde.device.device)
+    try:
+        local = sde.sample((hi - lo,), c=c, steps=steps, corrections=corrections, tau=tau)
+    finally:
+        sde.initial_noise, sde.noise_source = None, None
+    return all_gather_samples(local, batch) if gather else local

@@ -277,44 +277,70 @@ class VPSDE(nn.Module):
     noise_source: Optional[Callable[[int, int], Tensor]] = None
     initial_noise: Optional[Tensor] = None
 
+    def sampler(self, shape: Size = (), c: Tensor = None, steps: int = 64, corrections: int = 0,
+                tau: float = 1.0) -> 'PCSampler':
+        r"""The predictor-corrector loop of :meth:`sample` as a steppable object (``sampler.step()`` advances one
+        diffusion step in place; used by ``sample`` itself, by bench.py and by the multi-GPU driver)."""
+        return PCSampler(self, tuple(shape), c, steps, corrections, tau)
+
     def sample(self, shape: Size = (), c: Tensor = None, steps: int = 64, corrections: int = 0,
                tau: float = 1.0) -> Tensor:
         r"""Samples from p(x(0)) with ``steps`` predictor steps and ``corrections`` Langevin corrections each."""
-        shape = tuple(shape)
-        if self.initial_noise is not None:
-            x = self.initial_noise.to(self.device).clone()
-        else:
-            x = torch.randn(shape + tuple(self.shape)).to(self.device)      # host RNG then H2D, as the reference
-        x = x.reshape(-1, *self.shape).contiguous()
-        ops._dev(x)
-        nb = x.shape[0]
-
-        # the schedule is evaluated once on the host in fp32 with the reference's own formulas (score.py:246-253)
-        time_cpu = torch.linspace(1, 0, steps + 1)
-        dt = 1 / steps
-        t_next = time_cpu[:-1] - dt
-        mu_t, mu_n = self.mu(time_cpu[:-1]), self.mu(t_next)
-        sg_t, sg_n = self.sigma(time_cpu[:-1]), self.sigma(t_next)
-        r_all = mu_n / mu_t
-        c1_all = sg_n - r_all * sg_t
-        r_all, c1_all, sg_n = r_all.tolist(), c1_all.tolist(), sg_n.tolist()
-        time = time_cpu.to(self.device)
-        partial = torch.empty(nb * ops.SUMSQ_CHUNKS, device=x.device, dtype=torch.float32)
-
-        with torch.no_grad():
-            for i, t in enumerate(tqdm(time[:-1], ncols=88)):
-                # predictor: x <- r x + (sigma' - r sigma) eps(x, t)
-                ops.pc_predict(x, self.eps(x, t, c).contiguous(), r_all[i], c1_all[i])
-                # corrector: Langevin steps with delta = tau / mean(eps^2)
-                for j in range(corrections):
-                    z = torch.randn_like(x) if self.noise_source is None else self.noise_source(i, j).to(x)
-                    eps = self.eps(x, t - dt, c).contiguous()
-                    ops.sumsq_partial(eps, nb, partial)
-                    ops.pc_correct(x, eps, z.contiguous(), nb, partial, tau, sg_n[i])
-        return x.reshape(shape + tuple(self.shape))
+        sampler = self.sampler(shape, c, steps, corrections, tau)
+        for _ in tqdm(range(steps), ncols=88):
+            sampler.step()
+        return sampler.result()
 
     def loss(self, x: Tensor, c: Tensor = None, w: Tensor = None) -> Tensor:
         raise NotImplementedError('training (the denoising loss, score.py:265-276) is outside the sampling hot path')
+
+
+class PCSampler:
+    r"""State of one ``VPSDE.sample`` call (score.py:225-263): x, the host-evaluated schedule and scratch buffers.
+
+    The schedule is evaluated once on the host in fp32 with the reference's own formulas -- ``r = mu(t-dt)/mu(t)``,
+    ``c1 = sigma(t-dt) - r sigma(t)`` (score.py:252-253) -- so no 0-dim device arithmetic or host sync happens per
+    step; the updates themselves are in-place HIP kernels."""
+
+    def __init__(self, sde: VPSDE, shape, c, steps: int, corrections: int, tau: float):
+        self.sde, self.shape, self.c = sde, shape, c
+        self.steps, self.corrections, self.tau = steps, corrections, tau
+        if sde.initial_noise is not None:
+            x = sde.initial_noise.to(sde.device).clone()
+        else:
+            x = torch.randn(shape + tuple(sde.shape)).to(sde.device)       # host RNG then H2D, as the reference
+        self.x = x.reshape(-1, *sde.shape).contiguous()
+        ops._dev(self.x)
+        self.nb = self.x.shape[0]
+        time_cpu = torch.linspace(1, 0, steps + 1)
+        self.dt = 1 / steps
+        t_next = time_cpu[:-1] - self.dt
+        mu_t, mu_n = sde.mu(time_cpu[:-1]), sde.mu(t_next)
+        sg_t, sg_n = sde.sigma(time_cpu[:-1]), sde.sigma(t_next)
+        r = mu_n / mu_t
+        self.r, self.c1, self.sg_n = r.tolist(), (sg_n - r * sg_t).tolist(), sg_n.tolist()
+        self.time = time_cpu.to(sde.device)
+        self.partial = torch.empty(self.nb * ops.SUMSQ_CHUNKS, device=self.x.device, dtype=torch.float32)
+        self.i = 0
+
+    @torch.no_grad()
+    def step(self):
+        sde, x, i = self.sde, self.x, self.i
+        if i >= self.steps:
+            raise StopIteration
+        t = self.time[i]
+        # predictor: x <- r x + (sigma' - r sigma) eps(x, t)
+        ops.pc_predict(x, sde.eps(x, t, self.c).contiguous(), self.r[i], self.c1[i])
+        # corrector: Langevin steps with delta = tau / mean(eps^2)
+        for j in range(self.corrections):
+            z = torch.randn_like(x) if sde.noise_source is None else sde.noise_source(i, j).to(x)
+            eps = sde.eps(x, t - self.dt, self.c).contiguous()
+            ops.sumsq_partial(eps, self.nb, self.partial)
+            ops.pc_correct(x, eps, z.contiguous(), self.nb, self.partial, self.tau, self.sg_n[i])
+        self.i = i + 1
+
+    def result(self) -> Tensor:
+        return self.x.reshape(self.shape + tuple(self.sde.shape))
 
 
 class SubVPSDE(VPSDE):
@@ -357,7 +383,9 @@ class DPSGaussianScore(nn.Module):
         self.sde = sde
         self.zeta = zeta
 
-    def forward(self, x: Tensor, t: Tensor) -> Tensor:
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        # (the reference's signature is (x, t); ``c`` is accepted and ignored so that VPSDE.sample, which always
+        # passes it, can drive this module)
         mu, sigma = self.sde.mu(t), self.sde.sigma(t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, None, False)
         eps_d = eps.detach().contiguous()
