@@ -114,7 +114,7 @@ def cpu_baseline(wl, args, guided, corrections):
     """The CPU oracle (oracle/sda_oracle.py, pinned against the reference's own code) on a bounded sample of the
     workload: same net family / resolution / guidance, fewer trajectory windows; cost is linear in windows."""
     from oracle import sda_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, int(args.cpu_threads)) if args.cpu_threads else max(1, (os.cpu_count() or 2) // 4)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     sched = O.Schedule()
@@ -175,8 +175,12 @@ def cpu_baseline(wl, args, guided, corrections):
             xx = xx - (delta * e + torch.sqrt(2 * delta) * z) * sched.sigma(t - dt)
         return xx
 
-    xx = one_step(xx, 0)                       # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    xx = one_step(xx, 0)                       # warm-up (thread pool, allocator); also bounds the timed sample
+    t_warm = time.perf_counter() - t0
     i = 1
+    if t_warm > args.cpu_seconds:              # one step already exceeds the budget: report the warm-up step itself
+        steps_done, t_spent = 1, t_warm
     while t_spent < args.cpu_seconds and steps_done < 50:
         t0 = time.perf_counter()
         xx = one_step(xx, i)
@@ -203,6 +207,7 @@ def main():
     ap.add_argument('--per-gpu', type=int, default=0, help='override trajectories per GPU')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--cpu-windows', type=int, default=2)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = physical cores of one socket (cpu_count/4 on a 2-socket SMT box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
