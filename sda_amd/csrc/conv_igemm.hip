@@ -20,6 +20,7 @@
 // Everything that is index arithmetic lives in __host__ __device__ functions so that the very same code is
 // replayed on the CPU by the emulator at the bottom (built only into libsda_emu.so for tests/).
 #include "sda_common.hpp"
+#include <stdlib.h>
 
 #ifndef SDA_CONV_CK
 #define SDA_CONV_CK 8
@@ -41,6 +42,8 @@ struct ConvGeom {
     int ntaps;
     int bm;                        // cout tile = 32*mt
     int nstage;
+    int fast32;                    // producer offsets relative to the tile base fit 32 bits (always, in practice)
+    int debug;                     // perf-ablation bits from $SDA_CONV_DEBUG (0 in production)
     int64_t lds_bytes;
 };
 
@@ -56,7 +59,7 @@ static int pick_pow2_tile(int extent, int budget) {
     return best;
 }
 
-static int conv_plan(const sda_conv_desc* d, ConvGeom* g) {
+static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, int max_pos = SDA_CONV_MAXPOS * SDA_CONV_THREADS) {
     if (!d || !d->x || !d->w || !d->out) return SDA_E_BADARG;
     if (d->n <= 0 || d->cx <= 0 || d->cout <= 0 || d->hs <= 0 || d->ws <= 0 || d->ho <= 0 || d->wo <= 0) return SDA_E_BADARG;
     if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1)) return SDA_E_UNSUPPORTED;
@@ -74,9 +77,9 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g) {
     g->bm = 32 * d->mt;
     if (d->cout_pad % g->bm || d->cout_pad < d->cout) return SDA_E_BADARG;
     if (d->cin_pad % SDA_CONV_CK || d->cin_pad < g->cin) return SDA_E_BADARG;
-    g->tw = pick_pow2_tile(d->wo, SDA_CONV_BP);
-    g->tr = pick_pow2_tile(d->ho, SDA_CONV_BP / g->tw);
-    g->tn = SDA_CONV_BP / (g->tw * g->tr);
+    g->tw = pick_pow2_tile(d->wo, bp < 128 ? bp : 128);
+    g->tr = pick_pow2_tile(d->ho, bp / g->tw);
+    g->tn = bp / (g->tw * g->tr);
     g->tw_shift = ilog2_pow2(g->tw);
     g->tr_shift = ilog2_pow2(g->tr);
     g->tiles_x = (d->wo + g->tw - 1) / g->tw;
@@ -93,9 +96,18 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g) {
     g->in_cols = (g->tw - 1) * d->stride_w + d->kw;
     g->plane = g->in_rows * g->in_cols;
     g->S = g->tn * g->plane;
-    if (g->S > SDA_CONV_MAXPOS * SDA_CONV_THREADS) return SDA_E_UNSUPPORTED;
+    if (g->S > max_pos) return SDA_E_UNSUPPORTED;
     g->ntaps = d->kh * d->kw;
     g->nstage = d->cin_pad / SDA_CONV_CK;
+    {   // worst-case |offset| of a halo element relative to its tile's first image, channel 0
+        auto ab = [](int64_t v) { return v < 0 ? -v : v; };
+        int64_t span = (int64_t)g->tn * (ab(d->x_sn_outer) + ab(d->x_sn_inner)) + (int64_t)d->hs * ab(d->x_sy) +
+                       (int64_t)d->ws * ab(d->x_sx);
+        bool nonneg = d->x_sn_outer >= 0 && d->x_sn_inner >= 0 && d->x_sy >= 0 && d->x_sx >= 0 &&
+                      (g->tn == 1 || d->n_inner == 1 || d->x_sn_outer >= d->x_sn_inner * (int64_t)(d->n_inner - 1));
+        g->fast32 = (span < (1LL << 30)) && nonneg;
+    }
+    { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
     g->lds_bytes = ((int64_t)g->ntaps * SDA_CONV_CK * g->bm + (int64_t)SDA_CONV_CK * g->S) * 4;
     if (g->lds_bytes > 160 * 1024) return SDA_E_LDS;
     return SDA_OK;
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
     for (int st = 0; st < g.nstage; ++st) {
         const int c0 = st * CK;
         // ---- stage the weight slab: [tap][ck][BM] <- w[tap][c0+ck][co0 .. co0+BM)
-        {
+        if (!((g.debug & 2) && st > 0)) {
             constexpr int ROW4 = BM / 4;
             const int total4 = g.ntaps * CK * ROW4;
             for (int f = tid; f < total4; f += SDA_CONV_THREADS) {
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
             }
         }
         // ---- stage the input halo tile with every loader-side fusion applied
-        {
+        if (!((g.debug & 2) && st > 0)) {
             float v[NPOS][CK];
 #pragma unroll
             for (int i = 0; i < NPOS; ++i)
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
         }
         __syncthreads();
         // ---- MFMA over all taps of this channel slab
-        {
+        if (!(g.debug & 4)) {
             int dy = 0, dx = 0;
             for (int tap = 0; tap < g.ntaps; ++tap) {
                 const int toff = dy * g.in_cols + dx + pixbase;
@@ -324,6 +336,330 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
         for (int r = 0; r < 16; ++r) conv_epilogue_store(d, obase, co0 + m * 32 + mfma32_row(r, lane), acc[m][r]);
 }
 
+// ---------------------------------------------------------------- v2: wave-specialised, double-buffered kernel
+//
+// 8 wavefronts per workgroup: waves 0-3 are CONSUMERS (nothing but ds_read + v_mfma, every LDS offset an immediate),
+// waves 4-7 are PRODUCERS (global loads, loader-side fusions, LDS writes; the weight slab goes HBM/L2 -> LDS directly
+// with global_load_lds_dwordx4).  Two LDS buffers: producers fill stage s+1 while consumers multiply stage s; one
+// workgroup barrier per stage.  The matrix pipe and the VALU are separate pipes of a SIMD, so the producers' index
+// math and LayerNorm/activation arithmetic run beside the consumers' MFMAs instead of in front of them (v1 measured:
+// matrix pipe busy 65 %, SQ_WAIT_ANY 45 % of wave cycles, 5 VALU + 4 SALU instructions per MFMA).
+//
+// Compile-time: MT (cout tile = 32 MT), NT (pixel tile = 128 NT; each consumer wave owns 32 NT pixels x all MT cout
+// sub-tiles), SPAD (LDS stride between channel planes of the halo tile, >= S), KH x KW.
+template <int MT, int NT, int SPAD, int KH, int KW>
+__global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2)) void conv_igemm_ws_kernel(const sda_conv_desc d, const ConvGeom g) {
+    constexpr int CK = SDA_CONV_CK;
+    constexpr int BM = MT * 32;
+    constexpr int NTAPS = KH * KW;
+    constexpr int NPOS = (SPAD + 255) / 256;
+    constexpr int WSZ = NTAPS * CK * BM;     // floats of one weight slab
+    constexpr int BUF = WSZ + CK * SPAD;     // floats of one stage buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    const bool producer = __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    // Persistent workgroups: gridDim.x (a multiple of 8) workgroups walk all g.grid tiles.  Hardware places workgroup
+    // b on XCD b % 8; XCD x owns a contiguous range of tiles and its workgroups take them round-robin, so at any
+    // moment one XCD's L2 serves neighbouring pixel tiles (shared halos) and the cout tiles of one pixel tile.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int tq = g.grid >> 3, tr_ = g.grid & 7;
+    const int t_begin = xcd * tq + (xcd < tr_ ? xcd : tr_);
+    const int t_end = t_begin + tq + (xcd < tr_ ? 1 : 0);
+
+    if (producer) {
+        // ------------------------------------------------ producer waves: HBM/L2 -> (fusions) -> LDS
+        // Lean by construction: everything that does not depend on the channel is computed once per workgroup
+        // (per-lane 32-bit offsets relative to a wave-uniform tile base, LayerNorm statistics, validity); per stage a
+        // lane issues its loads against SGPR bases, applies <= 5 VALU per element and writes LDS at immediates.
+        const int ptid = tid & 255;
+        int gs = 0;                                    // running stage counter across tiles: buffer = gs & 1
+        for (int tile = t_begin + slot; tile < t_end; tile += per_xcd) {
+        int ct, n0, oy0, ox0;
+        conv_decode_block(g, tile, ct, n0, oy0, ox0);
+        const int co0 = ct * BM;
+        // tile base (uniform): address of image n0, channel 0, pixel (0,0)
+        const int ng0 = n0 + d.x_n_off;
+        const int64_t nb0 = (int64_t)(ng0 / d.n_inner) * d.x_sn_outer + (int64_t)(ng0 % d.n_inner) * d.x_sn_inner;
+        const float* xtile = d.x + nb0;
+        unsigned poff[NPOS];
+        int coff[NPOS], nimg[NPOS];
+        bool pvalid[NPOS];
+        float pmean[NPOS], prstd[NPOS];
+        int64_t xabs[NPOS];
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+            const int pos = ptid + i * 256;
+            poff[i] = 0; coff[i] = 0; nimg[i] = 0; pvalid[i] = false; pmean[i] = 0.f; prstd[i] = 1.f; xabs[i] = -1;
+            if (pos < g.S) {
+                const ConvPos ps = conv_decode_pos(d, g, pos, n0, oy0, ox0);
+                xabs[i] = ps.xoff; coff[i] = (int)ps.coff; nimg[i] = ps.nimg;
+                if (ps.xoff >= 0) {
+                    pvalid[i] = true;
+                    poff[i] = (unsigned)(ps.xoff - nb0);
+                    if (d.ln_mean) {
+                        pmean[i] = d.ln_mean[ps.stat];
+                        prstd[i] = d.ln_rstd[ps.stat];
+                    }
+                }
+            }
+        }
+        constexpr int ROW4 = BM / 4;
+        constexpr int TOTAL4 = NTAPS * CK * ROW4;
+        constexpr int NIT = (TOTAL4 + 255) / 256;
+        unsigned woff[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int f = ptid + it * 256;
+            const int row = f / ROW4, c4 = f - row * ROW4;
+            const int tap = row / CK, ck = row - tap * CK;
+            woff[it] = (unsigned)((tap * d.cin_pad + ck) * d.cout_pad + co0 + c4 * 4);
+        }
+        const bool fast = g.fast32 && (d.mod == nullptr || d.mod_sn == 0);
+
+        auto produce = [&](int st, float* buf) {
+            const int c0 = st * CK;
+            // weight slab: [tap][ck][BM] <- w[tap][c0+ck][co0 .. co0+BM), straight into LDS (lane-linear image)
+            const float* wst = d.w + (int64_t)c0 * d.cout_pad;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = ptid + it * 256;
+                if (it + 1 < NIT || f < TOTAL4) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wst + woff[it]),
+                                                     (__attribute__((address_space(3))) void*)(buf + (f - lane) * 4), 16, 0, 0);
+                }
+            }
+            // halo tile with every loader-side fusion applied
+            float v[NPOS][CK];
+            if (fast && c0 + CK <= d.cx) {
+                const float* xs = xtile + (int64_t)c0 * d.x_sc;
+#pragma unroll
+                for (int ck = 0; ck < CK; ++ck) {
+                    const float* xc = xs + (int64_t)ck * d.x_sc;            // wave-uniform channel base
+#pragma unroll
+                    for (int i = 0; i < NPOS; ++i) v[i][ck] = xc[poff[i]];
+                }
+                if (d.ln_mean) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck) {
+                        const float m = d.mod ? d.mod[c0 + ck] : 0.f;       // shared modulation: scalar
+#pragma unroll
+                        for (int i = 0; i < NPOS; ++i) v[i][ck] = ((v[i][ck] + m) - pmean[i]) * prstd[i];
+                    }
+                } else if (d.mod) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck) {
+                        const float m = d.mod[c0 + ck];
+#pragma unroll
+                        for (int i = 0; i < NPOS; ++i) v[i][ck] += m;
+                    }
+                }
+                // activation id is wave-uniform: branch once per stage, not once per element
+#define SDA_APPLY_ACT(ID)                                                               \
+    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck)                                  \
+        _Pragma("unroll") for (int i = 0; i < NPOS; ++i) v[i][ck] = sda_act(ID, v[i][ck]);
+                switch (d.act_in) {
+                    case SDA_ACT_SILU: SDA_APPLY_ACT(SDA_ACT_SILU) break;
+                    case SDA_ACT_RELU: SDA_APPLY_ACT(SDA_ACT_RELU) break;
+                    case SDA_ACT_ELU:  SDA_APPLY_ACT(SDA_ACT_ELU) break;
+                    case SDA_ACT_GELU: SDA_APPLY_ACT(SDA_ACT_GELU) break;
+                    case SDA_ACT_SELU: SDA_APPLY_ACT(SDA_ACT_SELU) break;
+                    default: break;
+                }
+#undef SDA_APPLY_ACT
+#pragma unroll
+                for (int ck = 0; ck < CK; ++ck)
+#pragma unroll
+                    for (int i = 0; i < NPOS; ++i) v[i][ck] = pvalid[i] ? v[i][ck] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) {
+                    ConvPos ps;
+                    ps.xoff = xabs[i]; ps.coff = coff[i]; ps.stat = 0; ps.nimg = nimg[i];
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck) v[i][ck] = conv_load_value(d, g, ps, c0 + ck, pmean[i], prstd[i]);
+                }
+            }
+            float* s_in = buf + WSZ;
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) {
+                const int pos = ptid + i * 256;
+                if (pos < g.S) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck) s_in[ck * SPAD + pos] = v[i][ck];
+                }
+            }
+        };
+
+        for (int st = 0; st < g.nstage; ++st, ++gs) {
+            if (!((g.debug & 2) && gs > 0)) produce(st, smem + (gs & 1) * BUF);
+            __syncthreads();
+        }
+        }   // tiles
+        __syncthreads();                               // pairs with the consumers' final barrier
+    } else {
+        // ------------------------------------------------ consumer waves: ds_read + MFMA only
+        __builtin_amdgcn_s_setprio(2);                 // the matrix-pipe feeders outrank the loaders on their SIMD
+        int pixbase[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) pixbase[q] = conv_pix_lds_base(d, g, (wave * NT + q) * 32 + l31);
+        int gs = 0;
+        __syncthreads();                               // stage 0 of the first tile has landed
+        for (int tile = t_begin + slot; tile < t_end; tile += per_xcd) {
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+        for (int st = 0; st < g.nstage; ++st, ++gs) {
+            const float* buf = smem + (gs & 1) * BUF;
+            if (g.debug & 4) { __syncthreads(); continue; }
+            const float* bw = buf + khalf * BM + l31;
+            const float* bin = buf + WSZ + khalf * SPAD;
+            // operands of one tap live in registers; the next tap's are fetched while this tap's MFMAs run
+            float av[2][CK / 2][MT], bv[2][CK / 2][NT];
+            auto fetch = [&](int tap, int slot_) {
+                const int dy = tap / KW, dx = tap - dy * KW;
+                const int toff = dy * g.in_cols + dx;
+#pragma unroll
+                for (int k2 = 0; k2 < CK / 2; ++k2) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) bv[slot_][k2][q] = bin[pixbase[q] + toff + 2 * k2 * SPAD];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[slot_][k2][m] = bw[(tap * CK + 2 * k2) * BM + m * 32];
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                if (tap + 1 < NTAPS) fetch(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);       // keep the next tap's ds_reads ahead of this tap's MFMAs
+#pragma unroll
+                for (int k2 = 0; k2 < CK / 2; ++k2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap & 1][k2][m], bv[tap & 1][k2][q], acc[m][q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                           // producers may now refill this buffer; next stage is ready
+        }
+
+        // epilogue of this tile (the producers are already staging the next tile's second stage)
+        int ct, n0, oy0, ox0;
+        conv_decode_block(g, tile, ct, n0, oy0, ox0);
+        const int co0 = ct * BM;
+        // All loads of a 16-register fragment (bias / act'(z) operand / residual) are issued before its first store:
+        // `out` may alias nothing here, but the compiler cannot know, and a load placed after a store waits for it.
+        const int hw_o = d.ho * d.wo;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int64_t obase = conv_pix_out_base(d, g, (wave * NT + q) * 32 + l31, n0, oy0, ox0);
+            const bool pvalid = obase >= 0;
+            const int64_t ob = pvalid ? obase : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int cb = co0 + m * 32 + 4 * khalf;          // co = cb + (r & 3) + 8 * (r >> 2)
+                float bia[16], zv[16], rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb + (r & 3) + 8 * (r >> 2);
+                    const bool ok = pvalid && co < d.cout;
+                    const int64_t off = ob + (int64_t)(ok ? co : 0) * hw_o;
+                    bia[r] = (d.bias && ok) ? d.bias[co] : 0.f;
+                    zv[r] = d.dact_z ? d.dact_z[off] : 0.f;
+                    rv[r] = d.res ? d.res[off] : 0.f;
+                }
+                if (d.dact_z) {
+#define SDA_APPLY_DACT(ID) _Pragma("unroll") for (int r = 0; r < 16; ++r) zv[r] = sda_dact(ID, zv[r]);
+                    switch (d.act_d) {
+                        case SDA_ACT_SILU: SDA_APPLY_DACT(SDA_ACT_SILU) break;
+                        case SDA_ACT_RELU: SDA_APPLY_DACT(SDA_ACT_RELU) break;
+                        case SDA_ACT_ELU:  SDA_APPLY_DACT(SDA_ACT_ELU) break;
+                        case SDA_ACT_GELU: SDA_APPLY_DACT(SDA_ACT_GELU) break;
+                        case SDA_ACT_SELU: SDA_APPLY_DACT(SDA_ACT_SELU) break;
+                        default: break;
+                    }
+#undef SDA_APPLY_DACT
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zv[r] = 1.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb + (r & 3) + 8 * (r >> 2);
+                    const float v = (acc[m][q][r] + bia[r]) * zv[r] + rv[r];
+                    if (pvalid && co < d.cout) d.out[ob + (int64_t)co * hw_o] = v;
+                }
+            }
+        }
+        }   // tiles
+    }
+}
+
+template <int MT, int NT, int SPAD, int KH, int KW>
+static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    constexpr int BUF = KH * KW * SDA_CONV_CK * MT * 32 + SDA_CONV_CK * SPAD;
+    constexpr int lds = 2 * BUF * 4;
+    static_assert(lds <= 160 * 1024, "stage buffers exceed the LDS");
+    auto kern = conv_igemm_ws_kernel<MT, NT, SPAD, KH, KW>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    // persistent grid: as many workgroups as stay co-resident
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SDA_E_BADARG;
+        cus = prop.multiProcessorCount;
+    }
+    const int per_cu = (NT == 1 && 2 * lds <= 160 * 1024 && MT <= 3 && SPAD <= 392) ? 2 : 1;
+    int grid = cus * per_cu;
+    grid -= grid % 8;
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
+    return sda_launch_status();
+}
+
+// NT = 2 (256-pixel tiles, one workgroup per CU): SPAD classes 400 / 520 / 1280
+// NT = 1 (128-pixel tiles, two workgroups per CU when LDS allows): SPAD classes 272 / 392 / 1024
+template <int MT, int KH, int KW>
+static int conv_launch_ws_s(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    if (g.tn * g.tr * g.tw == 128) {
+        if (g.S <= 272) return conv_launch_ws<MT, 1, 272, KH, KW>(d, g, stream);
+        if (g.S <= 392) return conv_launch_ws<MT, 1, 392, KH, KW>(d, g, stream);
+        if (MT <= 3 && g.S <= 1024) return conv_launch_ws<MT, 1, 1024, KH, KW>(d, g, stream);
+        return SDA_E_LDS;
+    }
+    if (g.S <= 400) return conv_launch_ws<MT, 2, 400, KH, KW>(d, g, stream);
+    if (g.S <= 520) return conv_launch_ws<MT, 2, 520, KH, KW>(d, g, stream);
+    if (g.S <= 1280) return conv_launch_ws<MT, 2, 1280, KH, KW>(d, g, stream);
+    return SDA_E_LDS;
+}
+
+template <int KH, int KW>
+static int conv_launch_ws_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    switch (d->mt) {
+        case 1: return conv_launch_ws_s<1, KH, KW>(d, g, stream);
+        case 2: return conv_launch_ws_s<2, KH, KW>(d, g, stream);
+        case 3: return conv_launch_ws_s<3, KH, KW>(d, g, stream);
+        default: return conv_launch_ws_s<4, KH, KW>(d, g, stream);
+    }
+}
+
 template <int MT, int NPOS>
 static int conv_launch_t(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
     auto kern = conv_igemm_kernel<MT, NPOS>;
@@ -344,10 +680,24 @@ static int conv_launch_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t 
 }
 
 extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    static const bool force_v1 = getenv("SDA_CONV_V1") != nullptr;
+    if (!force_v1 && d && ((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 3))) {
+        ConvGeom g2;
+        // 256-pixel tiles (one workgroup per CU) unless the problem is too small to give every CU a tile, or forced
+        static const int nt_env = getenv("SDA_CONV_NT") ? atoi(getenv("SDA_CONV_NT")) : 0;
+        int rc2 = nt_env == 1 ? SDA_E_LDS : conv_plan(d, &g2, 256, 1280);
+        if (nt_env != 2 && (rc2 != SDA_OK || g2.grid < 256)) rc2 = conv_plan(d, &g2, 128, 1024);
+        if (rc2 == SDA_OK) {
+            rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
+            if (rc2 != SDA_E_LDS) return rc2;
+        } else if (rc2 != SDA_E_UNSUPPORTED && rc2 != SDA_E_LDS) {
+            return rc2;
+        }
+    }
     ConvGeom g;
     int rc = conv_plan(d, &g);
     if (rc != SDA_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     switch (d->mt) {
         case 1: return conv_launch_m<1>(d, g, s);
         case 2: return conv_launch_m<2>(d, g, s);

@@ -38,9 +38,9 @@ def round_up(v: int, m: int) -> int:
 
 
 def pick_mt(cout: int) -> int:
-    """cout tile = 32*mt; choose the mt in 1..4 that wastes the fewest padded output channels (ties: larger)."""
+    """cout tile = 32*mt; choose the mt in 1..4 that wastes the fewest padded output channels."""
     best, best_pad = 1, None
-    for mt in (4, 3, 2, 1):
+    for mt in (3, 4, 2, 1):      # ties prefer 96-wide tiles: two double-buffered workgroups fit one CU's LDS
         pad = round_up(cout, 32 * mt)
         if best_pad is None or pad < best_pad:
             best, best_pad = mt, pad

@@ -26,6 +26,10 @@ LAYERS = [
     ('head0   11->96  s1', 11, 96, S, 1, 1, 1, False),
     ('blk0    96->96  LN', 96, 96, S, 1, 1, 1, True),
     ('blk0    96->96  act', 96, 96, S, 1, 1, 1, 'act'),
+    ('blk0    96->96  actonly', 96, 96, S, 1, 1, 1, 'actonly'),
+    ('blk0    96->96  resonly', 96, 96, S, 1, 1, 1, 'resonly'),
+    ('blk0    96->96  plain', 96, 96, S, 1, 1, 1, False),
+    ('blk0^T  96->96  dact', 96, 96, S, 1, 1, 1, 'dact'),
     ('head1   96->192 s2', 96, 192, S, 2, 1, 1, False),
     ('blk1   192->192 LN', 192, 192, S // 2, 1, 1, 1, True),
     ('head2  192->384 s2', 192, 384, S // 2, 2, 1, 1, False),
@@ -53,6 +57,12 @@ for name, cin, cout, h, stride, up, zins, fused in LAYERS:
         kw.update(ln=(mean, rstd), mod=torch.randn(1, cin, device=dev))
     elif fused == 'act':
         kw.update(act_in=1, res=torch.randn_like(out))
+    elif fused == 'actonly':
+        kw.update(act_in=1)
+    elif fused == 'resonly':
+        kw.update(res=torch.randn_like(out))
+    elif fused == 'dact':
+        kw.update(dact_z=torch.randn_like(out), act_d=1)
     launch_conv(pk, planar_source(x), out, ho, ho, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
