@@ -309,8 +309,13 @@ def main():
         if prof is not None:
             s = prof.summary()
             ach = s['total_flops'] / (s['total_ms'] * 1e-3) / 1e12 if s['total_ms'] > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)', 'achieved': ach,
-                               'peak': 157.3, 'unit': 'TFLOP/s', 'frac': ach / 157.3, 'traffic': None,
+            traffic = None
+            tfile = os.path.join(ROOT, 'profiles', f'r01_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
+            if os.path.exists(tfile):          # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command
+                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_igemm_ws_kernel (fp32 v_mfma_f32_32x32x2_f32)', 'achieved': ach,
+                               'peak': 157.3, 'unit': 'TFLOP/s', 'frac': ach / 157.3, 'traffic': traffic,
+                               'traffic_source': os.path.basename(tfile) if traffic is not None else None,
                                'launches': s['launches'], 'avg_launch_ms': s['total_ms'] / max(1, s['launches']),
                                'avg_launch_gflop': s['total_flops'] / max(1, s['launches']) / 1e9,
                                'conv_time_share_of_step': s['total_ms'] * 1e-3 / elapsed}
