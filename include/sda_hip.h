@@ -143,6 +143,21 @@ int sda_linear_small(const float* x, int rows, int in_f, const float* w, const f
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fully-connected layers of ScoreNet / ResMLP (the Lorenz local kernel; sda/nn.py:31-71, sda/score.py:38-63), row-major
+ * (rows, features) fp32, on the fp32 matrix cores:
+ *   y = act_out( act_in(x) . Wop + b ) * act'(dact_z) + res
+ *   trans_w = 0: Wop = w^T with w = torch's [out_f][in_f]  (forward of nn.Linear)
+ *   trans_w = 1: Wop = w   with w = [in_f][out_f]          (backward-data of nn.Linear: gx = gy . W, pass in_f = W's out)
+ * and zuko.nn.LayerNorm over the last axis (call site sda/nn.py:61) with its input gradient; one 64-lane wavefront per
+ * row, shuffle reductions.
+ * ------------------------------------------------------------------------------------------ */
+int sda_linear(const float* x, int rows, int in_f, const float* w, const float* b, int out_f, int trans_w, int act_in,
+               int act_out, const float* dact_z, int act_d, const float* res, float* y, void* stream);
+int sda_row_ln(const float* x, int rows, int f, float eps, int unbiased, float* y, float* mean, float* rstd, void* stream);
+int sda_row_ln_bwd(const float* gh, const float* x, int rows, int f, const float* mean, const float* rstd, int unbiased,
+                   const float* res, float* gx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * MCScoreNet.fold (sda/score.py:155-164): selective gather, NOT an overlap-add.
  *   s: [b][nw][(2k+1)*c][hw] -> out: [b][nw+2k][c][hw]
  * and the adjoints needed for the guidance gradient (sda/score.py:394):

@@ -63,6 +63,9 @@ SIGNATURES = {
                            c_void_p]),
     'sda_time_embed': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear_small': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
+    'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),
+    'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
+    'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_fold': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_fold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_unfold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int64, c_fp, c_void_p]),

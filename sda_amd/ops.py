@@ -192,6 +192,36 @@ def linear_small(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     return y
 
 
+# ------------------------------------------------------------------------------------------ ResMLP pieces
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], *, trans_w: bool = False, act_in: int = 0, act_out: int = 0,
+           dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None) -> Tensor:
+    """x: (rows, in) contiguous.  trans_w=False: w is torch's [out][in] (forward);  True: w is [in][out] (gx = gy @ W)."""
+    _dev(x, w, b, dact_z, res)
+    rows, in_f = x.shape
+    out_f = w.shape[1] if trans_w else w.shape[0]
+    assert (w.shape[0] if trans_w else w.shape[1]) == in_f
+    y = torch.empty(rows, out_f, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().sda_linear(x.data_ptr(), rows, in_f, w.data_ptr(), _ptr(b), out_f, int(trans_w), act_in,
+                                      act_out, _ptr(dact_z), act_d, _ptr(res), y.data_ptr(), _stream()), 'sda_linear')
+    return y
+
+
+def row_ln(x: Tensor, eps: float, unbiased: bool, y: Tensor, mean: Optional[Tensor] = None,
+           rstd: Optional[Tensor] = None):
+    _dev(x, y, mean, rstd)
+    rows, f = x.shape
+    _lib.check(_lib.load().sda_row_ln(x.data_ptr(), rows, f, eps, int(unbiased), y.data_ptr(), _ptr(mean), _ptr(rstd),
+                                      _stream()), 'sda_row_ln')
+
+
+def row_ln_bwd(gh: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, unbiased: bool, res: Optional[Tensor], gx: Tensor):
+    _dev(gh, x, mean, rstd, res, gx)
+    rows, f = x.shape
+    _lib.check(_lib.load().sda_row_ln_bwd(gh.data_ptr(), x.data_ptr(), rows, f, mean.data_ptr(), rstd.data_ptr(),
+                                          int(unbiased), _ptr(res), gx.data_ptr(), _stream()), 'sda_row_ln_bwd')
+
+
 # ------------------------------------------------------------------------------------------ fold / unfold adjoints
 
 def fold(s: Tensor, b: int, nw: int, k: int, c: int, hw: int, out: Tensor):

@@ -125,10 +125,45 @@ def install(monkeypatch):
         v = 0 if vjp is None else sigma * vjp
         out.copy_(eps - (sigma / mu) * (ghat - v))
 
+    def linear(x, w, b, *, trans_w=False, act_in=0, act_out=0, dact_z=None, act_d=0, res=None):
+        xin = _ACT[act_in](x) if act_in else x
+        y = xin @ (w if trans_w else w.t())
+        if b is not None:
+            y = y + b
+        if act_out:
+            y = _ACT[act_out](y)
+        if dact_z is not None:
+            with torch.enable_grad():
+                zz = dact_z.detach().clone().requires_grad_(True)
+                dz, = torch.autograd.grad(_ACT[act_d](zz).sum(), zz)
+            y = y * dz
+        if res is not None:
+            y = y + res
+        return y.contiguous()
+
+    def row_ln(x, eps, unbiased, y, mean=None, rstd=None):
+        var, m = torch.var_mean(x, dim=-1, unbiased=bool(unbiased), keepdim=True)
+        r = 1 / torch.sqrt(var + eps)
+        y.copy_((x - m) * r)
+        if mean is not None:
+            mean.copy_(m.reshape(-1))
+        if rstd is not None:
+            rstd.copy_(r.reshape(-1))
+
+    def row_ln_bwd(gh, x, mean, rstd, unbiased, res, gx):
+        f = x.shape[-1]
+        h = (x - mean[:, None]) * rstd[:, None]
+        a = gh.mean(-1, keepdim=True)
+        b2 = (gh * h).sum(-1, keepdim=True) / (f - 1 if unbiased else f)
+        out = rstd[:, None] * (gh - a - h * b2)
+        if res is not None:
+            out = out + res
+        gx.copy_(out)
+
     for name, fn in dict(_dev=_dev, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
                          ln_bwd=ln_bwd, time_embed=time_embed, linear_small=linear_small, fold=fold,
                          fold_adjoint=fold_adjoint, unfold_adjoint=unfold_adjoint, pc_predict=pc_predict,
                          sumsq_partial=sumsq_partial, pc_correct=pc_correct, denoise=denoise,
-                         guided_combine=guided_combine).items():
+                         guided_combine=guided_combine, linear=linear, row_ln=row_ln, row_ln_bwd=row_ln_bwd).items():
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: n)

@@ -226,3 +226,39 @@ def test_size_independent_properties_full_size(dev):
     v2, = torch.autograd.grad(out, xg, g2, retain_graph=True)
     v12, = torch.autograd.grad(out, xg, 2 * g1 - 3 * g2)
     assert rel_err(v12, 2 * v1 - 3 * v2) < 1e-4
+
+
+def test_golden_scorenet_local_and_guided_sampling(dev):
+    """Lorenz local kernel (ResMLP over trajectory windows) vs the reference's fixture, its VJP vs the oracle, and a
+    guided PC run with the experiment's strided observation (experiments/lorenz/eval.py:72-84)."""
+    from sda_amd.experiments.lorenz import make_local_score
+    from sda_amd.score import GaussianScore, MCScoreNet, VPSDE
+    g, grp = load_golden('scorenet_local_tiny')
+    net = MCScoreNet(features=3, order=2, embedding=8, hidden_features=[16] * 2, activation=nn.SiLU)
+    net.load_state_dict(grp['sd'])
+    sd = {k: v.clone() for k, v in grp['sd'].items()}
+    net.to(dev)
+    with torch.no_grad():
+        out = net(g['x'].to(dev), g['t'].to(dev))
+    assert_close(out.cpu(), g['out'], TOL)
+    cfg = O.ResMLPConfig(15 + 8, 15, (16, 16), 'SiLU')
+    eps_o = lambda x, t: O.mc_score_net(lambda a, b, c: O.score_net(sd, 'kernel.', cfg, a, b, c), 2, x, t)
+    torch.manual_seed(0)
+    gg = torch.randn_like(g['x'])
+    xo = g['x'].clone().requires_grad_(True)
+    ref, = torch.autograd.grad(eps_o(xo, g['t']), xo, gg)
+    xs = g['x'].to(dev).requires_grad_(True)
+    got, = torch.autograd.grad(net(xs, g['t'].to(dev)), xs, gg.to(dev))
+    assert_close(got.cpu(), ref, TOL)
+
+    # the experiment-size local net (window 5, width 128, depth 5), guided, a few PC steps: finite and deterministic
+    torch.manual_seed(1)
+    big = make_local_score().to(dev)
+    A = lambda x: x[..., ::8, :1]
+    y = torch.randn(4, 9, 1)
+    sde = VPSDE(GaussianScore(y, A=A, std=0.5, sde=VPSDE(big, shape=()), gamma=3e-2), shape=(65, 3)).to(dev)
+    torch.manual_seed(2)
+    x1 = sde.sample((4,), steps=4, corrections=1, tau=0.25)
+    torch.manual_seed(2)
+    x2 = sde.sample((4,), steps=4, corrections=1, tau=0.25)
+    assert torch.isfinite(x1).all() and torch.equal(x1, x2)

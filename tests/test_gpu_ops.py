@@ -212,3 +212,33 @@ def test_pc_updates_and_guidance_glue(dev):
     out = torch.empty(b, per, device=dev)
     ops.guided_combine(eps.to(dev), z.to(dev), x.to(dev), 0.7, 0.6, out)
     assert_close(out.cpu(), eps - 0.6 * (z / 0.7 - (0.6 / 0.7) * x), 1e-5)
+
+
+def test_linear_and_row_layernorm(dev):
+    from sda_amd import ops
+    from sda_amd._lib import ACT_IDS
+    torch.manual_seed(15)
+    for rows, fin, fout in ((5, 23, 16), (300, 128, 128), (130, 256, 15), (64, 16, 200)):
+        x, w, b = torch.randn(rows, fin), torch.randn(fout, fin) / fin ** 0.5, torch.randn(fout)
+        y = ops.linear(x.to(dev), w.to(dev), b.to(dev))
+        assert_close(y.cpu(), F.linear(x, w, b), TOL, what=f'linear {rows}x{fin}->{fout}')
+        res = torch.randn(rows, fout)
+        y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act_in=ACT_IDS['SiLU'], res=res.to(dev))
+        assert_close(y.cpu(), F.linear(F.silu(x), w, b) + res, TOL, what='linear act_in+res')
+        g = torch.randn(rows, fout)
+        z = torch.randn(rows, fin, requires_grad=True)
+        dz, = torch.autograd.grad(F.silu(z).sum(), z)
+        gx = ops.linear(g.to(dev), w.to(dev), None, trans_w=True, dact_z=z.detach().to(dev), act_d=ACT_IDS['SiLU'])
+        assert_close(gx.cpu(), (g @ w) * dz, TOL, what='linear backward-data * act\'')
+    for rows, f in ((7, 23), (100, 128), (33, 256), (5, 1000)):
+        x = (torch.randn(rows, f) * 2 + 0.7).requires_grad_(True)
+        xd = x.detach().to(dev)
+        y = torch.empty_like(xd); mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+        ops.row_ln(xd, 1e-5, True, y, mean, rstd)
+        ref = O.layer_norm(x, dim=-1)
+        assert_close(y.cpu(), ref, TOL, what='row_ln')
+        g, res = torch.randn(rows, f), torch.randn(rows, f)
+        gx_ref, = torch.autograd.grad(ref, x, g)
+        gx = torch.empty_like(xd)
+        ops.row_ln_bwd(g.to(dev), xd, mean, rstd, True, res.to(dev), gx)
+        assert_close(gx.cpu(), gx_ref + res, TOL, what='row_ln_bwd')

@@ -138,3 +138,25 @@ def test_generic_kernel_path_user_subclass():
     net.load_state_dict(grp['sd'])
     with torch.no_grad():
         assert_close(net(g['x'], g['t']), g['out'], TOL)
+
+
+def test_scorenet_local_golden_and_vjp():
+    """Lorenz local kernel: MCScoreNet(features=3, order=2) over a ScoreNet/ResMLP (score.py:38-63, nn.py:31-71)."""
+    from oracle import sda_oracle as O
+    from sda_amd.score import MCScoreNet
+    g, grp = load_golden('scorenet_local_tiny')
+    net = MCScoreNet(features=3, order=2, embedding=8, hidden_features=[16] * 2, activation=nn.SiLU)
+    net.load_state_dict(grp['sd'])
+    with torch.no_grad():
+        out = net(g['x'], g['t'])
+    assert_close(out, g['out'], TOL)
+    cfg = O.ResMLPConfig(15 + 8, 15, (16, 16), 'SiLU')
+    sd = grp['sd']
+    eps_o = lambda x, t: O.mc_score_net(lambda a, b, c: O.score_net(sd, 'kernel.', cfg, a, b, c), 2, x, t)
+    torch.manual_seed(0)
+    gg = torch.randn_like(g['x'])
+    xo = g['x'].clone().requires_grad_(True)
+    ref, = torch.autograd.grad(eps_o(xo, g['t']), xo, gg)
+    xs = g['x'].clone().requires_grad_(True)
+    got, = torch.autograd.grad(net(xs, g['t']), xs, gg)
+    assert_close(got, ref, 5e-5)
