@@ -228,6 +228,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = calibrate: fastest of 8..128 threads on a probe conv')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -265,11 +266,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.graph:
+        sampler.capture()
     for _ in range(args.warmup):
         sampler.step()
     sync()
     prof = None
-    if rank == 0 and not args.no_profile:
+    if rank == 0 and not args.no_profile and not args.graph:
         prof = ops.ConvProfile()
         ops.conv_profile = prof
     t0 = time.perf_counter()
@@ -302,7 +305,7 @@ def main():
             'config': {'workload': args.workload, 'description': wl['desc'], 'event': list(event),
                        'per_gpu_batch': b, 'global_batch': global_batch, 'guided': bool(args.guided),
                        'corrections': args.corrections, 'tau': args.tau, 'schedule_steps': 1000,
-                       'score_evals_per_step': 1 + args.corrections, 'parallelism': f'dp{world} (batch-sharded, no in-loop collective)'},
+                       'score_evals_per_step': 1 + args.corrections, 'hipgraph_step': bool(args.graph), 'parallelism': f'dp{world} (batch-sharded, no in-loop collective)'},
             'wallclock_per_1000_steps_s': elapsed / args.steps * 1000,
             'samples_finite': finite, 'final_allgather_ms': gather_ms,
         }

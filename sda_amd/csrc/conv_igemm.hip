@@ -42,6 +42,7 @@ struct ConvGeom {
     int ntaps;
     int bm;                        // cout tile = 32*mt
     int nstage;
+    int wide_out;                  // 4-pixel groups of the output are contiguous + 16-B aligned: dwordx4 epilogue
     int fast32;                    // producer offsets relative to the tile base fit 32 bits (always, in practice)
     int debug;                     // perf-ablation bits from $SDA_CONV_DEBUG (0 in production)
     int64_t lds_bytes;
@@ -99,6 +100,9 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
     if (g->S > max_pos) return SDA_E_UNSUPPORTED;
     g->ntaps = d->kh * d->kw;
     g->nstage = d->cin_pad / SDA_CONV_CK;
+    g->wide_out = (d->wo % 4 == 0) && (g->tw >= 4) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0) &&
+                  (!d->res || (reinterpret_cast<uintptr_t>(d->res) & 15) == 0) &&
+                  (!d->dact_z || (reinterpret_cast<uintptr_t>(d->dact_z) & 15) == 0);
     {   // worst-case |offset| of a halo element relative to its tile's first image, channel 0
         auto ab = [](int64_t v) { return v < 0 ? -v : v; };
         int64_t span = (int64_t)g->tn * (ab(d->x_sn_outer) + ab(d->x_sn_inner)) + (int64_t)d->hs * ab(d->x_sy) +
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
     constexpr int NPOS = (SPAD + 255) / 256;
     constexpr int WSZ = NTAPS * CK * BM;     // floats of one weight slab
     constexpr int BUF = WSZ + CK * SPAD;     // floats of one stage buffer
+    // wide (dwordx4) epilogue through a wave-private LDS slab: needs NT = 2 (64-pixel runs) and 8 KiB more LDS
+    constexpr bool WIDE_EPI = (NT == 2) && (2 * BUF * 4 + 4 * 16 * 32 * NT * 4 <= 160 * 1024);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -459,19 +465,18 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
                         for (int i = 0; i < NPOS; ++i) v[i][ck] += m;
                     }
                 }
-                // activation id is wave-uniform: branch once per stage, not once per element
-#define SDA_APPLY_ACT(ID)                                                               \
-    _Pragma("unroll") for (int ck = 0; ck < CK; ++ck)                                  \
-        _Pragma("unroll") for (int i = 0; i < NPOS; ++i) v[i][ck] = sda_act(ID, v[i][ck]);
-                switch (d.act_in) {
-                    case SDA_ACT_SILU: SDA_APPLY_ACT(SDA_ACT_SILU) break;
-                    case SDA_ACT_RELU: SDA_APPLY_ACT(SDA_ACT_RELU) break;
-                    case SDA_ACT_ELU:  SDA_APPLY_ACT(SDA_ACT_ELU) break;
-                    case SDA_ACT_GELU: SDA_APPLY_ACT(SDA_ACT_GELU) break;
-                    case SDA_ACT_SELU: SDA_APPLY_ACT(SDA_ACT_SELU) break;
-                    default: break;
+                // activation id is wave-uniform: branch once per stage, not once per element (SiLU inlined, rest generic)
+                if (d.act_in == SDA_ACT_SILU) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck)
+#pragma unroll
+                        for (int i = 0; i < NPOS; ++i) v[i][ck] = sda_act(SDA_ACT_SILU, v[i][ck]);
+                } else if (d.act_in) {
+#pragma unroll
+                    for (int ck = 0; ck < CK; ++ck)
+#pragma unroll
+                        for (int i = 0; i < NPOS; ++i) v[i][ck] = sda_act(d.act_in, v[i][ck]);
                 }
-#undef SDA_APPLY_ACT
 #pragma unroll
                 for (int ck = 0; ck < CK; ++ck)
 #pragma unroll
@@ -558,6 +563,78 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
         int ct, n0, oy0, ox0;
         conv_decode_block(g, tile, ct, n0, oy0, ox0);
         const int co0 = ct * BM;
+        if (g.debug & 8) {                              // ablation: no epilogue memory traffic at all
+            float keep = 0.f;
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[m][q][r];
+            if (keep == 123.456f) d.out[0] = keep;
+            continue;
+        }
+        if (WIDE_EPI && g.wide_out) {
+            // Store-issue is what an MFMA epilogue pays for (~400+ cycles per store instruction with every CU storing),
+            // so each 16-cout x 64-pixel fragment is transposed through a wave-private LDS slab and leaves as
+            // global_store_dwordx4 of 4 consecutive pixels per lane: 24 stores per wave and tile instead of 96.
+            float* slab = smem + 2 * BUF + wave * (16 * 32 * NT);
+            const int hw_w = d.ho * d.wo;
+            const int px4 = (lane & 15) * 4;                       // 16 lanes cover the wave's 32*NT-pixel run (NT = 2)
+            const int64_t gb = conv_pix_out_base(d, g, wave * 32 * NT + px4, n0, oy0, ox0);
+            const bool gvalid = gb >= 0;
+            const int64_t gbs = gvalid ? gb : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr)
+                            slab[((rr & 3) + 8 * (rr >> 2) + 4 * khalf) * (32 * NT) + q * 32 + l31] = acc[m][q][8 * h + rr];
+#pragma unroll
+                    for (int it0 = 0; it0 < 4; it0 += 2) {
+                        f32x4 val[2], zz[2], rs[2];
+                        float bia[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int lr = (it0 + u) * 4 + (lane >> 4);
+                            const int co = co0 + m * 32 + 16 * h + lr;
+                            const bool ok = gvalid && co < d.cout;
+                            const int64_t off = gbs + (int64_t)(ok ? co : 0) * hw_w;
+                            val[u] = *reinterpret_cast<const f32x4*>(slab + lr * (32 * NT) + px4);
+                            bia[u] = (d.bias && ok) ? d.bias[co] : 0.f;
+                            if (d.dact_z) zz[u] = *reinterpret_cast<const f32x4*>(d.dact_z + off);
+                            if (d.res) rs[u] = *reinterpret_cast<const f32x4*>(d.res + off);
+                        }
+                        if (d.dact_z) {                  // activation id is wave-uniform
+                            if (d.act_d == SDA_ACT_SILU) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) zz[u][e] = sda_dact(SDA_ACT_SILU, zz[u][e]);
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) zz[u][e] = sda_dact(d.act_d, zz[u][e]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int lr = (it0 + u) * 4 + (lane >> 4);
+                            const int co = co0 + m * 32 + 16 * h + lr;
+                            f32x4 v = val[u] + bia[u];
+                            if (d.dact_z) v *= zz[u];
+                            if (d.res) v += rs[u];
+                            if (gvalid && co < d.cout) *reinterpret_cast<f32x4*>(d.out + gbs + (int64_t)co * hw_w) = v;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         // All loads of a 16-register fragment (bias / act'(z) operand / residual) are issued before its first store:
         // `out` may alias nothing here, but the compiler cannot know, and a load placed after a store waits for it.
         const int hw_o = d.ho * d.wo;
@@ -580,16 +657,13 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
                     rv[r] = d.res ? d.res[off] : 0.f;
                 }
                 if (d.dact_z) {
-#define SDA_APPLY_DACT(ID) _Pragma("unroll") for (int r = 0; r < 16; ++r) zv[r] = sda_dact(ID, zv[r]);
-                    switch (d.act_d) {
-                        case SDA_ACT_SILU: SDA_APPLY_DACT(SDA_ACT_SILU) break;
-                        case SDA_ACT_RELU: SDA_APPLY_DACT(SDA_ACT_RELU) break;
-                        case SDA_ACT_ELU:  SDA_APPLY_DACT(SDA_ACT_ELU) break;
-                        case SDA_ACT_GELU: SDA_APPLY_DACT(SDA_ACT_GELU) break;
-                        case SDA_ACT_SELU: SDA_APPLY_DACT(SDA_ACT_SELU) break;
-                        default: break;
+                    if (d.act_d == SDA_ACT_SILU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zv[r] = sda_dact(SDA_ACT_SILU, zv[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zv[r] = sda_dact(d.act_d, zv[r]);
                     }
-#undef SDA_APPLY_DACT
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) zv[r] = 1.f;
@@ -609,7 +683,8 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
 template <int MT, int NT, int SPAD, int KH, int KW>
 static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
     constexpr int BUF = KH * KW * SDA_CONV_CK * MT * 32 + SDA_CONV_CK * SPAD;
-    constexpr int lds = 2 * BUF * 4;
+    constexpr int slab = (NT == 2 && 2 * BUF * 4 + 4 * 16 * 32 * NT * 4 <= 160 * 1024) ? 4 * 16 * 32 * NT * 4 : 0;
+    constexpr int lds = 2 * BUF * 4 + slab;
     static_assert(lds <= 160 * 1024, "stage buffers exceed the LDS");
     auto kern = conv_igemm_ws_kernel<MT, NT, SPAD, KH, KW>;
     static bool attr_set = false;
@@ -629,6 +704,8 @@ static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t
     const int per_cu = (NT == 1 && 2 * lds <= 160 * 1024 && MT <= 3 && SPAD <= 392) ? 2 : 1;
     int grid = cus * per_cu;
     grid -= grid % 8;
+    const int need = (g.grid + 7) / 8 * 8;            // never launch more workgroups than there are tiles (x8 for the XCD map)
+    if (grid > need) grid = need;
     if (grid < 8) grid = 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
     return sda_launch_status();

@@ -276,6 +276,8 @@ class VPSDE(nn.Module):
     #: optional initial draw; both exist so that parity tests can inject the reference's CPU noise (RNG).
     noise_source: Optional[Callable[[int, int], Tensor]] = None
     initial_noise: Optional[Tensor] = None
+    #: replay each diffusion step from a captured hipGraph (see PCSampler.capture); off by default
+    use_graph: bool = False
 
     def sampler(self, shape: Size = (), c: Tensor = None, steps: int = 64, corrections: int = 0,
                 tau: float = 1.0) -> 'PCSampler':
@@ -287,6 +289,8 @@ class VPSDE(nn.Module):
                tau: float = 1.0) -> Tensor:
         r"""Samples from p(x(0)) with ``steps`` predictor steps and ``corrections`` Langevin corrections each."""
         sampler = self.sampler(shape, c, steps, corrections, tau)
+        if self.use_graph and self.noise_source is None:
+            sampler.capture()
         for _ in tqdm(range(steps), ncols=88):
             sampler.step()
         return sampler.result()
@@ -300,7 +304,14 @@ class PCSampler:
 
     The schedule is evaluated once on the host in fp32 with the reference's own formulas -- ``r = mu(t-dt)/mu(t)``,
     ``c1 = sigma(t-dt) - r sigma(t)`` (score.py:252-253) -- so no 0-dim device arithmetic or host sync happens per
-    step; the updates themselves are in-place HIP kernels."""
+    step; the updates themselves are in-place HIP kernels.
+
+    ``capture()`` records one whole diffusion step (predictor + corrections, every score evaluation with its guidance
+    VJP, RNG draws included) into a hipGraph and ``step()`` then replays it: the per-step scalars live in a device
+    table indexed by a device-side step counter, so the replayed graph is step-independent.  This removes the Python /
+    launch overhead that bounds the 1-D (Lorenz) configurations."""
+
+    ROW = 5   # t, t - dt, r, c1, sigma(t - dt)
 
     def __init__(self, sde: VPSDE, shape, c, steps: int, corrections: int, tau: float):
         self.sde, self.shape, self.c = sde, shape, c
@@ -318,16 +329,18 @@ class PCSampler:
         mu_t, mu_n = sde.mu(time_cpu[:-1]), sde.mu(t_next)
         sg_t, sg_n = sde.sigma(time_cpu[:-1]), sde.sigma(t_next)
         r = mu_n / mu_t
-        self.r, self.c1, self.sg_n = r.tolist(), (sg_n - r * sg_t).tolist(), sg_n.tolist()
+        c1 = sg_n - r * sg_t
+        self.r, self.c1, self.sg_n = r.tolist(), c1.tolist(), sg_n.tolist()
         self.time = time_cpu.to(sde.device)
+        self._table_cpu = torch.stack((time_cpu[:-1], t_next, r, c1, sg_n), dim=1).contiguous()
         self.partial = torch.empty(self.nb * ops.SUMSQ_CHUNKS, device=self.x.device, dtype=torch.float32)
         self.i = 0
+        self._graph = None
 
+    # ------------------------------------------------------------------ eager step
     @torch.no_grad()
-    def step(self):
-        sde, x, i = self.sde, self.x, self.i
-        if i >= self.steps:
-            raise StopIteration
+    def _eager_step(self, i: int):
+        sde, x = self.sde, self.x
         t = self.time[i]
         # predictor: x <- r x + (sigma' - r sigma) eps(x, t)
         ops.pc_predict(x, sde.eps(x, t, self.c).contiguous(), self.r[i], self.c1[i])
@@ -337,7 +350,54 @@ class PCSampler:
             eps = sde.eps(x, t - self.dt, self.c).contiguous()
             ops.sumsq_partial(eps, self.nb, self.partial)
             ops.pc_correct(x, eps, z.contiguous(), self.nb, self.partial, self.tau, self.sg_n[i])
-        self.i = i + 1
+
+    # ------------------------------------------------------------------ graph-captured step
+    @torch.no_grad()
+    def _graph_body(self):
+        sde, x, cur = self.sde, self.x, self._cur
+        cur.copy_(self._table.index_select(0, self._istep).reshape(-1))      # this step's scalars, device side
+        ops.pc_predict(x, sde.eps(x, cur[0], self.c).contiguous(), 0.0, 0.0, coef_dev=cur[2:4])
+        for _ in range(self.corrections):
+            z = torch.randn_like(x)
+            eps = sde.eps(x, cur[1], self.c).contiguous()
+            ops.sumsq_partial(eps, self.nb, self.partial)
+            ops.pc_correct(x, eps, z, self.nb, self.partial, self.tau, 0.0, coef_dev=cur[4:5])
+        self._istep.add_(1)
+
+    def capture(self):
+        """Record one diffusion step into a hipGraph (torch.cuda.CUDAGraph).  Leaves x, the RNG streams and the step
+        counter exactly as they were."""
+        if self.sde.noise_source is not None:
+            raise SdaHipError('an injected noise_source cannot be captured into a graph')
+        dev = self.x.device
+        self._table = self._table_cpu.to(dev)
+        self._cur = torch.zeros(self.ROW, device=dev, dtype=torch.float32)
+        self._istep = torch.full((1,), self.i, device=dev, dtype=torch.int64)
+        keep_x = self.x.clone()
+        keep_rng = torch.cuda.get_rng_state(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up off the capture stream (packs weights, sizes pools)
+            self._graph_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._graph_body()
+        self.x.copy_(keep_x)
+        torch.cuda.set_rng_state(keep_rng, dev)
+        self._istep.fill_(self.i)
+        self._graph = graph
+        return self
+
+    def step(self):
+        if self.i >= self.steps:
+            raise StopIteration
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._eager_step(self.i)
+        self.i += 1
 
     def result(self) -> Tensor:
         return self.x.reshape(self.shape + tuple(self.sde.shape))

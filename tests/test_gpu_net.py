@@ -262,3 +262,26 @@ def test_golden_scorenet_local_and_guided_sampling(dev):
     torch.manual_seed(2)
     x2 = sde.sample((4,), steps=4, corrections=1, tau=0.25)
     assert torch.isfinite(x1).all() and torch.equal(x1, x2)
+
+
+def test_hipgraph_step_matches_eager(dev):
+    """One captured-and-replayed diffusion step == the eager step (same device RNG stream), guided, C = 1."""
+    from sda_amd.score import GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=VPSDE(net, shape=()), gamma=1e-2)
+    sde = VPSDE(gs, shape=(5, 2, 8, 8)).to(dev)
+    outs = []
+    for use_graph in (False, True):
+        sde.initial_noise = g['pc_x_init']
+        torch.manual_seed(7)
+        sampler = sde.sampler((2,), steps=6, corrections=1, tau=0.5)
+        if use_graph:
+            sampler.capture()
+        for _ in range(6):
+            sampler.step()
+        outs.append(sampler.result().clone())
+    sde.initial_noise = None
+    assert torch.isfinite(outs[0]).all()
+    assert_close(outs[1].cpu(), outs[0].cpu(), 1e-5)
