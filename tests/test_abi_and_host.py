@@ -131,3 +131,26 @@ def test_schedule_matches_golden():
                           atol=1e-7)
     assert torch.allclose(VPSDE(ident, shape=(), alpha='lin').mu(t), torch.from_numpy(data['mu_lin']), rtol=1e-6)
     assert torch.allclose(VPSDE(ident, shape=(), alpha='exp').mu(t), torch.from_numpy(data['mu_exp']), rtol=1e-6)
+
+
+def test_load_score_roundtrip(tmp_path):
+    """Checkpoint compatibility: state.pth + config.json as the reference's train scripts write them."""
+    import json
+    from sda_amd.experiments import kolmogorov as K, lorenz as Lz
+    cfg = dict(window=3, embedding=16, hidden_channels=(4, 8), hidden_blocks=(1, 1), kernel_size=3, activation='SiLU',
+               epochs=1, batch_size=2)
+    net = K.make_score(**cfg)
+    (tmp_path / 'k').mkdir()
+    torch.save(net.state_dict(), tmp_path / 'k' / 'state.pth')
+    json.dump(cfg, open(tmp_path / 'k' / 'config.json', 'w'))
+    net2 = K.load_score(tmp_path / 'k' / 'state.pth')
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    for local in (False, True):
+        cfg = dict(embedding=8, hidden_channels=(8,), hidden_blocks=(1,), window=5, width=16, depth=2, activation='SiLU')
+        net = Lz.make_local_score(**cfg) if local else Lz.make_global_score(**cfg)
+        d = tmp_path / f'l{int(local)}'
+        d.mkdir()
+        torch.save(net.state_dict(), d / 'state.pth')
+        json.dump(cfg, open(d / 'config.json', 'w'))
+        net2 = Lz.load_score(d / 'state.pth', local=local)
+        assert set(net.state_dict()) == set(net2.state_dict())

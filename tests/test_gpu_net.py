@@ -285,3 +285,64 @@ def test_hipgraph_step_matches_eager(dev):
     sde.initial_noise = None
     assert torch.isfinite(outs[0]).all()
     assert_close(outs[1].cpu(), outs[0].cpu(), 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(3, 12, 20), (2, 10, 6), (5, 8, 8)])
+def test_unet2d_zero_padding_odd_sizes_and_per_image_time(dev, shape):
+    """Edge cases the Kolmogorov path never hits: zero padding, widths not divisible by 4 (scalar epilogue), several
+    images per pixel tile, per-image time (training-style call, score.py:268-271) and a per-image context tensor."""
+    from sda_amd.score import ScoreUNet
+    n, h, w = shape
+    torch.manual_seed(n)
+    net = ScoreUNet(3, context=2, embedding=16, hidden_channels=(8, 16), hidden_blocks=(1, 2), activation=nn.GELU,
+                    spatial=2)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    cfg = O.UNetConfig(5, 3, 16, (8, 16), (1, 2), 3, 2, 'GELU', 2, 'zeros')
+    x, t, c = torch.randn(n, 3, h, w), torch.rand(n), torch.randn(n, 2, h, w)
+    ref = O.score_unet(sd, '', cfg, x, t, c)
+    net.to(dev)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev), c.to(dev))
+    assert_close(out.cpu(), ref, TOL)
+    # VJP
+    g = torch.randn_like(x)
+    xo = x.clone().requires_grad_(True)
+    gref, = torch.autograd.grad(O.score_unet(sd, '', cfg, xo, t, c), xo, g)
+    xd = x.to(dev).requires_grad_(True)
+    got, = torch.autograd.grad(net(xd, t.to(dev), c.to(dev)), xd, g.to(dev))
+    assert_close(got.cpu(), gref, TOL)
+
+
+def test_mcscore_short_and_long_trajectories(dev):
+    """L = 2k+1 (a single window: fold takes every slot from it) and a long trajectory (L = 127, figures.ipynb#cell43)."""
+    net = _midsize_net(dev, seed=3)
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    net.to(dev)
+    for L in (5, 6, 127):
+        torch.manual_seed(L)
+        x, t = torch.randn(1, L, 2, 16, 16), torch.tensor(0.2)
+        with torch.no_grad():
+            out = net(x.to(dev), t.to(dev))
+        assert_close(out.cpu(), eps_o(x, t), TOL, what=f'L={L}')
+    with pytest.raises(Exception):
+        net(torch.randn(1, 4, 2, 16, 16, device=dev), torch.tensor(0.2, device=dev))
+
+
+def test_subvp_schedules_sample(dev):
+    from sda_amd.score import SubSubVPSDE, SubVPSDE
+    g, grp = load_golden('unet1d_tiny')
+    net = build_unet1d_tiny()
+    net.load_state_dict(grp['sd'])
+    sd = {k: v.clone() for k, v in grp['sd'].items()}
+    cfg = O.UNetConfig(3, 3, 8, (8,), (1,), 3, 2, 'SiLU', 1, 'zeros')
+    eps_o = lambda x, t: O.mc_score_wrapper(lambda a, b, c=None: O.score_unet(sd, 'score.', cfg, a, b, c), x, t)
+    for cls, kind in ((SubVPSDE, 'subvp'), (SubSubVPSDE, 'subsubvp')):
+        sde = cls(net, shape=(16, 3)).to(dev)
+        torch.manual_seed(0)
+        x1 = torch.randn(2, 16, 3)
+        zs = torch.randn(6, 2, 16, 3)
+        sde.initial_noise = x1
+        sde.noise_source = lambda i, j: zs[i]
+        x = sde.sample((2,), steps=6, corrections=1, tau=0.3)
+        ref = O.sample(eps_o, O.Schedule('cos', kind=kind), x1, 2, 6, 1, 0.3, noise=lambda i, j: zs[i])
+        assert_close(x.cpu(), ref, TOL, what=kind)
