@@ -189,6 +189,21 @@ int sda_denoise(const float* x, const float* eps, int64_t numel, float mu, float
 int sda_guided_combine(const float* eps, const float* ghat, const float* vjp, int64_t numel, float mu, float sigma,
                        const float* coef_dev, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Linear observation operators A of the reference's experiments and their adjoints A^T, so that GaussianScore
+ * (sda/score.py:387-394) needs no autograd through A: d log p / d x_hat = A^T((y - A x_hat)/var).
+ *   subsample: a 5-D strided slice x[..., start::step, ...] (experiments/lorenz/eval.py:75; kolmogorov/figures.ipynb#cell30-39)
+ *   coarsen:   KolmogorovFlow.coarsen, block mean over f x f cells      (sda/mcs.py:340-347)
+ *   vorticity: KolmogorovFlow.vorticity, periodic central differences   (sda/mcs.py:361-375); x = [pairs][2][h][w]
+ * size5/start5/step5: host int[5] (leading dims padded with size 1, start 0, step 1).
+ * ------------------------------------------------------------------------------------------ */
+int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, float* out, void* stream);
+int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, float* gx, void* stream);
+int sda_obs_coarsen(const float* x, int64_t planes, int h, int w, int f, float* out, void* stream);
+int sda_obs_coarsen_adjoint(const float* r, int64_t planes, int h, int w, int f, float* gx, void* stream);
+int sda_obs_vorticity(const float* x, int64_t pairs, int h, int w, float* out, void* stream);
+int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, int w, float* gx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

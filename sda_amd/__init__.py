@@ -8,5 +8,6 @@ path; the arithmetic runs in hand-written gfx950 kernels (``sda_amd/csrc`` -> ``
 from . import nn
 from . import score
 from . import utils
+from . import observe
 
 __version__ = '0.1.0'

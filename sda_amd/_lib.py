@@ -66,6 +66,12 @@ SIGNATURES = {
     'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
+    'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_subsample_adjoint': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_coarsen': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_fp, c_void_p]),
+    'sda_obs_coarsen_adjoint': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_fp, c_void_p]),
+    'sda_obs_vorticity': (c_int, [c_fp, c_int64, c_int, c_int, c_fp, c_void_p]),
+    'sda_obs_vorticity_adjoint': (c_int, [c_fp, c_int64, c_int, c_int, c_fp, c_void_p]),
     'sda_fold': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_fold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_unfold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int64, c_fp, c_void_p]),

@@ -1,0 +1,172 @@
+// Linear observation operators of the reference's experiments and their adjoints:
+//   strided sub-sampling x[..., a::s, ...]   (experiments/lorenz/eval.py:75, kolmogorov/figures.ipynb#cell30-39)
+//   KolmogorovFlow.coarsen  (block mean)     (sda/mcs.py:340-347)
+//   KolmogorovFlow.vorticity (periodic central differences)   (sda/mcs.py:361-375)
+// With an adjoint available, GaussianScore needs no autograd through A: d log p / d x_hat = A^T((y - A x_hat)/var).
+// All kernels are streaming (HBM-bound): one read of the source, one write of the destination.
+#include "sda_common.hpp"
+
+static inline unsigned obs_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 65536) b = 65536;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+struct Slice5 { int size[5]; int start[5]; int step[5]; int osize[5]; };
+
+// out[o0..o4] = x[start + o*step]   over a 5-D view (leading dims padded with size 1)
+__global__ void strided_gather_kernel(const float* __restrict__ x, Slice5 s, float* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i, src = 0, mul = 1;
+        int idx[5];
+#pragma unroll
+        for (int d = 4; d >= 0; --d) { idx[d] = (int)(r % s.osize[d]); r /= s.osize[d]; }
+#pragma unroll
+        for (int d = 4; d >= 0; --d) { src += (int64_t)(s.start[d] + idx[d] * s.step[d]) * mul; mul *= s.size[d]; }
+        out[i] = x[src];
+    }
+}
+
+// gx = 0 except gx[start + o*step] = r[o]
+__global__ void strided_scatter_kernel(const float* __restrict__ r, Slice5 s, float* __restrict__ gx, int64_t total_x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_x; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t q = i, dst = 0, mul = 1;
+        bool hit = true;
+        int o[5];
+#pragma unroll
+        for (int d = 4; d >= 0; --d) {
+            const int c = (int)(q % s.size[d]); q /= s.size[d];
+            const int rel = c - s.start[d];
+            hit = hit && rel >= 0 && (rel % s.step[d]) == 0 && (rel / s.step[d]) < s.osize[d];
+            o[d] = rel / s.step[d];
+        }
+        if (hit) {
+#pragma unroll
+            for (int d = 4; d >= 0; --d) { dst += (int64_t)o[d] * mul; mul *= s.osize[d]; }
+        }
+        gx[i] = hit ? r[dst] : 0.f;
+    }
+}
+
+static int fill_slice(Slice5* s, const int* size, const int* start, const int* step) {
+    for (int d = 0; d < 5; ++d) {
+        if (size[d] <= 0 || step[d] <= 0 || start[d] < 0 || start[d] >= size[d]) return SDA_E_BADARG;
+        s->size[d] = size[d]; s->start[d] = start[d]; s->step[d] = step[d];
+        s->osize[d] = (size[d] - start[d] + step[d] - 1) / step[d];
+    }
+    return SDA_OK;
+}
+
+extern "C" int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, float* out,
+                                 void* stream) {
+    if (!x || !out || !size5 || !start5 || !step5) return SDA_E_BADARG;
+    Slice5 s;
+    int rc = fill_slice(&s, size5, start5, step5);
+    if (rc) return rc;
+    int64_t total = 1;
+    for (int d = 0; d < 5; ++d) total *= s.osize[d];
+    hipLaunchKernelGGL(strided_gather_kernel, dim3(obs_grid(total)), dim3(256), 0, (hipStream_t)stream, x, s, out, total);
+    return sda_launch_status();
+}
+
+extern "C" int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, float* gx,
+                                         void* stream) {
+    if (!r || !gx || !size5 || !start5 || !step5) return SDA_E_BADARG;
+    Slice5 s;
+    int rc = fill_slice(&s, size5, start5, step5);
+    if (rc) return rc;
+    int64_t total = 1;
+    for (int d = 0; d < 5; ++d) total *= s.size[d];
+    hipLaunchKernelGGL(strided_scatter_kernel, dim3(obs_grid(total)), dim3(256), 0, (hipStream_t)stream, r, s, gx, total);
+    return sda_launch_status();
+}
+
+// coarsen: out[n][y][x] = mean over the f x f cell   (planes = product of leading dims)
+__global__ void coarsen_kernel(const float* __restrict__ x, int64_t planes, int h, int w, int f, float* __restrict__ out) {
+    const int ho = h / f, wo = w / f;
+    const int64_t total = planes * ho * wo;
+    const float inv = 1.0f / (float)(f * f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const int oy = (int)((i / wo) % ho);
+        const int64_t p = i / ((int64_t)wo * ho);
+        const float* src = x + p * h * w + (int64_t)oy * f * w + ox * f;
+        float acc = 0.f;
+        for (int a = 0; a < f; ++a)
+            for (int b = 0; b < f; ++b) acc += src[a * w + b];
+        out[i] = acc * inv;
+    }
+}
+
+__global__ void coarsen_adjoint_kernel(const float* __restrict__ r, int64_t planes, int h, int w, int f,
+                                       float* __restrict__ gx) {
+    const int ho = h / f, wo = w / f;
+    const int64_t total = planes * h * w;
+    const float inv = 1.0f / (float)(f * f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const int yy = (int)((i / w) % h);
+        const int64_t p = i / ((int64_t)w * h);
+        gx[i] = r[(p * ho + yy / f) * wo + xx / f] * inv;
+    }
+}
+
+extern "C" int sda_obs_coarsen(const float* x, int64_t planes, int h, int w, int f, float* out, void* stream) {
+    if (!x || !out || planes <= 0 || h <= 0 || w <= 0 || f <= 0 || h % f || w % f) return SDA_E_BADARG;
+    hipLaunchKernelGGL(coarsen_kernel, dim3(obs_grid(planes * (h / f) * (w / f))), dim3(256), 0, (hipStream_t)stream, x,
+                       planes, h, w, f, out);
+    return sda_launch_status();
+}
+
+extern "C" int sda_obs_coarsen_adjoint(const float* r, int64_t planes, int h, int w, int f, float* gx, void* stream) {
+    if (!r || !gx || planes <= 0 || h <= 0 || w <= 0 || f <= 0 || h % f || w % f) return SDA_E_BADARG;
+    hipLaunchKernelGGL(coarsen_adjoint_kernel, dim3(obs_grid(planes * h * w)), dim3(256), 0, (hipStream_t)stream, r, planes,
+                       h, w, f, gx);
+    return sda_launch_status();
+}
+
+// vorticity: x [pairs][2][h][w] (u, v) -> w[pairs][h][w] = (u[x+1]-u[x-1])/2 - (v[y+1]-v[y-1])/2, periodic
+__global__ void vorticity_kernel(const float* __restrict__ x, int64_t pairs, int h, int w, float* __restrict__ out) {
+    const int64_t total = pairs * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const int yy = (int)((i / w) % h);
+        const int64_t p = i / ((int64_t)w * h);
+        const float* u = x + p * 2 * h * w;
+        const float* v = u + (int64_t)h * w;
+        const int xp = xx + 1 == w ? 0 : xx + 1, xm = xx == 0 ? w - 1 : xx - 1;
+        const int yp = yy + 1 == h ? 0 : yy + 1, ym = yy == 0 ? h - 1 : yy - 1;
+        out[i] = (u[yy * w + xp] - u[yy * w + xm]) * 0.5f - (v[yp * w + xx] - v[ym * w + xx]) * 0.5f;
+    }
+}
+
+// adjoint: gu[y][x] = (r[y][x-1] - r[y][x+1])/2 ;  gv[y][x] = (r[y+1][x] - r[y-1][x])/2
+__global__ void vorticity_adjoint_kernel(const float* __restrict__ r, int64_t pairs, int h, int w, float* __restrict__ gx) {
+    const int64_t total = pairs * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % w);
+        const int yy = (int)((i / w) % h);
+        const int64_t p = i / ((int64_t)w * h);
+        const float* rp = r + p * h * w;
+        const int xp = xx + 1 == w ? 0 : xx + 1, xm = xx == 0 ? w - 1 : xx - 1;
+        const int yp = yy + 1 == h ? 0 : yy + 1, ym = yy == 0 ? h - 1 : yy - 1;
+        float* gu = gx + p * 2 * h * w;
+        float* gv = gu + (int64_t)h * w;
+        gu[yy * w + xx] = (rp[yy * w + xm] - rp[yy * w + xp]) * 0.5f;
+        gv[yy * w + xx] = (rp[yp * w + xx] - rp[ym * w + xx]) * 0.5f;
+    }
+}
+
+extern "C" int sda_obs_vorticity(const float* x, int64_t pairs, int h, int w, float* out, void* stream) {
+    if (!x || !out || pairs <= 0 || h < 3 || w < 3) return SDA_E_BADARG;
+    hipLaunchKernelGGL(vorticity_kernel, dim3(obs_grid(pairs * h * w)), dim3(256), 0, (hipStream_t)stream, x, pairs, h, w, out);
+    return sda_launch_status();
+}
+
+extern "C" int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, int w, float* gx, void* stream) {
+    if (!r || !gx || pairs <= 0 || h < 3 || w < 3) return SDA_E_BADARG;
+    hipLaunchKernelGGL(vorticity_adjoint_kernel, dim3(obs_grid(pairs * h * w)), dim3(256), 0, (hipStream_t)stream, r, pairs,
+                       h, w, gx);
+    return sda_launch_status();
+}

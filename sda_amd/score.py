@@ -485,13 +485,19 @@ class GaussianScore(nn.Module):
         eps_d = eps.detach().contiguous()
         xhat = torch.empty_like(eps_d)
         ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
-        with torch.enable_grad():
-            xhat.requires_grad_(True)
+        if hasattr(self.A, 'adjoint'):
+            # linear operator with a hand-written adjoint (sda_amd.observe): d log p / d x_hat = A^T((y - A x_hat)/var)
             err = self.y - self.A(xhat)
             var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
-            log_p = -(err ** 2 / var).sum() / 2
-        ghat, = torch.autograd.grad(log_p, xhat)
-        ghat = ghat.contiguous()
+            ghat = self.A.adjoint((err / var).contiguous(), xhat.shape).contiguous()
+        else:
+            with torch.enable_grad():
+                xhat.requires_grad_(True)
+                err = self.y - self.A(xhat)
+                var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
+                log_p = -(err ** 2 / var).sum() / 2
+            ghat, = torch.autograd.grad(log_p, xhat)
+            ghat = ghat.contiguous()
         out = torch.empty_like(eps_d)
         ops.guided_combine(eps_d, ghat, None if vjp is None else vjp(ghat).contiguous(), mu, sigma, out)
         return out

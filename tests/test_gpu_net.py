@@ -346,3 +346,45 @@ def test_subvp_schedules_sample(dev):
         x = sde.sample((2,), steps=6, corrections=1, tau=0.3)
         ref = O.sample(eps_o, O.Schedule('cos', kind=kind), x1, 2, 6, 1, 0.3, noise=lambda i, j: zs[i])
         assert_close(x.cpu(), ref, TOL, what=kind)
+
+
+def test_fused_observation_operators_match_autograd(dev):
+    """sda_amd.observe operators == the reference's callables, and GaussianScore's adjoint fast path == autograd."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    torch.manual_seed(9)
+    x = torch.randn(2, 9, 2, 16, 16)
+    cases = [
+        (Ob.Subsample.space(4), lambda v: v[..., ::4, ::4]),
+        (Ob.Subsample.space(8, 3), lambda v: v[..., 3::8, 3::8]),
+        (Ob.Subsample((slice(None, None, 2), slice(None), slice(None, None, 2), slice(None, None, 2))),
+         lambda v: v[..., ::2, :, ::2, ::2]),
+        (Ob.Compose(Ob.Subsample((slice(None, None, 4), slice(None), slice(None), slice(None))), Ob.Coarsen(4)),
+         lambda v: O.coarsen(v[..., ::4, :, :, :], 4)),
+        (Ob.Vorticity(), O.vorticity),
+        (Ob.Compose(Ob.Coarsen(2), Ob.Vorticity()), lambda v: O.vorticity(O.coarsen(v, 2))),
+    ]
+    for op, ref_fn in cases:
+        xo = x.clone().requires_grad_(True)
+        ref = ref_fn(xo)
+        out = op(x.to(dev))
+        assert_close(out.cpu(), ref.detach(), 1e-5)
+        r = torch.randn_like(ref)
+        gref, = torch.autograd.grad(ref, xo, r)
+        assert_close(op.adjoint(r.to(dev), x.shape).cpu(), gref, 1e-5)
+    xl = torch.randn(3, 65, 3)
+    op = Ob.Subsample((slice(None, None, 8), slice(0, 1)))
+    xo = xl.clone().requires_grad_(True)
+    ref = xo[..., ::8, :1]
+    assert torch.equal(op(xl.to(dev)).cpu(), ref.detach())
+    r = torch.randn_like(ref)
+    gref, = torch.autograd.grad(ref, xo, r)
+    assert torch.equal(op.adjoint(r.to(dev), xl.shape).cpu(), gref)
+    # guidance: adjoint fast path vs autograd path on the same net
+    net = _midsize_net(dev, seed=5).to(dev)
+    xg, t = torch.randn(2, 7, 2, 16, 16, device=dev), torch.tensor(0.55, device=dev)
+    A_ref = lambda v: v[..., ::4, ::4]
+    y = torch.randn(A_ref(xg).shape)
+    a = GaussianScore(y, A=A_ref, std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    b = GaussianScore(y, A=Ob.Subsample.space(4), std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    assert_close(b.cpu(), a.cpu(), 1e-5)
