@@ -229,18 +229,23 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)            # one rank per GPU on a real node; wraps only in 1-GPU dry runs
+    device = torch.device('cuda', dev_index)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))     # nccl == RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)                          # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
 
     from sda_amd import ops, parallel
     from sda_amd.score import GaussianScore, VPSDE
