@@ -34,6 +34,8 @@ from .ops import PackedConv, conv_out_size, make_conv_desc
 
 # fraction of currently-unallocated HBM one chunk's activations may occupy
 CHUNK_HBM_FRACTION = 0.45
+# fraction of unallocated HBM that activations kept from the forward for the VJP may occupy
+KEEP_HBM_FRACTION = 0.45
 _warned_training = False
 
 
@@ -207,11 +209,57 @@ class UNetEngine:
             total += plane * ((2 * nblk + 4) if save else 5)
         return total
 
-    def chunk_size(self, n: int, hs: int, ws: int, save: bool, device) -> int:
+    def chunk_size(self, n: int, hs: int, ws: int, save: bool, device, fraction: Optional[float] = None) -> int:
         total = torch.cuda.get_device_properties(device).total_memory
         avail = max(total - torch.cuda.memory_allocated(device), total // 8)
         per = max(self.bytes_per_image(hs, ws, save), 1)
-        return int(max(1, min(n, (avail * CHUNK_HBM_FRACTION) // per)))
+        return int(max(1, min(n, (avail * (fraction or CHUNK_HBM_FRACTION)) // per)))
+
+    # -------------------------------------------------------------------------------- whole-batch drivers
+    def forward_all(self, src: Source, mod_all, per_image: bool, out: Tensor, need_grad: bool):
+        """All images of ``src`` -> ``out``; returns the VJP state: a list of (lo, hi, saved-or-None).
+
+        With ``need_grad`` the activations of as many images as fit ``KEEP_HBM_FRACTION`` of the unallocated HBM are kept
+        (all of them when they fit: one forward, one backward); the rest is recomputed chunk by chunk in the backward."""
+        n = src.n
+        dev = out.device
+        state = []
+        lo = 0
+        if need_grad:
+            keep = self.chunk_size(n, src.hs, src.ws, True, dev, KEEP_HBM_FRACTION)
+            if keep >= n:
+                state.append((0, n, self.forward_chunk(src, 0, n, mod_all, per_image, out, True)))
+                return state
+            if keep >= max(8, n // 16):                 # worth keeping a leading part
+                state.append((0, keep, self.forward_chunk(src, 0, keep, mod_all, per_image, out[:keep], True)))
+                lo = keep
+        chunk = self.chunk_size(n - lo, src.hs, src.ws, False, dev)
+        while lo < n:
+            hi = min(n, lo + chunk)
+            self.forward_chunk(src, lo, hi, mod_all, per_image, out[lo:hi], False)
+            state.append((lo, hi, None))
+            lo = hi
+        return state
+
+    def backward_all(self, state, g_out: Tensor, src: Source, mod_all, per_image: bool, g_in: Tensor):
+        """VJP for every image: kept chunks go straight to the backward, the others recompute their forward first."""
+        dev = g_out.device
+        for lo, hi, saved in state:
+            if saved is not None:
+                self.backward_chunk(saved, g_out[lo:hi], src, lo, mod_all, per_image, g_in[lo:hi])
+        pending = [(lo, hi) for lo, hi, saved in state if saved is None]
+        if not pending:
+            return
+        lo, end = pending[0][0], pending[-1][1]
+        chunk = self.chunk_size(end - lo, src.hs, src.ws, True, dev)
+        scratch = torch.empty(min(chunk, end - lo), g_out.shape[1], g_out.shape[2], g_out.shape[3], device=dev,
+                              dtype=torch.float32)
+        while lo < end:
+            hi = min(end, lo + chunk)
+            saved = self.forward_chunk(src, lo, hi, mod_all, per_image, scratch[:hi - lo], True)
+            self.backward_chunk(saved, g_out[lo:hi], src, lo, mod_all, per_image, g_in[lo:hi])
+            del saved
+            lo = hi
 
     # -------------------------------------------------------------------------------- forward
     def _mod_for(self, blk: _Block, mod_all: Optional[Tensor], lo: int, per_image: bool):
@@ -384,37 +432,16 @@ class _UNetFunction(torch.autograd.Function):
         ho, wo = conv_out_size(src.hs, hd.kh, hd.sh), conv_out_size(src.ws, hd.kw, hd.sw)
         out = torch.empty(n, out_channels, ho, wo, device=dev, dtype=torch.float32)
         ctx.engine, ctx.src, ctx.mod_all, ctx.per_image = engine, src, mod_all, per_image
-        ctx.saved_acts = None
         ctx.x_shape = x.shape
-        if need:
-            chunk_save = engine.chunk_size(n, src.hs, src.ws, True, dev)
-            if chunk_save >= n:
-                ctx.saved_acts = engine.forward_chunk(src, 0, n, mod_all, per_image, out, True)
-                return out
-        chunk = engine.chunk_size(n, src.hs, src.ws, False, dev)
-        for lo in range(0, n, chunk):
-            hi = min(n, lo + chunk)
-            engine.forward_chunk(src, lo, hi, mod_all, per_image, out[lo:hi], False)
+        ctx.vjp_state = engine.forward_all(src, mod_all, per_image, out, need)
         return out
 
     @staticmethod
     def backward(ctx, g_out: Tensor):
         engine, src = ctx.engine, ctx.src
         g_out = g_out.contiguous()
-        n = src.n
-        dev = g_out.device
-        g_in = torch.empty(n, src.cx, src.hs, src.ws, device=dev, dtype=torch.float32)
-        if ctx.saved_acts is not None:
-            engine.backward_chunk(ctx.saved_acts, g_out, src, 0, ctx.mod_all, ctx.per_image, g_in)
-        else:   # recompute chunk by chunk (activations of all images do not fit HBM at once)
-            chunk = engine.chunk_size(n, src.hs, src.ws, True, dev)
-            scratch = torch.empty(min(chunk, n), g_out.shape[1], g_out.shape[2], g_out.shape[3], device=dev,
-                                  dtype=torch.float32)
-            for lo in range(0, n, chunk):
-                hi = min(n, lo + chunk)
-                saved = engine.forward_chunk(src, lo, hi, ctx.mod_all, ctx.per_image, scratch[:hi - lo], True)
-                engine.backward_chunk(saved, g_out[lo:hi], src, lo, ctx.mod_all, ctx.per_image, g_in[lo:hi])
-                del saved
+        g_in = torch.empty(src.n, src.cx, src.hs, src.ws, device=g_out.device, dtype=torch.float32)
+        engine.backward_all(ctx.vjp_state, g_out, src, ctx.mod_all, ctx.per_image, g_in)
         return g_in.reshape(ctx.x_shape), None, None, None, None, None
 
 

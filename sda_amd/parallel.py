@@ -30,12 +30,18 @@ def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 
 def sharded_initial_noise(batch: int, event: tuple, seed: int, rank: int, world_size: int) -> Tensor:
-    """This rank's rows of the (batch, *event) initial draw the single-process sampler would make with
-    ``torch.manual_seed(seed); torch.randn(batch, *event)`` (host RNG, as score.py:243)."""
-    gen = torch.Generator().manual_seed(seed)
+    """This rank's rows of the (batch, *event) initial draw (host RNG, as score.py:243).  Row i comes from its own
+    generator stream keyed by (seed, i), so the union over ranks is the same tensor for every world size -- and no rank
+    ever materialises rows it does not own (config [3]: 4.3 GB of noise for the global batch)."""
     lo, hi = shard_range(batch, rank, world_size)
-    full = torch.randn((batch,) + tuple(event), generator=gen)
-    return full[lo:hi].clone()
+    gen = torch.Generator()
+    rows = []
+    for i in range(lo, hi):
+        gen.manual_seed((seed * 1000003 + i) & 0x7fffffffffffffff)
+        rows.append(torch.randn(tuple(event), generator=gen))
+    if not rows:
+        return torch.empty((0,) + tuple(event))
+    return torch.stack(rows)
 
 
 class ShardedNoise:

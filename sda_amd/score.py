@@ -132,15 +132,7 @@ class _MCScoreFunction(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         dev = x.device
         s = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
-        ctx.saved_acts = None
-        chunk_save = engine.chunk_size(src.n, H, W, True, dev) if need else 0
-        if need and chunk_save >= src.n:
-            ctx.saved_acts = engine.forward_chunk(src, 0, src.n, mod_all, per_image, s, True)
-        else:
-            chunk = engine.chunk_size(src.n, H, W, False, dev)
-            for lo in range(0, src.n, chunk):
-                hi = min(src.n, lo + chunk)
-                engine.forward_chunk(src, lo, hi, mod_all, per_image, s[lo:hi], False)
+        ctx.vjp_state = engine.forward_all(src, mod_all, per_image, s, need)
         out = torch.empty_like(x)
         ops.fold(s, B, nw, order, C, hw, out)
         ctx.engine, ctx.src, ctx.mod_all, ctx.per_image = engine, src, mod_all, per_image
@@ -158,16 +150,7 @@ class _MCScoreFunction(torch.autograd.Function):
         g_s = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
         ops.fold_adjoint(g, B, nw, order, C, hw, g_s)
         g_win = torch.empty(src.n, wl * C, H, W, device=dev, dtype=torch.float32)
-        if ctx.saved_acts is not None:
-            engine.backward_chunk(ctx.saved_acts, g_s, src, 0, ctx.mod_all, ctx.per_image, g_win)
-        else:
-            chunk = engine.chunk_size(src.n, H, W, True, dev)
-            scratch = torch.empty(min(chunk, src.n), wl * C, H, W, device=dev, dtype=torch.float32)
-            for lo in range(0, src.n, chunk):
-                hi = min(src.n, lo + chunk)
-                saved = engine.forward_chunk(src, lo, hi, ctx.mod_all, ctx.per_image, scratch[:hi - lo], True)
-                engine.backward_chunk(saved, g_s[lo:hi], src, lo, ctx.mod_all, ctx.per_image, g_win[lo:hi])
-                del saved
+        engine.backward_all(ctx.vjp_state, g_s, src, ctx.mod_all, ctx.per_image, g_win)
         g_x = torch.empty(B, nw + 2 * order, C, H, W, device=dev, dtype=torch.float32)
         ops.unfold_adjoint(g_win, B, nw, order, C, hw, wl * C, g_x)
         return g_x.reshape(ctx.x_shape), None, None, None, None

@@ -162,12 +162,14 @@ def test_chunked_equals_unchunked_and_recompute(dev, monkeypatch):
     xg = x.clone().requires_grad_(True)
     out = net(xg, t)
     vjp, = torch.autograd.grad(out, xg, g)
-    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: 4)
-    xg2 = x.clone().requires_grad_(True)
-    out2 = net(xg2, t)
-    vjp2, = torch.autograd.grad(out2, xg2, g)
-    assert torch.equal(out, out2)
-    assert torch.equal(vjp, vjp2)
+    for forced in (4, 10):      # 4: everything recomputed in the backward; 10: a leading part kept, the rest recomputed
+        monkeypatch.setattr(E.UNetEngine, 'chunk_size',
+                            lambda self, n, hs, ws, save, device, fraction=None, forced=forced: min(n, forced))
+        xg2 = x.clone().requires_grad_(True)
+        out2 = net(xg2, t)
+        vjp2, = torch.autograd.grad(out2, xg2, g)
+        assert torch.equal(out, out2)
+        assert torch.equal(vjp, vjp2)
 
 
 def test_k64_single_window_vs_oracle(dev):

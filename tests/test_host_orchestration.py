@@ -113,7 +113,7 @@ def test_chunked_recompute_path(monkeypatch):
     xs = g['x'].clone().requires_grad_(True)
     out = net(xs, g['t'])
     v, = torch.autograd.grad(out, xs, gg)
-    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device: 2)
+    monkeypatch.setattr(E.UNetEngine, 'chunk_size', lambda self, n, hs, ws, save, device, fraction=None: min(n, 2))
     xs2 = g['x'].clone().requires_grad_(True)
     out2 = net(xs2, g['t'])
     v2, = torch.autograd.grad(out2, xs2, gg)

@@ -21,10 +21,12 @@ def test_shard_range_partitions():
 
 
 def test_sharded_initial_noise_is_a_slice_of_the_single_process_draw():
-    torch.manual_seed(5)
-    full = torch.randn(7, 4, 3)
-    parts = [P.sharded_initial_noise(7, (4, 3), 5, r, 3) for r in range(3)]
-    assert torch.equal(torch.cat(parts), full)
+    full = P.sharded_initial_noise(7, (4, 3), 5, 0, 1)               # the single-process draw
+    assert full.shape == (7, 4, 3)
+    for ws in (2, 3, 8):
+        parts = [P.sharded_initial_noise(7, (4, 3), 5, r, ws) for r in range(ws)]
+        assert torch.equal(torch.cat(parts), full)
+    assert not torch.equal(full, P.sharded_initial_noise(7, (4, 3), 6, 0, 1))
 
 
 def _worker(rank, ws, port, ret):
