@@ -98,6 +98,10 @@ typedef struct sda_conv_desc {
     const float* res;               /* out += res           (NULL = off) */
     /* tiling: cout tile = 32*mt (mt in 1..4); weights must be packed with cout_pad % (32*mt) == 0 */
     int32_t mt;
+    /* optional Winograd F(2x2,3x3) weights [16][cin_pad][cout_pad] (sda_pack_conv_weight_wino); when non-NULL and the
+     * layer is eligible (3x3, stride 1, no zero insertion, no ctx, cout % 96 == 0, even output size, mt == 3) the
+     * transform-domain kernel is used: 2.25x fewer multiplies, fp32 round-off-level error */
+    const float* w_wino;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
@@ -112,6 +116,10 @@ int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);
  * Rows/cols beyond the real sizes are zero filled. */
 int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int transpose, int cin_keep,
                          float* dst, int k_pad, int m_pad, void* stream);
+
+/* Winograd-domain weights U[4*xi+nu][k][m] = (G g G^T)[xi][nu] for 3x3 filters; transpose / cin_keep as above. */
+int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
+                              int m_pad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * zuko.nn.LayerNorm(dim=-(spatial+1)) statistics: per pixel, over channels, of (x + mod).

@@ -48,6 +48,7 @@ class ConvDesc(Structure):
         ('act_d', c_int32),
         ('res', c_fp),
         ('mt', c_int32),
+        ('w_wino', c_fp),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
+    'sda_pack_conv_weight_wino': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_ln_stats': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_float, c_int, c_fp, c_fp, c_void_p]),
     'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
     'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_fp, c_fp,

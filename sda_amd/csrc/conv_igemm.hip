@@ -756,8 +756,16 @@ static int conv_launch_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t 
     return conv_launch_t<MT, SDA_CONV_MAXPOS>(d, g, stream);
 }
 
+// Winograd F(2x2,3x3) path (conv_wino.hip)
+struct WinoGeom;
+int sda_wino_try(const sda_conv_desc* d, hipStream_t stream);   // SDA_E_UNSUPPORTED -> use the direct kernel
+
 extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (d && d->w_wino) {
+        const int rcw = sda_wino_try(d, s);
+        if (rcw != SDA_E_UNSUPPORTED) return rcw;
+    }
     static const bool force_v1 = getenv("SDA_CONV_V1") != nullptr;
     if (!force_v1 && d && ((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 3))) {
         ConvGeom g2;

@@ -1,0 +1,463 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores: 2.25x fewer multiplies than the direct implicit GEMM at
+// fp32 round-off-level error (measured ~1e-6 relative), used for the stride-1 3x3 layers whose cout is a multiple of 96
+// (every block / tail convolution of the reference Kolmogorov net and their backward-data forms).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//   U[p][ci][co] = (G g G^T)[xi][nu],  p = 4 xi + nu            (precomputed: sda_pack_conv_weight_wino)
+//   V[p][ci][t]  = (B^T d B)[xi][nu]   for tile t              (computed by the producer waves while staging)
+//   M[p][co][t]  = sum_ci U[p][ci][co] V[p][ci][t]              (16 independent GEMMs on v_mfma_f32_32x32x2_f32)
+//
+// Same machine as conv_igemm_ws_kernel (8 wavefronts: 4 MFMA consumers + 4 producers, two LDS stage buffers of 8 input
+// channels, persistent XCD-aware tiles, LDS-DMA weight slabs, loader-side LayerNorm / modulation / activation /
+// upsample / padding), with:
+//   * workgroup tile = 32 Winograd tiles (128 output pixels) x 96 couts;
+//   * producer thread (ck, t) loads its 4x4 patch, applies the loader fusions, transforms it in registers (32 adds) and
+//     writes V[0..15][ck][t];
+//   * consumer wave w owns the four positions p = 4w .. 4w+3 (xi = w): accumulators [4][3] 32x32 fragments = 192 VGPRs;
+//   * epilogue: the nu-part of A^T . A is lane-local; the xi-part crosses waves through a 32 KiB LDS exchange buffer
+//     (two workgroup barriers per 32-cout slab, mirrored by the producers so that barrier counts match), after which
+//     every lane owns 2x2 outputs of one (cout, tile) and stores float2 rows (consecutive lanes = consecutive tiles).
+#include "sda_common.hpp"
+#include <stdlib.h>
+
+#define WINO_CK 8
+#define WINO_BM 96
+#define WINO_T 32
+#define WINO_MT 3
+
+struct WinoGeom {
+    int cin, hv, wv;
+    int TX, TY;                     // output tiles per image (2x2 pixels each)
+    int ttx, tty, ttn, ttx_shift, tty_shift;
+    int tiles_x, tiles_y, tiles_n;  // workgroup tiles over (TX, TY, n)
+    int n_ct, grid, nstage, debug;
+    int hrows, hcols, sh;           // halo of one workgroup tile per channel: ttn x hrows x hcols = sh positions
+};
+
+static inline int wino_ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+static int wino_pick(int extent, int budget) {
+    for (int t = budget; t >= 1; t >>= 1) {
+        long padded = (long)((extent + t - 1) / t) * t;
+        if (padded * 4 <= (long)extent * 5) return t;
+    }
+    return 1;
+}
+
+// eligibility + geometry.  Returns SDA_E_UNSUPPORTED when the direct kernel must be used.
+int sda_wino_plan(const sda_conv_desc* d, WinoGeom* g) {
+    if (!d || !d->x || !d->w_wino || !d->out) return SDA_E_UNSUPPORTED;
+    if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
+        return SDA_E_UNSUPPORTED;
+    if (d->cctx > 0 || d->mt != WINO_MT || d->cout % WINO_BM || d->cout_pad != d->cout || d->cin_pad % WINO_CK)
+        return SDA_E_UNSUPPORTED;
+    if ((d->ho & 1) || (d->wo & 1) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
+    if (d->mod && d->mod_sn != 0) return SDA_E_UNSUPPORTED;            // per-image modulation: direct path
+    if ((reinterpret_cast<uintptr_t>(d->out) & 7) || (d->res && (reinterpret_cast<uintptr_t>(d->res) & 7)) ||
+        (d->dact_z && (reinterpret_cast<uintptr_t>(d->dact_z) & 7)))
+        return SDA_E_UNSUPPORTED;
+    // 32-bit producer offsets relative to the tile's first image
+    {
+        auto ab = [](int64_t v) { return v < 0 ? -v : v; };
+        int64_t span = 32 * (ab(d->x_sn_outer) + ab(d->x_sn_inner)) + (int64_t)d->hs * ab(d->x_sy) + (int64_t)d->ws * ab(d->x_sx);
+        if (span >= (1LL << 30) || d->x_sn_outer < 0 || d->x_sn_inner < 0 || d->x_sy < 0 || d->x_sx < 0) return SDA_E_UNSUPPORTED;
+        if (d->n_inner > 1 && d->x_sn_outer < d->x_sn_inner * (int64_t)(d->n_inner - 1)) return SDA_E_UNSUPPORTED;
+    }
+    g->cin = d->cx;
+    g->hv = d->ho; g->wv = d->wo;
+    g->TX = d->wo / 2; g->TY = d->ho / 2;
+    g->ttx = wino_pick(g->TX, WINO_T);
+    g->tty = wino_pick(g->TY, WINO_T / g->ttx);
+    g->ttn = WINO_T / (g->ttx * g->tty);
+    g->ttx_shift = wino_ilog2(g->ttx);
+    g->tty_shift = wino_ilog2(g->tty);
+    g->tiles_x = (g->TX + g->ttx - 1) / g->ttx;
+    g->tiles_y = (g->TY + g->tty - 1) / g->tty;
+    g->tiles_n = (d->n + g->ttn - 1) / g->ttn;
+    g->n_ct = d->cout / WINO_BM;
+    long total = (long)g->tiles_x * g->tiles_y * g->tiles_n * g->n_ct;
+    if (total > 0x7fffffffL) return SDA_E_UNSUPPORTED;
+    g->grid = (int)total;
+    g->nstage = d->cin_pad / WINO_CK;
+    g->hrows = 2 * g->tty + 2;
+    g->hcols = 2 * g->ttx + 2;
+    g->sh = g->ttn * g->hrows * g->hcols;
+    if (g->sh > 288) return SDA_E_UNSUPPORTED;       // (degenerate 2x2-pixel images)
+    { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+    return SDA_OK;
+}
+
+__device__ inline void wino_decode_tile(const WinoGeom& g, int tile, int& ct, int& n0, int& ty0, int& tx0) {
+    ct = tile % g.n_ct;
+    int pt = tile / g.n_ct;
+    int txi = pt % g.tiles_x;
+    int r = pt / g.tiles_x;
+    int tyi = r % g.tiles_y;
+    int tni = r / g.tiles_y;
+    n0 = tni * g.ttn; ty0 = tyi * g.tty; tx0 = txi * g.ttx;
+}
+
+// tile slot t (0..31) of a workgroup tile -> image / tile coordinates; false if outside the tensor
+__device__ inline bool wino_slot(const sda_conv_desc& d, const WinoGeom& g, int t, int n0, int ty0, int tx0, int& n, int& ty,
+                                 int& tx) {
+    const int ix = t & (g.ttx - 1);
+    const int iy = (t >> g.ttx_shift) & (g.tty - 1);
+    const int in = t >> (g.ttx_shift + g.tty_shift);
+    n = n0 + in; ty = ty0 + iy; tx = tx0 + ix;
+    return n < d.n && ty < g.TY && tx < g.TX;
+}
+
+__device__ inline int conv_wrap_i(int v, int m) { v %= m; return v < 0 ? v + m : v; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d, const WinoGeom g) {
+    constexpr int CK = WINO_CK, BM = WINO_BM, MT = WINO_MT;
+    // LDS carries only V (the transformed input patches).  U is read by exactly one wave each (wave w owns positions
+    // 4w..4w+3), so staging it in LDS would buy no reuse: the consumers stream their U fragments straight from L2 into
+    // registers as one dwordx4 per (position, m-tile) -- U is packed [stage][p][khalf][cout][k2] for that purpose.
+    constexpr int VSZ = 16 * CK * WINO_T;        //  4096 floats: V slab of one stage, layout [p][khalf][t][k2]
+    constexpr int BUF = VSZ;                     // 16 KiB
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xch = smem + 2 * BUF;           // [xi 4][j 2][co 32][t 32] exchange buffer (32 KiB)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+    const bool producer = __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int tq = g.grid >> 3, tr_ = g.grid & 7;
+    const int t_begin = xcd * tq + (xcd < tr_ ? xcd : tr_);
+    const int t_end = t_begin + tq + (xcd < tr_ ? 1 : 0);
+    const int EPI_BARRIERS = 2 * MT;
+
+    if (producer) {
+        const int ptid = tid - 256;
+        const int ck = ptid >> 5, t = ptid & 31;
+        int pb = 0;                                  // barriers executed so far
+        int gs = 0, tile_idx = 0;
+        for (int tile = t_begin + slot; tile < t_end; tile += per_xcd, ++tile_idx) {
+            int ct, n0, ty0, tx0;
+            wino_decode_tile(g, tile, ct, n0, ty0, tx0);
+            const int co0 = ct * BM;
+            const int ng0 = n0 + d.x_n_off;
+            const int64_t nb0 = (int64_t)(ng0 / d.n_inner) * d.x_sn_outer + (int64_t)(ng0 % d.n_inner) * d.x_sn_inner;
+            const float* xtile = d.x + nb0;
+            // Halo of the workgroup tile, two channels per producer wave (ck = 2 pw, 2 pw + 1), staged through a
+            // wave-private LDS area: every input pixel is fetched once per channel with row-contiguous loads (a patch-wise
+            // gather would fetch it four times with 8-byte lane strides), the loader fusions run once per pixel, and each
+            // lane then reads its 4x4 patch back from LDS.
+            constexpr int NH = 9;                          // ceil(2 * 288 / 64)
+            const int pw = wave - 4;
+            float* priv = smem + 2 * BUF + 4 * 2 * 32 * WINO_T + pw * (2 * 288);
+            unsigned hoff[NH];
+            float hmean[NH], hrstd[NH];
+            unsigned hmask = 0, hsel = 0;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int e = lane + 64 * i;
+                hoff[i] = 0; hmean[i] = 0.f; hrstd[i] = 1.f;
+                if (e < 2 * g.sh) {
+                    const int chsel = e >= g.sh ? 1 : 0;
+                    const int hp = e - chsel * g.sh;
+                    const int plane = g.hrows * g.hcols;
+                    const int in = hp / plane;
+                    const int rem = hp - in * plane;
+                    const int hy = rem / g.hcols, hx = rem - hy * g.hcols;
+                    const int n = n0 + in;
+                    int vy = 2 * ty0 - 1 + hy, vx = 2 * tx0 - 1 + hx;
+                    bool ok = n < d.n;
+                    if (d.circular) {
+                        vy = conv_wrap_i(vy, g.hv);
+                        vx = conv_wrap_i(vx, g.wv);
+                    } else {
+                        ok = ok && vy >= 0 && vy < g.hv && vx >= 0 && vx < g.wv;
+                    }
+                    hsel |= (unsigned)chsel << i;
+                    if (ok) {
+                        const int sy = vy / d.up_h, sx = vx / d.up_w;
+                        const int ng = n + d.x_n_off;
+                        const int64_t nb = (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
+                        hoff[i] = (unsigned)(nb - nb0 + (int64_t)sy * d.x_sy + (int64_t)sx * d.x_sx);
+                        hmask |= 1u << i;
+                        if (d.ln_mean) {
+                            const int64_t st = (int64_t)n * d.hs * d.ws + (int64_t)sy * d.ws + sx;
+                            hmean[i] = d.ln_mean[st];
+                            hrstd[i] = d.ln_rstd[st];
+                        }
+                    }
+                }
+            }
+            // where this lane's patch starts inside the wave-private halo
+            int pbase;
+            {
+                const int ix = t & (g.ttx - 1);
+                const int iy = (t >> g.ttx_shift) & (g.tty - 1);
+                const int in = t >> (g.ttx_shift + g.tty_shift);
+                pbase = (lane >> 5) * g.sh + (in * g.hrows + 2 * iy) * g.hcols + 2 * ix;
+            }
+            for (int st = 0; st < g.nstage; ++st, ++gs) {
+                // this ring slot was last read in global stage gs-2: wait for the barrier the consumers pass after it
+                if (gs >= 2) {
+                    const int g2 = gs - 2;
+                    const int t2 = g2 / g.nstage;
+                    const int need = 1 + g2 + t2 * EPI_BARRIERS;      // index of that barrier
+                    while (pb <= need) { __syncthreads(); ++pb; }
+                }
+                float* buf = smem + (gs & 1) * BUF;
+                const int c0 = st * CK;
+                if (!((g.debug & 2) && gs > 0)) {
+                    if (g.debug & 32) continue;
+                    const int ca = c0 + 2 * pw, cb = ca + 1;                 // this wave's two channels
+                    // channel offsets relative to the tile base (padded channels >= cin read channel 0 and are zeroed)
+                    const unsigned offa = ca < g.cin ? (unsigned)((int64_t)ca * d.x_sc) : 0u;
+                    const unsigned offb = cb < g.cin ? (unsigned)((int64_t)cb * d.x_sc) : 0u;
+                    float hv_[NH];
+#pragma unroll
+                    for (int i = 0; i < NH; ++i) hv_[i] = xtile[hoff[i] + (((hsel >> i) & 1u) ? offb : offa)];
+                    {
+                        const float ma = (d.mod && ca < g.cin) ? d.mod[ca] : 0.f;
+                        const float mb = (d.mod && cb < g.cin) ? d.mod[cb] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) {
+                            const bool second = (hsel >> i) & 1u;
+                            float x_ = hv_[i] + (second ? mb : ma);
+                            if (d.ln_mean) x_ = (x_ - hmean[i]) * hrstd[i];
+                            hv_[i] = x_;
+                        }
+                        if (d.act_in == SDA_ACT_SILU) {
+#pragma unroll
+                            for (int i = 0; i < NH; ++i) hv_[i] = sda_act(SDA_ACT_SILU, hv_[i]);
+                        } else if (d.act_in) {
+#pragma unroll
+                            for (int i = 0; i < NH; ++i) hv_[i] = sda_act(d.act_in, hv_[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) {
+                            const bool second = (hsel >> i) & 1u;
+                            const bool live = ((hmask >> i) & 1u) && ((second ? cb : ca) < g.cin);
+                            if (lane + 64 * i < 2 * g.sh) priv[lane + 64 * i] = live ? hv_[i] : 0.f;
+                        }
+                    }
+                    float v[16];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) v[a * 4 + b] = priv[pbase + a * g.hcols + b];
+                    // B^T d B  (rows then columns)
+                    float u[16];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        u[0 * 4 + b] = v[0 * 4 + b] - v[2 * 4 + b];
+                        u[1 * 4 + b] = v[1 * 4 + b] + v[2 * 4 + b];
+                        u[2 * 4 + b] = v[2 * 4 + b] - v[1 * 4 + b];
+                        u[3 * 4 + b] = v[1 * 4 + b] - v[3 * 4 + b];
+                    }
+                    // V[p][khalf = ck & 1][t][k2 = ck >> 1]
+                    float* s_v = buf + ((ck & 1) * WINO_T + t) * 4 + (ck >> 1);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        s_v[(a * 4 + 0) * (2 * WINO_T * 4)] = u[a * 4 + 0] - u[a * 4 + 2];
+                        s_v[(a * 4 + 1) * (2 * WINO_T * 4)] = u[a * 4 + 1] + u[a * 4 + 2];
+                        s_v[(a * 4 + 2) * (2 * WINO_T * 4)] = u[a * 4 + 2] - u[a * 4 + 1];
+                        s_v[(a * 4 + 3) * (2 * WINO_T * 4)] = u[a * 4 + 1] - u[a * 4 + 3];
+                    }
+                }
+            }
+        }
+        // drain: match every remaining consumer barrier
+        const int total = 1 + gs + tile_idx * EPI_BARRIERS;
+        while (pb < total) { __syncthreads(); ++pb; }
+    } else {
+        __builtin_amdgcn_s_setprio(2);
+        int gs = 0;
+        __syncthreads();                                   // barrier 0: the first stage has landed
+        for (int tile = t_begin + slot; tile < t_end; tile += per_xcd) {
+            int ct, n0, ty0, tx0;
+            wino_decode_tile(g, tile, ct, n0, ty0, tx0);
+            const int co0 = ct * BM;
+            f32x16 acc[4][MT];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][m][r] = 0.f;
+
+            // U fragments: [stage][p][khalf][cout][k2] (one float4 per lane, m-tile and position), streamed L2 -> VGPRs one
+            // position ahead of their MFMAs -- across stage boundaries too, since weights do not depend on the barrier.
+            const float* ubase = d.w_wino + ((int64_t)(wave * 4 * 2 + khalf) * d.cout_pad + co0 + l31) * 4;
+            const int64_t ustage = (int64_t)(16 * 2 * 4) * d.cout_pad;
+            f32x4 av[2][MT], bv[2];
+            auto fetch_a = [&](int st_, int pl, int s_) {
+                const float* u = ubase + st_ * ustage + ((int64_t)pl * 2 * d.cout_pad) * 4;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[s_][m] = *reinterpret_cast<const f32x4*>(u + m * 32 * 4);
+            };
+            if (!(g.debug & 4)) fetch_a(0, 0, 0);
+            for (int st = 0; st < g.nstage; ++st, ++gs) {
+                const float* buf = smem + (gs & 1) * BUF;
+                if (g.debug & 4) { __syncthreads(); continue; }
+                const float* vst = buf + ((wave * 4 * 2 + khalf) * WINO_T + l31) * 4;
+                bv[0] = *reinterpret_cast<const f32x4*>(vst);
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                    if (pl + 1 < 4) {
+                        bv[(pl + 1) & 1] = *reinterpret_cast<const f32x4*>(vst + (pl + 1) * (2 * WINO_T * 4));
+                        fetch_a(st, pl + 1, (pl + 1) & 1);
+                    } else if (st + 1 < g.nstage) {
+                        fetch_a(st + 1, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k2 = 0; k2 < CK / 2; ++k2)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pl & 1][m][k2], bv[pl & 1][k2], acc[pl][m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+
+            // ---------------- epilogue: A^T M A, nu in registers, xi through the LDS exchange buffer
+            int n, ty, tx;
+            const bool tv = wino_slot(d, g, l31, n0, ty0, tx0, n, ty, tx);
+            const int hw_o = d.ho * d.wo;
+            const int64_t pix = tv ? ((int64_t)n * d.cout * d.ho + 2 * ty) * d.wo + 2 * tx : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (!(g.debug & 8)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                        const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r];
+                        xch[((wave * 2 + 0) * 32 + row) * WINO_T + l31] = (m0 + m1) + m2;
+                        xch[((wave * 2 + 1) * 32 + row) * WINO_T + l31] = (m1 - m2) - m3;
+                    }
+                }
+                __syncthreads();
+                if (!(g.debug & 8)) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = wave * 8 + it * 2 + khalf;
+                        const int co = co0 + m * 32 + row;
+                        float z[4][2];
+#pragma unroll
+                        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) z[xi][j] = xch[((xi * 2 + j) * 32 + row) * WINO_T + l31];
+                        const float bias = d.bias ? d.bias[co] : 0.f;
+                        f32x2 y0, y1;
+                        y0[0] = (z[0][0] + z[1][0]) + z[2][0] + bias; y0[1] = (z[0][1] + z[1][1]) + z[2][1] + bias;
+                        y1[0] = (z[1][0] - z[2][0]) - z[3][0] + bias; y1[1] = (z[1][1] - z[2][1]) - z[3][1] + bias;
+                        const int64_t off = pix + (int64_t)co * hw_o;
+                        if (tv) {
+                            if (d.dact_z) {
+                                const f32x2 q0 = *reinterpret_cast<const f32x2*>(d.dact_z + off);
+                                const f32x2 q1 = *reinterpret_cast<const f32x2*>(d.dact_z + off + d.wo);
+                                if (d.act_d == SDA_ACT_SILU) {
+                                    y0[0] *= sda_dact(SDA_ACT_SILU, q0[0]); y0[1] *= sda_dact(SDA_ACT_SILU, q0[1]);
+                                    y1[0] *= sda_dact(SDA_ACT_SILU, q1[0]); y1[1] *= sda_dact(SDA_ACT_SILU, q1[1]);
+                                } else {
+                                    y0[0] *= sda_dact(d.act_d, q0[0]); y0[1] *= sda_dact(d.act_d, q0[1]);
+                                    y1[0] *= sda_dact(d.act_d, q1[0]); y1[1] *= sda_dact(d.act_d, q1[1]);
+                                }
+                            }
+                            if (d.res) {
+                                y0 += *reinterpret_cast<const f32x2*>(d.res + off);
+                                y1 += *reinterpret_cast<const f32x2*>(d.res + off + d.wo);
+                            }
+                            *reinterpret_cast<f32x2*>(d.out + off) = y0;
+                            *reinterpret_cast<f32x2*>(d.out + off + d.wo) = y1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t stream) {
+    constexpr int lds = (2 * (16 * WINO_CK * WINO_T) + 4 * 2 * 32 * WINO_T + 4 * 2 * 288) * 4;   // 2 V stages + exchange + halos = 73 KiB
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SDA_E_BADARG;
+        cus = prop.multiProcessorCount;
+    }
+    int grid = cus - cus % 8;
+    const int need = (g.grid + 7) / 8 * 8;
+    if (grid > need) grid = need;
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
+    return sda_launch_status();
+}
+
+int sda_wino_try(const sda_conv_desc* d, hipStream_t stream) {
+    static const bool off = getenv("SDA_CONV_WINO") && atoi(getenv("SDA_CONV_WINO")) == 0;
+    if (off) return SDA_E_UNSUPPORTED;
+    WinoGeom g;
+    const int rc = sda_wino_plan(d, &g);
+    if (rc != SDA_OK) return rc;
+    return sda_wino_launch(d, g, stream);
+}
+
+// ---------------------------------------------------------------- Winograd weight transform (one-off per layer)
+// dst[stage][p][khalf][mm][k2] with kk = 8 stage + 2 k2 + khalf, p = 4 xi + nu:  forward (transpose=0): kk = ci, mm = co, g = w[co][ci];
+// backward-data (transpose=1): kk = co, mm = ci, g[dy][dx] = w[co][ci][2-dy][2-dx].
+__global__ void pack_wino_kernel(const float* __restrict__ w, int cout, int cin, int transpose, int cin_keep,
+                                 float* __restrict__ dst, int k_pad, int m_pad) {
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int64_t total = (int64_t)k_pad * m_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int mm = (int)(i % m_pad), kk = (int)(i / m_pad);
+        float gk[3][3];
+        bool live;
+        int co, ci;
+        if (!transpose) { ci = kk; co = mm; live = ci < cin && co < cout; }
+        else { co = kk; ci = mm; live = ci < cin_keep && ci < cin && co < cout; }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sy = transpose ? 2 - dy : dy, sx = transpose ? 2 - dx : dx;
+                gk[dy][dx] = live ? w[(((int64_t)co * cin + ci) * 3 + sy) * 3 + sx] : 0.f;
+            }
+        float tmp[4][3];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) tmp[xi][dx] = G[xi][0] * gk[0][dx] + G[xi][1] * gk[1][dx] + G[xi][2] * gk[2][dx];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const float u = tmp[xi][0] * G[nu][0] + tmp[xi][1] * G[nu][1] + tmp[xi][2] * G[nu][2];
+                // [stage = kk/8][p][khalf = kk&1][m][k2 = (kk&7)>>1]
+                const int st = kk >> 3, kh_ = kk & 1, k2 = (kk & 7) >> 1;
+                dst[((((int64_t)st * 16 + (xi * 4 + nu)) * 2 + kh_) * m_pad + mm) * 4 + k2] = u;
+            }
+    }
+}
+
+extern "C" int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst,
+                                         int k_pad, int m_pad, void* stream) {
+    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0) return SDA_E_BADARG;
+    int64_t total = (int64_t)k_pad * m_pad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transpose, cin_keep,
+                       dst, k_pad, m_pad);
+    return sda_launch_status();
+}

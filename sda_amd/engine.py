@@ -118,7 +118,8 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        ln_rstd_ptr=None if ln is None else ln[1].data_ptr(),
                        act_in=act_in, bias_ptr=None if bias is None else bias.data_ptr(),
                        dact_z_ptr=None if dact_z is None else dact_z.data_ptr(), act_d=act_d,
-                       res_ptr=None if res is None else res.data_ptr())
+                       res_ptr=None if res is None else res.data_ptr(),
+                       w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr())
     ops.conv_igemm(d)
 
 

@@ -13,6 +13,8 @@ from . import _lib
 from ._lib import ACT_IDS, ConvDesc
 
 CONV_CK = 8          # K-stage depth of conv_igemm (SDA_CONV_CK)
+import os as _os
+WINOGRAD = _os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3) for eligible 3x3 layers
 
 
 def _dev(*tensors):
@@ -55,7 +57,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
                    w_ptr, cin_pad, cout_pad, cout, kh, kw, out_ptr, ho, wo, mt,
                    stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
                    ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
-                   act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None) -> ConvDesc:
+                   act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None) -> ConvDesc:
     d = ConvDesc()
     d.x = x_ptr
     d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
@@ -74,6 +76,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     d.dact_z, d.act_d = dact_z_ptr, act_d
     d.res = res_ptr
     d.mt = mt
+    d.w_wino = w_wino_ptr
     return d
 
 
@@ -139,6 +142,13 @@ class PackedConv:
         self.packed = torch.empty(self.kh * self.kw * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
         pack_conv_weight(w, cout, cin, self.kh, self.kw, transpose, keep, self.packed, self.k_pad, self.m_pad)
         self.bias = None if (bias is None or transpose) else bias.detach().contiguous()
+        # Winograd F(2x2,3x3) form for 3x3 layers whose output channels tile by 96 (the U-Net block / tail convolutions)
+        self.wino = None
+        if WINOGRAD and (self.kh, self.kw) == (3, 3) and self.m_real % 96 == 0 and self.mt == 3:
+            self.wino = torch.empty(16 * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
+            _lib.check(_lib.load().sda_pack_conv_weight_wino(w.data_ptr(), cout, cin, int(transpose), keep,
+                                                             self.wino.data_ptr(), self.k_pad, self.m_pad, _stream()),
+                       'sda_pack_conv_weight_wino')
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm pieces

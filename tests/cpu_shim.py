@@ -166,4 +166,5 @@ def install(monkeypatch):
                          sumsq_partial=sumsq_partial, pc_correct=pc_correct, denoise=denoise,
                          guided_combine=guided_combine, linear=linear, row_ln=row_ln, row_ln_bwd=row_ln_bwd).items():
         monkeypatch.setattr(ops, name, fn)
+    monkeypatch.setattr(ops, 'WINOGRAD', False)      # the Winograd form has no host replay; the direct form is emulated
     monkeypatch.setattr(E.UNetEngine, "chunk_size", lambda self, n, hs, ws, save, device, fraction=None: n)
