@@ -41,11 +41,43 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const float* __res
     rstd[idx] = 1.0f / sqrtf(var + eps);
 }
 
+// Few pixels (the 1-D Lorenz nets: n*hw in the hundreds): one thread per pixel would leave the chip idle and serialise a
+// dependent load per channel, so one WAVEFRONT takes a pixel, its 64 lanes stride the channel axis and reduce with shuffles.
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_wave_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
+                                                                   const float* __restrict__ mod, int64_t mod_sn, float eps,
+                                                                   int unbiased, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    if (idx >= npix) return;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const float* xp = x + n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    float s = 0.f;
+    for (int k = lane; k < c; k += 64) s += xp[(int64_t)k * hw] + (mp ? mp[k] : 0.f);
+    const float m = __shfl(sda_wave_sum(s), 0, 64) / (float)c;
+    float q = 0.f;
+    for (int k = lane; k < c; k += 64) {
+        const float dlt = xp[(int64_t)k * hw] + (mp ? mp[k] : 0.f) - m;
+        q += dlt * dlt;
+    }
+    const float var = __shfl(sda_wave_sum(q), 0, 64) / (float)(unbiased ? c - 1 : c);
+    if (lane == 0) { mean[idx] = m; rstd[idx] = 1.0f / sqrtf(var + eps); }
+}
+
+#define LN_SMALL_PIXELS 16384      // below this many pixels the wave-per-pixel kernels are used
+
 extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, float eps,
                             int unbiased, float* mean, float* rstd, void* stream) {
     if (!x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return SDA_E_BADARG;
     if (unbiased && c < 2) return SDA_E_UNSUPPORTED;
     const int64_t npix = (int64_t)n * hw;
+    if (npix < LN_SMALL_PIXELS) {
+        hipLaunchKernelGGL(ln_stats_wave_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(LN_THREADS), 0, (hipStream_t)stream, x,
+                           npix, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        return sda_launch_status();
+    }
     const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
@@ -135,6 +167,50 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
     }
 }
 
+template <int POOL_H, int POOL_W>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_wave_kernel(const float* __restrict__ gh, const float* __restrict__ x,
+                                                                 int64_t npix, int c, int h, int w,
+                                                                 const float* __restrict__ mod, int64_t mod_sn,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int unbiased,
+                                                                 const float* __restrict__ res, float* __restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    if (idx >= npix) return;
+    const int hw = h * w;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const int py = p / w, px = p - py * w;
+    const int64_t xbase = n * (int64_t)c * hw + p;
+    const int gw = w * POOL_W;
+    const int64_t ghw = (int64_t)hw * POOL_H * POOL_W;
+    const int64_t gbase = n * (int64_t)c * ghw + (int64_t)(py * POOL_H) * gw + px * POOL_W;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    const float m = mean[idx], r = rstd[idx];
+    auto load_g = [&](int k) -> float {
+        const float* g = gh + gbase + (int64_t)k * ghw;
+        float v = g[0];
+        if (POOL_W == 2) v += g[1];
+        if (POOL_H == 2) { v += g[gw]; if (POOL_W == 2) v += g[gw + 1]; }
+        return v;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < c; k += 64) {
+        const float hh = (x[xbase + (int64_t)k * hw] + (mp ? mp[k] : 0.f) - m) * r;
+        const float g = load_g(k);
+        s1 += g;
+        s2 += g * hh;
+    }
+    const float a = __shfl(sda_wave_sum(s1), 0, 64) / (float)c;
+    const float b = __shfl(sda_wave_sum(s2), 0, 64) / (float)(unbiased ? c - 1 : c);
+    for (int k = lane; k < c; k += 64) {
+        const float hh = (x[xbase + (int64_t)k * hw] + (mp ? mp[k] : 0.f) - m) * r;
+        float v = r * (load_g(k) - a - hh * b);
+        if (res) v += res[xbase + (int64_t)k * hw];
+        gx[xbase + (int64_t)k * hw] = v;
+    }
+}
+
 extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
                           const float* mean, const float* rstd, int unbiased, int pool, const float* res, float* gx,
                           void* stream) {
@@ -145,6 +221,19 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     dim3 grid((unsigned)blocks), block(LN_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    if (npix < LN_SMALL_PIXELS) {
+        dim3 gs((unsigned)((npix + 3) / 4));
+        if (pool == 1)
+            hipLaunchKernelGGL((ln_bwd_wave_kernel<1, 1>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                               unbiased, res, gx);
+        else if (h == 1)
+            hipLaunchKernelGGL((ln_bwd_wave_kernel<1, 2>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                               unbiased, res, gx);
+        else
+            hipLaunchKernelGGL((ln_bwd_wave_kernel<2, 2>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
+                               unbiased, res, gx);
+        return sda_launch_status();
+    }
     if (pool == 1) {
         hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                            unbiased, res, gx);

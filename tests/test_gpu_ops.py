@@ -123,7 +123,9 @@ def test_loader_mod_ln_act_and_epilogue(dev, act):
 def test_ln_stats_apply_bwd(dev):
     from sda_amd import ops
     torch.manual_seed(11)
-    for (n, c, h, w_), pool in (((3, 24, 8, 8), 1), ((2, 96, 16, 16), 2), ((4, 16, 1, 20), 2), ((2, 8, 1, 33), 1)):
+    for (n, c, h, w_), pool in (((3, 24, 8, 8), 1), ((2, 96, 16, 16), 2), ((4, 16, 1, 20), 2), ((2, 8, 1, 33), 1),
+                              # >= 16384 pixels: the thread-per-pixel kernels (below: wave-per-pixel)
+                              ((5, 24, 64, 64), 1), ((3, 12, 64, 128), 2), ((2, 6, 1, 9000), 2)):
         x = (torch.randn(n, c, h, w_) * 3 + 1).requires_grad_(True)
         mod = torch.randn(n, c)
         xd, md = x.detach().to(dev), mod.to(dev)
