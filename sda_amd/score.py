@@ -88,6 +88,16 @@ class ScoreUNet(nn.Module):
         out = run_unet(self.network, src, emb, x)
         return out.reshape(x.shape)
 
+    def grad_bytes_per_sample(self, x_shape) -> Optional[int]:
+        """HBM the input-VJP keeps alive per row of a batch ``x_shape`` = (B, C, *spatial); None when ``x_shape`` has no
+        single leading batch axis (see GaussianScore._groups)."""
+        spatial = self.network.spatial
+        if len(x_shape) != spatial + 2:
+            return None
+        sp = tuple(x_shape)[-spatial:]
+        h, w = (1, sp[0]) if spatial == 1 else sp
+        return self.network.engine().bytes_per_image(h, w, True)
+
 
 class MCScoreWrapper(nn.Module):
     r"""Disguises a `ScoreUNet` as a score network for a Markov chain (score.py:96-110).
@@ -101,6 +111,12 @@ class MCScoreWrapper(nn.Module):
 
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
         return self.score(x.transpose(1, 2), t, c).transpose(1, 2)
+
+    def grad_bytes_per_sample(self, x_shape) -> Optional[int]:
+        f = getattr(self.score, 'grad_bytes_per_sample', None)
+        if f is None or len(x_shape) != 3:
+            return None
+        return f((x_shape[0], x_shape[2], x_shape[1]))
 
 
 class _MCScoreFunction(torch.autograd.Function):
@@ -206,6 +222,14 @@ class MCScoreNet(nn.Module):
         # generic kernel (ScoreNet, or a user subclass overriding forward): unfold as a view + one gather copy
         s = kernel(self.unfold(x, self.order), t, c)
         return self.fold(s, self.order)
+
+    def grad_bytes_per_sample(self, x_shape) -> Optional[int]:
+        """HBM the input-VJP keeps alive per trajectory of a batch ``x_shape`` = (B, L, C, *spatial): one U-Net image per
+        window.  None for kernels that are not U-Nets (small activations) and for unbatched trajectories."""
+        if not isinstance(self.kernel, ScoreUNet) or len(x_shape) != self.kernel.network.spatial + 3:
+            return None
+        per = self.kernel.grad_bytes_per_sample((1,) + tuple(x_shape)[2:])
+        return None if per is None else max(x_shape[1] - 2 * self.order, 1) * per
 
     @staticmethod
     def unfold(x: Tensor, order: int) -> Tensor:
@@ -462,25 +486,81 @@ class GaussianScore(nn.Module):
         self.sde = sde
         self.detach = detach
 
+    #: samples per streamed group: None = decide from free HBM, 0 = never split, n = force groups of n (tests)
+    group_size: Optional[int] = None
+
+    def _groups(self, x: Tensor, t: Tensor, c) -> Optional[int]:
+        """log p(y|x) is a sum over samples and the variance is not learned, so the guidance gradient of one sample never
+        depends on another: when the activations of the whole batch do not fit in HBM, the batch is streamed in groups
+        of whole samples (forward -> likelihood -> VJP per group, nothing recomputed) instead of running every forward
+        first and recomputing most of them in the backward."""
+        if self.group_size == 0 or self.detach or c is not None or x.dim() < 2 or x.shape[0] < 2:
+            return None
+        if torch.is_tensor(t) and t.numel() > 1:
+            return None
+        B = x.shape[0]
+        per = None
+        for m in self.sde.eps.modules():                 # outermost network that knows its activation footprint
+            f = getattr(m, 'grad_bytes_per_sample', None)
+            if f is not None:
+                per = f(tuple(x.shape))                  # None: x has no leading batch axis for this network
+                break
+        if not per:
+            return None
+        if self.group_size:
+            return self.group_size if self.group_size < B else None
+        if not x.is_cuda:
+            return None
+        from .engine import KEEP_HBM_FRACTION
+        total = torch.cuda.get_device_properties(x.device).total_memory
+        avail = max(total - torch.cuda.memory_allocated(x.device), total // 8)
+        budget = 0.9 * KEEP_HBM_FRACTION * avail
+        if per * B <= budget or per > budget:
+            return None                                  # everything fits / not even one sample does (engine recomputes)
+        ngroups = -(-B // int(budget // per))
+        return -(-B // ngroups)
+
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        g = self._groups(x, t, c)
+        if g is None:
+            return self._guided(x, t, c, None)
+        x = x.contiguous()
+        out = torch.empty_like(x, dtype=torch.float32)
+        B = x.shape[0]
+        for lo in range(0, B, g):
+            hi = min(B, lo + g)
+            self._guided(x[lo:hi], t, c, (lo, hi, B), out[lo:hi])
+        return out
+
+    def _guided(self, x: Tensor, t: Tensor, c, rows, out: Tensor = None) -> Tensor:
         mu, sigma = self.sde.mu(t), self.sde.sigma(t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
         eps_d = eps.detach().contiguous()
         xhat = torch.empty_like(eps_d)
         ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
+
+        def observed(ax: Tensor) -> Tensor:
+            # a per-sample observation follows its rows; a shared one broadcasts as in the reference
+            if rows is not None and self.y.dim() == ax.dim() and self.y.shape[0] == rows[2]:
+                return self.y[rows[0]:rows[1]]
+            return self.y
+
         if hasattr(self.A, 'adjoint'):
             # linear operator with a hand-written adjoint (sda_amd.observe): d log p / d x_hat = A^T((y - A x_hat)/var)
-            err = self.y - self.A(xhat)
+            ax = self.A(xhat)
+            err = observed(ax) - ax
             var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
             ghat = self.A.adjoint((err / var).contiguous(), xhat.shape).contiguous()
         else:
             with torch.enable_grad():
                 xhat.requires_grad_(True)
-                err = self.y - self.A(xhat)
+                ax = self.A(xhat)
+                err = observed(ax) - ax
                 var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
                 log_p = -(err ** 2 / var).sum() / 2
             ghat, = torch.autograd.grad(log_p, xhat)
             ghat = ghat.contiguous()
-        out = torch.empty_like(eps_d)
+        if out is None:
+            out = torch.empty_like(eps_d)
         ops.guided_combine(eps_d, ghat, None if vjp is None else vjp(ghat).contiguous(), mu, sigma, out)
         return out

@@ -89,6 +89,9 @@ def test_golden_guided_score_grad_and_dps(dev):
     guided = gs(x, t)
     assert_close(plain.cpu(), g['plain'], TOL)
     assert_close(guided.cpu(), g['guided'], TOL)
+    gs.group_size = 1                       # streamed trajectory by trajectory (batches whose activations exceed HBM)
+    assert_close(gs(x, t).cpu(), g['guided'], TOL)
+    gs.group_size = None
     sigma = inner.sigma(g['t_guided'])
     assert_close(((plain - guided) / sigma.to(dev)).cpu(), g['grad_logp'], 2e-3)   # cancellation-limited fixture
     dps = DPSGaussianScore(g['y_obs'], A=_A, sde=inner, zeta=1.0).to(dev)

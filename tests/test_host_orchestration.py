@@ -68,6 +68,16 @@ def test_guided_and_dps_golden():
     inner = VPSDE(net, shape=())
     gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2)
     assert_close(gs(g['x'], g['t_guided']), g['guided'], 5e-5)
+    # streamed in groups of whole trajectories (what a batch too large for HBM gets): same result, shared or per-row y
+    gs.group_size = 1
+    assert_close(gs(g['x'], g['t_guided']), g['guided'], 5e-5)
+    x3 = torch.cat((g['x'], g['x'][:1] * 0.5), 0)
+    y3 = _A(x3) + 0.1
+    per_row = GaussianScore(y3, A=_A, std=0.5, sde=inner, gamma=1e-2)
+    per_row.group_size = 0
+    whole = per_row(x3, g['t_guided'])
+    per_row.group_size = 2
+    assert_close(per_row(x3, g['t_guided']), whole, 1e-6)
     dps = DPSGaussianScore(g['y_obs'], A=_A, sde=inner, zeta=1.0)
     assert_close(dps(g['x'], g['t_guided']), g['dps'], 5e-5)
     gsd = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2, detach=True)
