@@ -212,6 +212,21 @@ int sda_obs_coarsen_adjoint(const float* r, int64_t planes, int h, int w, int f,
 int sda_obs_vorticity(const float* x, int64_t pairs, int h, int w, float* out, void* stream);
 int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, int w, float* gx, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics of the sampling experiments.
+ *   sda_pairwise_dist   : out[i][j] = |x_i - y_j|^2 (take_sqrt = 0) or |x_i - y_j| (1); x [m][d], y [n][d], out [m][n].
+ *                         Replaces torch.cdist in emd (sda/utils.py:215-219) and the Gram-matrix expansion of mmd
+ *                         (sda/utils.py:236-250).
+ *   sda_mmd_kernel_sums : partial[b] = sum over a grid-stride slice of d2[0..count) of
+ *                         sum_{sigma in 1e-3..1e3} exp(-d2/sigma)   (sda/utils.py:252-261); partial: nblocks doubles.
+ *   sda_assignment_cost : HOST pointers.  min over permutations of sum_i cost[i][p(i)] -- the optimal transport LP of
+ *                         ot.emd2 (sda/utils.py:215) for uniform weights and equally many samples (POT, a third-party CPU
+ *                         solver, is not vendored by the reference); col_of_row (optional) receives the permutation.
+ * ------------------------------------------------------------------------------------------ */
+int sda_pairwise_dist(const float* x, int m, const float* y, int n, int64_t d, int take_sqrt, float* out, void* stream);
+int sda_mmd_kernel_sums(const float* d2, int64_t count, double* partial, int nblocks, void* stream);
+int sda_assignment_cost(const float* cost, int n, double* total, int* col_of_row);
+
 #ifdef __cplusplus
 }
 #endif

@@ -492,3 +492,70 @@ def init_score_net(seed: int, prefix: str, cfg: ResMLPConfig, embedding: int, dt
 
 def cast_sd(sd: StateDict, dtype) -> StateDict:
     return {k: v.to(dtype) for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------- evaluation metrics
+# (test infrastructure like everything else in this file)
+
+MMD_BANDWIDTHS = (1e-3, 1e-2, 1e-1, 1e-0, 1e1, 1e2, 1e3)
+
+
+def mmd(x: Tensor, y: Tensor, exact: bool = False) -> Tensor:
+    """sda/utils.py:222-263.  ``exact=False`` follows the reference's arithmetic (Gram matrices, squared distances as
+    |x|^2 + |y|^2 - 2 x.y in the input dtype); ``exact=True`` forms the differences directly in float64 -- the value the
+    reference's formula approximates, free of its fp32 cancellation on the small bandwidths.  Pinned against
+    tests/golden/metrics_mmd.npz (the reference's own output)."""
+    x, y = x.flatten(1), y.flatten(1)
+    if exact:
+        x, y = x.double(), y.double()
+        err_xx = (x[:, None] - x[None]).square().sum(-1)
+        err_yy = (y[:, None] - y[None]).square().sum(-1)
+        err_xy = (x[:, None] - y[None]).square().sum(-1)
+    else:
+        xx, yy, xy = x @ x.T, y @ y.T, x @ y.T
+        dxx, dyy = xx.diag().unsqueeze(1), yy.diag().unsqueeze(0)
+        err_xx = dxx + dxx.T - 2 * xx
+        err_yy = dyy + dyy.T - 2 * yy
+        err_xy = dxx + dyy - 2 * xy
+    total = 0
+    for sigma in MMD_BANDWIDTHS:
+        total = total + torch.exp(-err_xx / sigma).mean() + torch.exp(-err_yy / sigma).mean() \
+            - 2 * torch.exp(-err_xy / sigma).mean()
+    return total
+
+
+def bpf(x: Tensor, y: Tensor, transition: Callable[[Tensor], Tensor], likelihood: Callable[[Tensor, Tensor], Tensor],
+        step: int = 1) -> Tensor:
+    """sda/utils.py:168-200: propagate, weight, multinomial resampling of whole histories.  Pinned against
+    tests/golden/metrics_bpf.npz."""
+    hist = [x]
+    for yi in y:
+        for _ in range(step):
+            hist.append(transition(hist[-1]))
+        w = likelihood(yi, hist[-1])
+        j = torch.multinomial(w, len(w), replacement=True)
+        hist = [h[j] for h in hist]
+    return torch.stack(hist, dim=1)
+
+
+def emd(x: Tensor, y: Tensor) -> Tensor:
+    """sda/utils.py:203-219: ``ot.emd2([], [], cdist(x, y))`` -- POT (PyPI ``POT``, unpinned in the reference's
+    environment file) solves min_P <P, C> over couplings with uniform marginals.  PARITY UNPINNED: POT is absent here, so
+    no fixture of the reference's own output exists.  Restated from the LP's definition: for equally many samples a
+    vertex of the transport polytope is a permutation / n (Birkhoff), so the optimum is a linear assignment (scipy's
+    solver); for unequal counts the LP itself is solved (scipy.optimize.linprog, small cases only)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment, linprog
+    c = torch.cdist(x.flatten(1).double(), y.flatten(1).double()).numpy()
+    m, n = c.shape
+    if m == n:
+        r, cidx = linear_sum_assignment(c)
+        return x.new_tensor(c[r, cidx].sum() / n)
+    a_eq = np.zeros((m + n, m * n))
+    for i in range(m):
+        a_eq[i, i * n:(i + 1) * n] = 1
+    for j in range(n):
+        a_eq[m + j, j::n] = 1
+    b_eq = np.concatenate([np.full(m, 1 / m), np.full(n, 1 / n)])
+    res = linprog(c.reshape(-1), A_eq=a_eq, b_eq=b_eq, bounds=(0, None), method='highs')
+    return x.new_tensor(res.fun)

@@ -82,6 +82,9 @@ SIGNATURES = {
     'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),
     'sda_denoise': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_guided_combine': (c_int, [c_fp, c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
+    'sda_pairwise_dist': (c_int, [c_fp, c_int, c_fp, c_int, c_int64, c_int, c_fp, c_void_p]),
+    'sda_mmd_kernel_sums': (c_int, [c_fp, c_int64, c_void_p, c_int, c_void_p]),
+    'sda_assignment_cost': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

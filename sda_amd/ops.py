@@ -299,3 +299,41 @@ def guided_combine(eps: Tensor, ghat: Tensor, vjp: Optional[Tensor], mu, sigma, 
     m, s, pair = _coef(mu, sigma)
     _lib.check(_lib.load().sda_guided_combine(eps.data_ptr(), ghat.data_ptr(), _ptr(vjp), eps.numel(), m, s, _ptr(pair),
                                               out.data_ptr(), _stream()), 'sda_guided_combine')
+
+
+# ---------------------------------------------------------------------------------------------- evaluation metrics
+def pairwise_dist(x: Tensor, y: Tensor, squared: bool) -> Tensor:
+    """x: (m, d), y: (n, d) -> (m, n) Euclidean distances (or their squares)."""
+    _dev(x, y)
+    x, y = x.contiguous(), y.contiguous()
+    if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+        raise _lib.SdaHipError(f'pairwise_dist: incompatible shapes {tuple(x.shape)} / {tuple(y.shape)}')
+    out = torch.empty(x.shape[0], y.shape[0], device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().sda_pairwise_dist(x.data_ptr(), x.shape[0], y.data_ptr(), y.shape[0], x.shape[1],
+                                             0 if squared else 1, out.data_ptr(), _stream()), 'sda_pairwise_dist')
+    return out
+
+
+def mmd_kernel_sum(d2: Tensor) -> Tensor:
+    """sum_ij sum_sigma exp(-d2_ij / sigma) as a 0-dim float64 device tensor."""
+    _dev(d2)
+    d2 = d2.contiguous()
+    nblocks = int(min(1024, max(1, (d2.numel() + 255) // 256)))
+    partial = torch.empty(nblocks, device=d2.device, dtype=torch.float64)
+    _lib.check(_lib.load().sda_mmd_kernel_sums(d2.data_ptr(), d2.numel(), partial.data_ptr(), nblocks, _stream()),
+               'sda_mmd_kernel_sums')
+    return partial.sum()
+
+
+def assignment_cost(cost: Tensor):
+    """Host linear-assignment solve of a square cost matrix (CPU tensor): (minimum total cost, column of each row)."""
+    if cost.is_cuda or cost.dtype != torch.float32 or cost.dim() != 2 or cost.shape[0] != cost.shape[1]:
+        raise _lib.SdaHipError('assignment_cost expects a square fp32 host matrix')
+    import ctypes
+    cost = cost.contiguous()
+    n = cost.shape[0]
+    total = ctypes.c_double(0.0)
+    cols = torch.empty(n, dtype=torch.int32)
+    _lib.check(_lib.load().sda_assignment_cost(cost.data_ptr(), n, ctypes.addressof(total), cols.data_ptr()),
+               'sda_assignment_cost')
+    return total.value, cols

@@ -1,5 +1,7 @@
 r"""Helpers on the sampling path (subset of the reference's ``sda/utils.py``: ACTIVATIONS and the run config
-json, sda/utils.py:19-42).  Training loop, datasets and metrics are out of scope."""
+json, sda/utils.py:19-42; the evaluation metrics ``bpf`` / ``emd`` / ``mmd`` of sda/utils.py:168-263 live in
+``sda_amd.metrics`` and are re-exported here under the reference's names).  Training loop and datasets are out of scope
+(SURVEY.md section 2)."""
 
 import json
 import random
@@ -7,6 +9,8 @@ from pathlib import Path
 from typing import Any, Dict, Sequence
 
 import torch
+
+from .metrics import bpf, emd, mmd  # noqa: F401  (sda.utils.bpf / emd / mmd)
 
 ACTIVATIONS = {
     'ReLU': torch.nn.ReLU,
