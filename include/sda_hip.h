@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 1
+#define SDA_ABI_VERSION 2
 
 enum {
     SDA_OK = 0,
@@ -102,6 +102,15 @@ typedef struct sda_conv_desc {
      * layer is eligible (3x3, stride 1, no zero insertion, no ctx, cout % 96 == 0, even output size, mt == 3) the
      * transform-domain kernel is used: 2.25x fewer multiplies, fp32 round-off-level error */
     const float* w_wino;
+    /* optional overrides (all zero = the defaults above, so a zero-initialised descriptor keeps its meaning).
+     *   explicit_pad != 0: taps read in[o*stride + t - pad_h|pad_w]; default kh/2, kw/2 (odd kernels).  Even kernels
+     *   need it.
+     *   out_sn / out_sc / out_sy / out_sx: element strides of `out` (and of dact_z / res, which always share its
+     *   layout) per image / channel / row / pixel; all zero = planar contiguous.  With pad they let the VJP of a
+     *   stride-2 convolution run as one small stride-1 convolution per output parity class, each writing its own
+     *   interleaved quarter of the gradient, instead of convolving a zero-inserted tensor (4x the multiplies). */
+    int32_t explicit_pad, pad_h, pad_w;
+    int64_t out_sn, out_sc, out_sy, out_sx;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);

@@ -49,6 +49,8 @@ class ConvDesc(Structure):
         ('res', c_fp),
         ('mt', c_int32),
         ('w_wino', c_fp),
+        ('explicit_pad', c_int32), ('pad_h', c_int32), ('pad_w', c_int32),
+        ('out_sn', c_int64), ('out_sc', c_int64), ('out_sy', c_int64), ('out_sx', c_int64),
     ]
 
 

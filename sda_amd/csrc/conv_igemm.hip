@@ -45,6 +45,7 @@ struct ConvGeom {
     int wide_out;                  // 4-pixel groups of the output are contiguous + 16-B aligned: dwordx4 epilogue
     int fast32;                    // producer offsets relative to the tile base fit 32 bits (always, in practice)
     int debug;                     // perf-ablation bits from $SDA_CONV_DEBUG (0 in production)
+    int64_t o_sn, o_sc, o_sy, o_sx; // element strides of out / dact_z / res (image, channel, row, pixel)
     int64_t lds_bytes;
 };
 
@@ -63,7 +64,9 @@ static int pick_pow2_tile(int extent, int budget) {
 static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, int max_pos = SDA_CONV_MAXPOS * SDA_CONV_THREADS) {
     if (!d || !d->x || !d->w || !d->out) return SDA_E_BADARG;
     if (d->n <= 0 || d->cx <= 0 || d->cout <= 0 || d->hs <= 0 || d->ws <= 0 || d->ho <= 0 || d->wo <= 0) return SDA_E_BADARG;
-    if (d->kh <= 0 || d->kw <= 0 || !(d->kh & 1) || !(d->kw & 1)) return SDA_E_UNSUPPORTED;
+    if (d->kh <= 0 || d->kw <= 0) return SDA_E_UNSUPPORTED;
+    if (!d->explicit_pad && (!(d->kh & 1) || !(d->kw & 1))) return SDA_E_UNSUPPORTED;     // even kernels: explicit pad
+    if (d->explicit_pad && (d->pad_h < 0 || d->pad_w < 0 || d->pad_h >= d->kh || d->pad_w >= d->kw)) return SDA_E_BADARG;
     if (d->stride_h < 1 || d->stride_w < 1 || d->up_h < 1 || d->up_w < 1 || d->zins_h < 1 || d->zins_w < 1) return SDA_E_UNSUPPORTED;
     if ((d->up_h > 1 || d->up_w > 1) && (d->zins_h > 1 || d->zins_w > 1)) return SDA_E_UNSUPPORTED;
     if (d->mt < 1 || d->mt > 4) return SDA_E_UNSUPPORTED;
@@ -73,8 +76,13 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
     g->cin = d->cx + (d->cctx > 0 ? d->cctx : 0);
     g->hv = d->hs * d->up_h * d->zins_h;
     g->wv = d->ws * d->up_w * d->zins_w;
-    g->pad_h = d->kh / 2;
-    g->pad_w = d->kw / 2;
+    g->pad_h = d->explicit_pad ? d->pad_h : d->kh / 2;
+    g->pad_w = d->explicit_pad ? d->pad_w : d->kw / 2;
+    const bool dense_out = !d->out_sn && !d->out_sc && !d->out_sy && !d->out_sx;
+    g->o_sn = dense_out ? (int64_t)d->cout * d->ho * d->wo : d->out_sn;
+    g->o_sc = dense_out ? (int64_t)d->ho * d->wo : d->out_sc;
+    g->o_sy = dense_out ? (int64_t)d->wo : d->out_sy;
+    g->o_sx = dense_out ? 1 : d->out_sx;
     g->bm = 32 * d->mt;
     if (d->cout_pad % g->bm || d->cout_pad < d->cout) return SDA_E_BADARG;
     if (d->cin_pad % SDA_CONV_CK || d->cin_pad < g->cin) return SDA_E_BADARG;
@@ -100,7 +108,7 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
     if (g->S > max_pos) return SDA_E_UNSUPPORTED;
     g->ntaps = d->kh * d->kw;
     g->nstage = d->cin_pad / SDA_CONV_CK;
-    g->wide_out = (d->wo % 4 == 0) && (g->tw >= 4) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0) &&
+    g->wide_out = dense_out && (d->wo % 4 == 0) && (g->tw >= 4) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0) &&
                   (!d->res || (reinterpret_cast<uintptr_t>(d->res) & 15) == 0) &&
                   (!d->dact_z || (reinterpret_cast<uintptr_t>(d->dact_z) & 15) == 0);
     {   // worst-case |offset| of a halo element relative to its tile's first image, channel 0
@@ -212,12 +220,12 @@ __host__ __device__ inline int64_t conv_pix_out_base(const sda_conv_desc& d, con
     int tni = p >> (g.tw_shift + g.tr_shift);
     int n = n0 + tni, oy = oy0 + ty, ox = ox0 + tx;
     if (n >= d.n || oy >= d.ho || ox >= d.wo) return -1;
-    return ((int64_t)n * d.cout * d.ho + oy) * d.wo + ox;
+    return (int64_t)n * g.o_sn + (int64_t)oy * g.o_sy + (int64_t)ox * g.o_sx;
 }
 
-__host__ __device__ inline void conv_epilogue_store(const sda_conv_desc& d, int64_t obase, int co, float acc) {
+__host__ __device__ inline void conv_epilogue_store(const sda_conv_desc& d, const ConvGeom& g, int64_t obase, int co, float acc) {
     if (obase < 0 || co >= d.cout) return;
-    int64_t off = obase + (int64_t)co * d.ho * d.wo;
+    int64_t off = obase + (int64_t)co * g.o_sc;
     float v = acc;
     if (d.bias) v += d.bias[co];
     if (d.dact_z) v *= sda_dact(d.act_d, d.dact_z[off]);
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) conv_epilogue_store(d, obase, co0 + m * 32 + mfma32_row(r, lane), acc[m][r]);
+        for (int r = 0; r < 16; ++r) conv_epilogue_store(d, g, obase, co0 + m * 32 + mfma32_row(r, lane), acc[m][r]);
 }
 
 // ---------------------------------------------------------------- v2: wave-specialised, double-buffered kernel
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
             // so each 16-cout x 64-pixel fragment is transposed through a wave-private LDS slab and leaves as
             // global_store_dwordx4 of 4 consecutive pixels per lane: 24 stores per wave and tile instead of 96.
             float* slab = smem + 2 * BUF + wave * (16 * 32 * NT);
-            const int hw_w = d.ho * d.wo;
+            const int64_t hw_w = g.o_sc;
             const int px4 = (lane & 15) * 4;                       // 16 lanes cover the wave's 32*NT-pixel run (NT = 2)
             const int64_t gb = conv_pix_out_base(d, g, wave * 32 * NT + px4, n0, oy0, ox0);
             const bool gvalid = gb >= 0;
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
         }
         // All loads of a 16-register fragment (bias / act'(z) operand / residual) are issued before its first store:
         // `out` may alias nothing here, but the compiler cannot know, and a load placed after a store waits for it.
-        const int hw_o = d.ho * d.wo;
+        const int64_t hw_o = g.o_sc;
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int64_t obase = conv_pix_out_base(d, g, (wave * NT + q) * 32 + l31, n0, oy0, ox0);
@@ -767,14 +775,17 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         if (rcw != SDA_E_UNSUPPORTED) return rcw;
     }
     static const bool force_v1 = getenv("SDA_CONV_V1") != nullptr;
-    if (!force_v1 && d && ((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 3))) {
+    const bool parity_shape = d && d->mt == 3 && d->kh >= 1 && d->kh <= 2 && d->kw >= 1 && d->kw <= 2;
+    if (!force_v1 && d && ((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 3) || parity_shape)) {
         ConvGeom g2;
         // 256-pixel tiles (one workgroup per CU) unless the problem is too small to give every CU a tile, or forced
         static const int nt_env = getenv("SDA_CONV_NT") ? atoi(getenv("SDA_CONV_NT")) : 0;
         int rc2 = nt_env == 1 ? SDA_E_LDS : conv_plan(d, &g2, 256, 1280);
         if (nt_env != 2 && (rc2 != SDA_OK || g2.grid < 256)) rc2 = conv_plan(d, &g2, 128, 1024);
         if (rc2 == SDA_OK) {
-            rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
+            if (d->kw == 3) rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
+            else if (d->kh == 1) rc2 = d->kw == 1 ? conv_launch_ws_s<3, 1, 1>(d, g2, s) : conv_launch_ws_s<3, 1, 2>(d, g2, s);
+            else rc2 = d->kw == 1 ? conv_launch_ws_s<3, 2, 1>(d, g2, s) : conv_launch_ws_s<3, 2, 2>(d, g2, s);
             if (rc2 != SDA_E_LDS) return rc2;
         } else if (rc2 != SDA_E_UNSUPPORTED && rc2 != SDA_E_LDS) {
             return rc2;
@@ -900,7 +911,7 @@ extern "C" int sda_conv_igemm_emulate(const sda_conv_desc* dp) {
             int64_t obase = conv_pix_out_base(d, g, pix, n0, oy0, ox0);
             for (int m = 0; m < MT; ++m)
                 for (int r = 0; r < 16; ++r)
-                    conv_epilogue_store(d, obase, co0 + m * 32 + mfma32_row(r, lane), acc[((size_t)tid * MT + m) * 16 + r]);
+                    conv_epilogue_store(d, g, obase, co0 + m * 32 + mfma32_row(r, lane), acc[((size_t)tid * MT + m) * 16 + r]);
         }
     }
     return SDA_OK;

@@ -48,6 +48,7 @@ int sda_wino_plan(const sda_conv_desc* d, WinoGeom* g) {
     if (!d || !d->x || !d->w_wino || !d->out) return SDA_E_UNSUPPORTED;
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
         return SDA_E_UNSUPPORTED;
+    if (d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx) return SDA_E_UNSUPPORTED;
     if (d->cctx > 0 || d->mt != WINO_MT || d->cout % WINO_BM || d->cout_pad != d->cout || d->cin_pad % WINO_CK)
         return SDA_E_UNSUPPORTED;
     if ((d->ho & 1) || (d->wo & 1) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;

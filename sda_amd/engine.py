@@ -36,6 +36,8 @@ from .ops import PackedConv, conv_out_size, make_conv_desc
 CHUNK_HBM_FRACTION = 0.45
 # fraction of unallocated HBM that activations kept from the forward for the VJP may occupy
 KEEP_HBM_FRACTION = 0.45
+# VJP of the stride-2 level heads as one small convolution per output parity class (False: one zero-insertion launch)
+PARITY_SPLIT = True
 _warned_training = False
 
 
@@ -84,12 +86,13 @@ class _ConvCache:
         self._key = None
         self._fwd = None
         self._bwd = {}
+        self._parity = None
 
     def _sync(self):
         w = self.conv.weight
         key = (w.data_ptr(), w._version, str(w.device), None if self.conv.bias is None else self.conv.bias._version)
         if key != self._key:
-            self._key, self._fwd, self._bwd = key, None, {}
+            self._key, self._fwd, self._bwd, self._parity = key, None, {}, None
 
     def fwd(self) -> PackedConv:
         self._sync()
@@ -103,11 +106,50 @@ class _ConvCache:
             self._bwd[cin_keep] = PackedConv(self.conv.weight, None, transpose=True, cin_keep=cin_keep)
         return self._bwd[cin_keep]
 
+    def bwd_parity(self):
+        """Backward-data form of a stride-2 (per axis) 3-tap convolution, split by output parity.
+
+        g_x[2i + p] only receives the taps t with (p + 1 - t) even: t = 1 for p = 0 (from g[i]) and t = 0, 2 for p = 1
+        (from g[i + 1], g[i]).  So each parity class is a small stride-1 convolution over g (1 or 2 taps per split axis,
+        pad 0) writing an interleaved quarter (half, for 1-D) of g_x -- together 9 of the 36 multiplies the zero-insertion
+        formulation spends per output pixel quad.  Returns [(py, px, PackedConv, (pad_h, pad_w))] or None when the layer
+        does not have that shape (then the zero-insertion path is used)."""
+        self._sync()
+        if self._parity is None:
+            taps = []
+            for k, s in ((self.kh, self.sh), (self.kw, self.sw)):
+                if s == 1:
+                    taps.append([(None, list(range(k)), k // 2)])
+                elif s == 2 and k == 3:
+                    taps.append([(0, [1], 0), (1, [0, 2], 0)])
+                else:
+                    taps = None
+                    break
+            if taps is None or (self.sh == 1 and self.sw == 1):
+                self._parity = False
+            else:
+                w = self.conv.weight.detach()
+                if w.dim() == 3:
+                    w = w.unsqueeze(2)
+                out = []
+                for py, ty, ph in taps[0]:
+                    for px, tx, pw in taps[1]:
+                        sub = w[:, :, ty][:, :, :, tx].contiguous()
+                        out.append((py, px, PackedConv(sub, None, transpose=True), (ph, pw)))
+                self._parity = out
+        return self._parity or None
+
 
 def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, circular: bool, stride=(1, 1), up=(1, 1),
                 zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
                 ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
-                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0):
+                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None):
+    out_strides = (0, 0, 0, 0)
+    if not out.is_contiguous():                      # an interleaved view of the real output (parity-split VJP)
+        out_strides = tuple(out.stride())
+        for t in (dact_z, res):
+            if t is not None and tuple(t.stride()) != out_strides:
+                raise SdaHipError('conv epilogue operands must share the layout of the output view')
     d = make_conv_desc(**src, w_ptr=pk.packed.data_ptr(), cin_pad=pk.k_pad, cout_pad=pk.m_pad, cout=pk.m_real,
                        kh=pk.kh, kw=pk.kw, out_ptr=out.data_ptr(), ho=ho, wo=wo, mt=pk.mt,
                        stride_h=stride[0], stride_w=stride[1], circular=circular, up_h=up[0], up_w=up[1],
@@ -119,7 +161,8 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        act_in=act_in, bias_ptr=None if bias is None else bias.data_ptr(),
                        dact_z_ptr=None if dact_z is None else dact_z.data_ptr(), act_d=act_d,
                        res_ptr=None if res is None else res.data_ptr(),
-                       w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr())
+                       w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr(),
+                       pad=pad, out_strides=out_strides)
     ops.conv_igemm(d)
 
 
@@ -410,8 +453,19 @@ class UNetEngine:
                 if hd.circular and ((hd.sh > 1 and hu % hd.sh) or (hd.sw > 1 and wu % hd.sw)):
                     raise NotImplementedError('VJP of a strided circular conv needs sizes divisible by the stride')
                 g2 = torch.empty(n, L[lvl - 1].C, hu, wu, device=dev, dtype=torch.float32)
-                launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw),
-                            res=g_skip.pop(lvl - 1))
+                skip = g_skip.pop(lvl - 1)
+                classes = hd.bwd_parity() if PARITY_SPLIT and hu % hd.sh == 0 and wu % hd.sw == 0 else None
+                if classes is not None:
+                    gsrc = planar_source(g)
+                    for py, px, pk, pad in classes:
+                        ys = slice(None) if py is None else slice(py, None, 2)
+                        xs = slice(None) if px is None else slice(px, None, 2)
+                        view = g2[:, :, ys, xs]
+                        launch_conv(pk, gsrc, view, view.shape[2], view.shape[3], circular=hd.circular, pad=pad,
+                                    res=skip[:, :, ys, xs])
+                else:
+                    launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw),
+                                res=skip)
                 g = g2
             else:
                 launch_conv(hd.bwd(cin_keep=src.cx), planar_source(g), g_in, src.hs, src.ws, circular=hd.circular,

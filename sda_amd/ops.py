@@ -57,7 +57,8 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
                    w_ptr, cin_pad, cout_pad, cout, kh, kw, out_ptr, ho, wo, mt,
                    stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
                    ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
-                   act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None) -> ConvDesc:
+                   act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None,
+                   pad=None, out_strides=(0, 0, 0, 0)) -> ConvDesc:
     d = ConvDesc()
     d.x = x_ptr
     d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
@@ -77,6 +78,9 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     d.res = res_ptr
     d.mt = mt
     d.w_wino = w_wino_ptr
+    d.explicit_pad = 0 if pad is None else 1
+    d.pad_h, d.pad_w = (0, 0) if pad is None else pad
+    d.out_sn, d.out_sc, d.out_sy, d.out_sx = out_strides
     return d
 
 

@@ -120,6 +120,33 @@ def test_loader_mod_ln_act_and_epilogue(dev, act):
     assert_close(out, ref_conv(x, wgt, None, 1, True) * dz + res, TOL)
 
 
+@pytest.mark.parametrize('circular', [False, True])
+@pytest.mark.parametrize('shape', [(2, 8, 6, 10, 5), (2, 192, 32, 32, 96), (1, 96, 16, 64, 192)])
+@pytest.mark.parametrize('kern', [(1, 1), (1, 2), (2, 1), (2, 2)])
+def test_conv_even_kernel_explicit_pad_strided_output(dev, circular, shape, kern):
+    """The parity-class convolutions of the stride-2 VJP: 1- / 2-tap kernels with pad 0 (taps read in[o + t]), written
+    into an interleaved view of a larger tensor together with a residual of the same layout."""
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    n, cin, h, w_, cout = shape
+    kh, kw = kern
+    torch.manual_seed(3)
+    x, w = torch.randn(n, cin, h, w_), torch.randn(cout, cin, kh, kw) / (kh * kw * cin) ** 0.5
+    xp = torch.nn.functional.pad(x, (0, kw - 1, 0, kh - 1), mode='circular' if circular else 'constant')
+    ref = torch.nn.functional.conv2d(xp.double(), w.double()).float()
+    big = torch.full((n, cout, 2 * h, 2 * w_), float('nan'), device=dev)
+    res = torch.randn(n, cout, 2 * h, 2 * w_)
+    resd = res.to(dev)
+    pk = ops.PackedConv(w.to(dev), None)
+    view = big[:, :, 1::2, 0::2]
+    launch_conv(pk, planar_source(x.to(dev)), view, h, w_, circular=circular, pad=(0, 0), res=resd[:, :, 1::2, 0::2])
+    torch.cuda.synchronize()
+    assert_close(view.cpu(), ref + res[:, :, 1::2, 0::2], TOL)
+    untouched = torch.ones(2 * h, 2 * w_, dtype=torch.bool)
+    untouched[1::2, 0::2] = False
+    assert torch.isnan(big.cpu()[:, :, untouched]).all()          # nothing outside the view was written
+
+
 def test_ln_stats_apply_bwd(dev):
     from sda_amd import ops
     torch.manual_seed(11)

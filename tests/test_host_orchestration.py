@@ -170,3 +170,39 @@ def test_scorenet_local_golden_and_vjp():
     xs = g['x'].clone().requires_grad_(True)
     got, = torch.autograd.grad(net(xs, g['t']), xs, gg)
     assert_close(got, ref, 5e-5)
+
+
+def test_stride2_vjp_parity_split_equals_zero_insertion(monkeypatch):
+    """The level heads' VJP as four (two, 1-D) parity-class convolutions == one convolution of the zero-inserted tensor,
+    and the split path really is the one taken (launches with an explicit pad and an interleaved output view)."""
+    from sda_amd import engine as E
+    from sda_amd import ops
+    seen = []
+    real = ops.conv_igemm
+
+    def spy(desc):
+        seen.append((desc.explicit_pad, desc.kh, desc.kw, desc.zins_h, desc.zins_w, desc.out_sx))
+        return real(desc)
+    monkeypatch.setattr(ops, 'conv_igemm', spy)
+    g, grp = load_golden('mcscore2d_tiny')
+    net2 = build_mcscore2d_tiny()
+    net2.load_state_dict(grp['sd'])
+    g1, grp1 = load_golden('unet1d_two_level')
+    net1 = build_unet1d_two_level()
+    net1.load_state_dict(grp1['sd'])
+    for net, x, t, want in ((net2, g['x'], g['t'], {(1, 1), (1, 2), (2, 1), (2, 2)}), (net1, g1['x'], g1['t'], {(1, 1), (1, 2)})):
+        torch.manual_seed(4)
+        gg = torch.randn_like(x)
+        grads = {}
+        for split in (True, False):
+            monkeypatch.setattr(E, 'PARITY_SPLIT', split)
+            seen.clear()
+            xs = x.clone().requires_grad_(True)
+            grads[split], = torch.autograd.grad(net(xs, t), xs, gg)
+            if split:
+                assert {(kh, kw) for ep, kh, kw, zh, zw, sx in seen if ep} == want
+                assert all(sx == 2 for ep, kh, kw, zh, zw, sx in seen if ep)
+                assert not any(zh > 1 or zw > 1 for ep, kh, kw, zh, zw, sx in seen)
+            else:
+                assert any(zh > 1 or zw > 1 for ep, kh, kw, zh, zw, sx in seen) and not any(ep for ep, *_ in seen)
+        assert_close(grads[True], grads[False], 1e-6)
