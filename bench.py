@@ -271,6 +271,7 @@ def main():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
+            torch.cuda.synchronize(device)           # the RCCL barrier is itself stream work
 
     if args.graph:
         sampler.capture()

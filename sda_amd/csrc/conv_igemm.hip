@@ -61,7 +61,8 @@ static int pick_pow2_tile(int extent, int budget) {
     return best;
 }
 
-static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, int max_pos = SDA_CONV_MAXPOS * SDA_CONV_THREADS) {
+static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, int max_pos = SDA_CONV_MAXPOS * SDA_CONV_THREADS,
+                     bool shrink_tn = true) {
     if (!d || !d->x || !d->w || !d->out) return SDA_E_BADARG;
     if (d->n <= 0 || d->cx <= 0 || d->cout <= 0 || d->hs <= 0 || d->ws <= 0 || d->ho <= 0 || d->wo <= 0) return SDA_E_BADARG;
     if (d->kh <= 0 || d->kw <= 0) return SDA_E_UNSUPPORTED;
@@ -89,6 +90,11 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
     g->tw = pick_pow2_tile(d->wo, bp < 128 ? bp : 128);
     g->tr = pick_pow2_tile(d->ho, bp / g->tw);
     g->tn = bp / (g->tw * g->tr);
+    // tiny images: a tile of many images can need more halo positions than the loader covers -- take fewer images per tile
+    // (the tile then has idle pixel slots; only the generic kernel accepts that)
+    while (shrink_tn && g->tn > 1 &&
+           (long)g->tn * ((g->tr - 1) * d->stride_h + d->kh) * ((g->tw - 1) * d->stride_w + d->kw) > max_pos)
+        g->tn >>= 1;
     g->tw_shift = ilog2_pow2(g->tw);
     g->tr_shift = ilog2_pow2(g->tr);
     g->tiles_x = (d->wo + g->tw - 1) / g->tw;
@@ -210,6 +216,7 @@ __host__ __device__ inline int conv_pix_lds_base(const sda_conv_desc& d, const C
     int tx = p & (g.tw - 1);
     int ty = (p >> g.tw_shift) & (g.tr - 1);
     int tni = p >> (g.tw_shift + g.tr_shift);
+    if (tni >= g.tn) tni = 0;                    // idle slot of a shrunken tile: reads staged data, result discarded
     return (tni * g.in_rows + ty * d.stride_h) * g.in_cols + tx * d.stride_w;
 }
 
@@ -219,7 +226,7 @@ __host__ __device__ inline int64_t conv_pix_out_base(const sda_conv_desc& d, con
     int ty = (p >> g.tw_shift) & (g.tr - 1);
     int tni = p >> (g.tw_shift + g.tr_shift);
     int n = n0 + tni, oy = oy0 + ty, ox = ox0 + tx;
-    if (n >= d.n || oy >= d.ho || ox >= d.wo) return -1;
+    if (tni >= g.tn || n >= d.n || oy >= d.ho || ox >= d.wo) return -1;
     return (int64_t)n * g.o_sn + (int64_t)oy * g.o_sy + (int64_t)ox * g.o_sx;
 }
 
@@ -780,8 +787,8 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         ConvGeom g2;
         // 256-pixel tiles (one workgroup per CU) unless the problem is too small to give every CU a tile, or forced
         static const int nt_env = getenv("SDA_CONV_NT") ? atoi(getenv("SDA_CONV_NT")) : 0;
-        int rc2 = nt_env == 1 ? SDA_E_LDS : conv_plan(d, &g2, 256, 1280);
-        if (nt_env != 2 && (rc2 != SDA_OK || g2.grid < 256)) rc2 = conv_plan(d, &g2, 128, 1024);
+        int rc2 = nt_env == 1 ? SDA_E_LDS : conv_plan(d, &g2, 256, 1280, false);
+        if (nt_env != 2 && (rc2 != SDA_OK || g2.grid < 256)) rc2 = conv_plan(d, &g2, 128, 1024, false);
         if (rc2 == SDA_OK) {
             if (d->kw == 3) rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
             else if (d->kh == 1) rc2 = d->kw == 1 ? conv_launch_ws_s<3, 1, 1>(d, g2, s) : conv_launch_ws_s<3, 1, 2>(d, g2, s);

@@ -71,7 +71,9 @@ def ref_conv(x, w, b, stride, circular):
 
 
 @pytest.mark.parametrize('circular', [False, True])
-@pytest.mark.parametrize('shape', [(3, 5, 8, 8, 7), (2, 11, 16, 16, 10), (1, 4, 5, 12, 3), (2, 9, 32, 32, 40)])
+@pytest.mark.parametrize('shape', [(3, 5, 8, 8, 7), (2, 11, 16, 16, 10), (1, 4, 5, 12, 3), (2, 9, 32, 32, 40),
+                                   # tiny images: tiles of many images are cut down to what the loader covers
+                                   (150, 4, 1, 1, 5), (70, 3, 3, 1, 4), (40, 2, 2, 5, 3)])
 def test_conv2d_stride1(emu, circular, shape):
     n, cin, h, w_, cout = shape
     torch.manual_seed(0)

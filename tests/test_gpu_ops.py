@@ -41,7 +41,7 @@ def ref_conv(x, w, b, stride, circular):
 
 @pytest.mark.parametrize('circular', [False, True])
 @pytest.mark.parametrize('shape', [(3, 5, 8, 8, 7), (2, 11, 64, 64, 96), (2, 96, 32, 32, 96), (1, 192, 16, 16, 384),
-                                   (1, 4, 5, 12, 3), (2, 96, 64, 64, 10)])
+                                   (1, 4, 5, 12, 3), (2, 96, 64, 64, 10), (150, 4, 1, 1, 5), (70, 3, 3, 1, 4), (40, 2, 2, 5, 3)])
 def test_conv2d_stride1(dev, circular, shape):
     n, cin, h, w_, cout = shape
     torch.manual_seed(0)
@@ -271,3 +271,22 @@ def test_linear_and_row_layernorm(dev):
         gx = torch.empty_like(xd)
         ops.row_ln_bwd(g.to(dev), xd, mean, rstd, True, res.to(dev), gx)
         assert_close(gx.cpu(), gx_ref + res, TOL, what='row_ln_bwd')
+
+
+def test_conv_randomised_sweep(dev):
+    """A bounded sample of tools/conv_fuzz.py (random layer shapes x random loader / epilogue fusions, every conv kernel
+    family) -- the full sweep (2000 cases) is run by hand on the GPU box."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'conv_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'conv_fuzz.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = random.Random(2024)
+    failures = []
+    for i in range(120):
+        cfg, msg = fuzz.one_case(rng, dev, 50000 + i)
+        if msg:
+            failures.append((cfg, msg))
+    assert not failures, failures[:3]
