@@ -143,10 +143,11 @@ int sda_ln_apply(const float* x, int n, int c, int hw, const float* mod, int64_t
                  const float* rstd, float* y, void* stream);
 /* Backward of h = LN_c(x + mod) w.r.t. x (what autograd computes through sda/nn.py:137,163):
  *   gx = (res ? res : 0) + rstd * (gh - mean_c(gh) - h * sum_c(gh*h)/(c-1|c))
- * pool = 2: gh is given at 2x resolution ([n][c][2h][2w]) and 2x2-summed first (backward of nn.Upsample nearest,
- * sda/nn.py:164).  pool_w_only = 1 for 1-D nets (h == 1). */
+ * pool_h x pool_w: gh is given at that multiple of the resolution ([n][c][pool_h*h][pool_w*w]) and summed over each cell
+ * first (backward of nn.Upsample nearest, sda/nn.py:164): 1x1 none, 2x2 for 2-D nets, 1x2 for 1-D nets (h == 1 there, but
+ * h == 1 does not imply a 1-D net: the deepest level of a 2-D net may be one row high). */
 int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
-               const float* mean, const float* rstd, int unbiased, int pool, const float* res, float* gx,
+               const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res, float* gx,
                void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -63,7 +63,7 @@ SIGNATURES = {
     'sda_pack_conv_weight_wino': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_ln_stats': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_float, c_int, c_fp, c_fp, c_void_p]),
     'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
-    'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_fp, c_fp,
+    'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,
                            c_void_p]),
     'sda_time_embed': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear_small': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),

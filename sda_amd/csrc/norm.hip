@@ -212,10 +212,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_wave_kernel(const float* __
 }
 
 extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
-                          const float* mean, const float* rstd, int unbiased, int pool, const float* res, float* gx,
-                          void* stream) {
+                          const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res,
+                          float* gx, void* stream) {
     if (!gh || !x || !mean || !rstd || !gx || n <= 0 || c <= 0 || h <= 0 || w <= 0) return SDA_E_BADARG;
-    if (pool != 1 && pool != 2) return SDA_E_UNSUPPORTED;
+    const int shape = pool_h * 10 + pool_w;          // 11: no pooling, 12: 1-D nets (length axis only), 22: 2-D nets
+    if (shape != 11 && shape != 12 && shape != 22) return SDA_E_UNSUPPORTED;
     const int64_t npix = (int64_t)n * h * w;
     const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
@@ -223,10 +224,10 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
     hipStream_t s = (hipStream_t)stream;
     if (npix < LN_SMALL_PIXELS) {
         dim3 gs((unsigned)((npix + 3) / 4));
-        if (pool == 1)
+        if (shape == 11)
             hipLaunchKernelGGL((ln_bwd_wave_kernel<1, 1>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                                unbiased, res, gx);
-        else if (h == 1)
+        else if (shape == 12)
             hipLaunchKernelGGL((ln_bwd_wave_kernel<1, 2>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                                unbiased, res, gx);
         else
@@ -234,10 +235,10 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
                                unbiased, res, gx);
         return sda_launch_status();
     }
-    if (pool == 1) {
+    if (shape == 11) {
         hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                            unbiased, res, gx);
-    } else if (h == 1) {   // 1-D net: only the length axis was upsampled
+    } else if (shape == 12) {
         hipLaunchKernelGGL((ln_bwd_kernel<1, 2>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                            unbiased, res, gx);
     } else {

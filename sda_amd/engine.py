@@ -411,7 +411,7 @@ class UNetEngine:
         c1 = blk.conv1
         launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular)
         gx = torch.empty_like(a)
-        ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, 1, g, gx)
+        ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, (1, 1), g, gx)
         return gx
 
     def backward_chunk(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
@@ -440,7 +440,7 @@ class UNetEngine:
                 launch_conv(tl.bwd(), planar_source(g), ghup, hu, wu, circular=tl.circular)
                 a, mean, rstd = saved['tails'][lvl]
                 g = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
-                ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, 2, None, g)
+                ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, (uh, uw), None, g)
             for bi in reversed(range(len(lev.ascent))):
                 g = self._block_bwd(lev.ascent[bi], g, saved['blocks'][('a', lvl, bi)], mod_all, lo, per_image)
         for lvl in reversed(range(D)):

@@ -175,11 +175,12 @@ def ln_apply(x: Tensor, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: 
 
 
 def ln_bwd(gh: Tensor, x: Tensor, h: int, w: int, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: Tensor,
-           unbiased: bool, pool: int, res: Optional[Tensor], gx: Tensor):
+           unbiased: bool, pool, res: Optional[Tensor], gx: Tensor):
+    """pool: (pool_h, pool_w) -- the nearest-upsample factors whose backward (cell sums of gh) is fused in; (1, 1) = none."""
     _dev(gh, x, mod, mean, rstd, res, gx)
     n, c = x.shape[0], x.shape[1]
     _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
-                                      rstd.data_ptr(), int(unbiased), pool, _ptr(res), gx.data_ptr(), _stream()),
+                                      rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(), _stream()),
                'sda_ln_bwd')
 
 

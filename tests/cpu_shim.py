@@ -68,11 +68,8 @@ def install(monkeypatch):
         u = _u(x, mod, mod_sn)
         hh = (u - mean.reshape(n, 1, -1)) * rstd.reshape(n, 1, -1)
         g = gh
-        if pool == 2:
-            if h == 1:
-                g = gh.reshape(n, c, 1, w, 2).sum(-1)
-            else:
-                g = gh.reshape(n, c, h, 2, w, 2).sum((-1, -3))
+        if tuple(pool) != (1, 1):
+            g = gh.reshape(n, c, h, pool[0], w, pool[1]).sum((-1, -3))
         g = g.reshape(n, c, -1)
         a = g.mean(1, keepdim=True)
         b = (g * hh).sum(1, keepdim=True) / (c - 1 if unbiased else c)

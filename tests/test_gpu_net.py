@@ -393,3 +393,25 @@ def test_fused_observation_operators_match_autograd(dev):
     a = GaussianScore(y, A=A_ref, std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
     b = GaussianScore(y, A=Ob.Subsample.space(4), std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
     assert_close(b.cpu(), a.cpu(), 1e-5)
+
+
+def test_random_architectures_forward_and_vjp():
+    """A bounded sample of tools/net_fuzz.py: random U-Net architectures / shapes (1-D, 2-D, 1-3 levels, MC windows,
+    context, every activation), forward and input-VJP against the float64 oracle.  Seed 0 contains 2-D nets whose deepest
+    level is one row high -- the shape that once took the 1-D (length-only) upsample-backward path."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'net_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'net_fuzz.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    from sda_amd import _lib
+    _lib.load()
+    rng = random.Random(0)
+    failures = []
+    for i in range(64):
+        cfg, msg = fuzz.one_case(rng, torch.device('cuda:0'), i)
+        if msg and msg != 'SKIP':
+            failures.append((cfg, msg))
+    assert not failures, failures[:3]

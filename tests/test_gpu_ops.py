@@ -150,9 +150,10 @@ def test_conv_even_kernel_explicit_pad_strided_output(dev, circular, shape, kern
 def test_ln_stats_apply_bwd(dev):
     from sda_amd import ops
     torch.manual_seed(11)
-    for (n, c, h, w_), pool in (((3, 24, 8, 8), 1), ((2, 96, 16, 16), 2), ((4, 16, 1, 20), 2), ((2, 8, 1, 33), 1),
+    for (n, c, h, w_), pool in (((3, 24, 8, 8), (1, 1)), ((2, 96, 16, 16), (2, 2)), ((4, 16, 1, 20), (1, 2)), ((2, 8, 1, 33), (1, 1)),
+                              ((3, 8, 1, 6), (2, 2)),     # a 2-D net's deepest level may be one row high
                               # >= 16384 pixels: the thread-per-pixel kernels (below: wave-per-pixel)
-                              ((5, 24, 64, 64), 1), ((3, 12, 64, 128), 2), ((2, 6, 1, 9000), 2)):
+                              ((5, 24, 64, 64), (1, 1)), ((3, 12, 64, 128), (2, 2)), ((2, 6, 1, 9000), (1, 2)), ((2, 6, 1, 9000), (2, 2))):
         x = (torch.randn(n, c, h, w_) * 3 + 1).requires_grad_(True)
         mod = torch.randn(n, c)
         xd, md = x.detach().to(dev), mod.to(dev)
@@ -163,12 +164,7 @@ def test_ln_stats_apply_bwd(dev):
         href = O.layer_norm(x + mod[:, :, None, None], dim=1)
         assert_close(y.cpu(), href, TOL, what='ln_apply')
         # backward (optionally through a nearest upsample)
-        if pool == 2:
-            hup = href.repeat_interleave(2, -1)
-            if h > 1:
-                hup = hup.repeat_interleave(2, -2)
-        else:
-            hup = href
+        hup = href.repeat_interleave(pool[1], -1).repeat_interleave(pool[0], -2)
         g = torch.randn_like(hup)
         res = torch.randn(n, c, h, w_)
         gx_ref, = torch.autograd.grad(hup, x, g)
