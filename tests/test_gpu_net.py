@@ -415,3 +415,24 @@ def test_random_architectures_forward_and_vjp():
         if msg and msg != 'SKIP':
             failures.append((cfg, msg))
     assert not failures, failures[:3]
+
+
+def test_random_guided_and_local_paths():
+    """A bounded sample of tools/path_fuzz.py: GaussianScore(MCScoreNet) with the engine forced through its chunked,
+    partial-keep/recompute and group-streamed paths, and MCScoreNet over a ResMLP kernel, against the float64 oracle."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'path_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'path_fuzz.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    from sda_amd import _lib
+    _lib.load()
+    rng = random.Random(5)
+    failures = []
+    for i in range(45):
+        cfg, msg = (fuzz.guided_case if i % 3 else fuzz.local_case)(rng, torch.device('cuda:0'), 700 + i)
+        if msg:
+            failures.append((cfg, msg))
+    assert not failures, failures[:3]
