@@ -61,8 +61,12 @@ class SyntheticScore(torch.nn.Module):
         self.net, self.scale, self.eta = net, scale, eta
 
     def forward(self, x, t, c=None):
-        mu = torch.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
-        sigma = (1 - mu ** 2 + self.eta ** 2).sqrt()
+        sched = getattr(self, '_sched', None)
+        if sched is not None:                       # the enclosing VPSDE's schedule (one launch for a device scalar t)
+            mu, sigma = sched.mu_sigma(t)
+        else:
+            mu = torch.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
+            sigma = (1 - mu ** 2 + self.eta ** 2).sqrt()
         return x * (sigma / (mu * mu + sigma * sigma)) + self.scale * self.net(x, t, c)
 
 
@@ -259,6 +263,7 @@ def main():
     global_batch = b * world
     score = SyntheticScore(net)
     inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)       # plain attribute: not a submodule (inner.eps is score)
     torch.manual_seed(2)
     y = torch.randn(A(torch.empty((b,) + event)).shape)
     eps_mod = GaussianScore(y, A=A, std=0.1, sde=inner) if args.guided else score

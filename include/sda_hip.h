@@ -194,6 +194,9 @@ int sda_unfold_adjoint(const float* g_win, int b, int nw, int k, int c, int hw, 
  *   correct:  delta = tau / mean(eps^2); x = x - (delta*eps + sqrt(2 delta)*z)*sigma   (score.py:259-261)
  * coef: device pointer to {r, c1} / {sigma} when coef_dev != NULL (graph replay), else the by-value scalars.
  * ------------------------------------------------------------------------------------------ */
+/* out2 = {mu(t), sigma(t)} of the VP / sub-VP / sub-sub-VP schedules (sda/score.py:195-210, 279-302) for a device scalar t.
+ * alpha_kind 0 'lin', 1 'cos' (k = acos(sqrt(eta))), 2 'exp' (k = log(eta)); sigma_kind 0 VPSDE, 1 SubVPSDE, 2 SubSubVPSDE. */
+int sda_vp_schedule(const float* t, int alpha_kind, float eta, float k, int sigma_kind, float* out2, void* stream);
 int sda_pc_predict(float* x, const float* eps, int64_t numel, float r, float c1, const float* coef_dev, void* stream);
 int sda_sumsq_partial(const float* eps, int b, int64_t per_sample, float* partial, int nchunk, void* stream);
 int sda_pc_correct(float* x, const float* eps, const float* z, int b, int64_t per_sample, const float* partial,

@@ -79,6 +79,7 @@ SIGNATURES = {
     'sda_fold': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_fold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_unfold_adjoint': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int64, c_fp, c_void_p]),
+    'sda_vp_schedule': (c_int, [c_fp, c_int, c_float, c_float, c_int, c_fp, c_void_p]),
     'sda_pc_predict': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_void_p]),
     'sda_sumsq_partial': (c_int, [c_fp, c_int, c_int64, c_fp, c_int, c_void_p]),
     'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),

@@ -168,6 +168,32 @@ extern "C" int sda_unfold_adjoint(const float* g_win, int b, int nw, int k, int 
     return sda_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------ VP schedule (score.py:195-210, 279-302)
+// out = {mu(t), sigma(t)} for a device-resident scalar t: one launch instead of the ~10 scalar torch kernels that
+// alpha(t), alpha(t)**2, 1 - ..., sqrt make of it (they dominate the launch count of the 1-D nets' guided step).
+//   alpha_kind 0 'lin': 1 - (1 - eta) t      1 'cos': cos(k t)^2, k = acos(sqrt(eta))      2 'exp': exp(k t^2), k = log(eta)
+//   sigma_kind 0 VPSDE: sqrt(1 - a^2 + eta^2)    1 SubVPSDE: 1 - a^2 + eta    2 SubSubVPSDE: 1 - a + eta
+__global__ void vp_schedule_kernel(const float* __restrict__ t, int alpha_kind, float eta, float k, int sigma_kind,
+                                   float* __restrict__ out) {
+    const float tv = t[0];
+    float a;
+    if (alpha_kind == 0) a = 1.0f - (1.0f - eta) * tv;
+    else if (alpha_kind == 1) { const float c = cosf(k * tv); a = c * c; }
+    else a = expf(k * (tv * tv));
+    float sg;
+    if (sigma_kind == 0) sg = sqrtf((1.0f - a * a) + eta * eta);
+    else if (sigma_kind == 1) sg = (1.0f - a * a) + eta;
+    else sg = (1.0f - a) + eta;
+    out[0] = a;
+    out[1] = sg;
+}
+
+extern "C" int sda_vp_schedule(const float* t, int alpha_kind, float eta, float k, int sigma_kind, float* out2, void* stream) {
+    if (!t || !out2 || alpha_kind < 0 || alpha_kind > 2 || sigma_kind < 0 || sigma_kind > 2) return SDA_E_BADARG;
+    hipLaunchKernelGGL(vp_schedule_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t, alpha_kind, eta, k, sigma_kind, out2);
+    return sda_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------ predictor / corrector (score.py:250-261)
 __global__ void pc_predict_kernel(float* __restrict__ x, const float* __restrict__ eps, int64_t numel, float r, float c1,
                                   const float* __restrict__ coef) {

@@ -282,9 +282,30 @@ def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: 
                                           SUMSQ_CHUNKS, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
 
 
+def vp_schedule(t: Tensor, alpha_kind: int, eta: float, k: float, sigma_kind: int) -> Tensor:
+    """Device scalar t -> device pair {mu(t), sigma(t)} in one launch."""
+    _dev(t)
+    out = torch.empty(2, device=t.device, dtype=torch.float32)
+    _lib.check(_lib.load().sda_vp_schedule(t.data_ptr(), alpha_kind, eta, k, sigma_kind, out.data_ptr(), _stream()),
+               'sda_vp_schedule')
+    return out
+
+
+def _adjacent_pair(mu, sigma):
+    """mu, sigma that are elements 0 and 1 of one fp32 device buffer (what vp_schedule returns) already form the pair."""
+    if isinstance(mu, Tensor) and isinstance(sigma, Tensor) and mu.is_cuda and mu.dtype == sigma.dtype == torch.float32 \
+            and mu.numel() == sigma.numel() == 1 and sigma.data_ptr() == mu.data_ptr() + 4 \
+            and mu.untyped_storage().data_ptr() == sigma.untyped_storage().data_ptr():
+        return mu.as_strided((2,), (1,))
+    return None
+
+
 def _coef(mu, sigma):
     """python floats travel by value; 0-dim device tensors travel as a device {mu, sigma} pair (no host sync)."""
     if isinstance(mu, Tensor) or isinstance(sigma, Tensor):
+        pair = _adjacent_pair(mu, sigma)
+        if pair is not None:
+            return 0.0, 0.0, pair
         dev = mu.device if isinstance(mu, Tensor) else sigma.device
         pair = torch.stack([torch.as_tensor(mu, dtype=torch.float32, device=dev).reshape(()),
                             torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(())])

@@ -256,6 +256,7 @@ class VPSDE(nn.Module):
         self.shape = shape
         self.dims = tuple(range(-len(shape), 0))
         self.eta = eta
+        self.alpha_kind = alpha
         if alpha == 'lin':
             self.alpha = lambda t: 1 - (1 - eta) * t
         elif alpha == 'cos':
@@ -271,6 +272,20 @@ class VPSDE(nn.Module):
 
     def sigma(self, t: Tensor) -> Tensor:
         return (1 - self.alpha(t) ** 2 + self.eta ** 2).sqrt()
+
+    def mu_sigma(self, t: Tensor):
+        """(mu(t), sigma(t)).  For a device-resident scalar t and the stock schedules both come from one HIP launch (as
+        adjacent elements of one buffer, which the elementwise kernels take as their device coefficient pair); anything
+        else -- batched t, CPU tensors, subclasses overriding mu / sigma / alpha -- goes through mu() and sigma()."""
+        cls = type(self)
+        kind = _SIGMA_KINDS.get(cls.sigma)
+        if (torch.is_tensor(t) and t.is_cuda and t.numel() == 1 and t.dtype == torch.float32 and kind is not None
+                and cls.mu is VPSDE.mu and self.alpha_kind in _ALPHA_KINDS):
+            ak = _ALPHA_KINDS[self.alpha_kind]
+            k = (0.0, math.acos(math.sqrt(self.eta)), math.log(self.eta))[ak]
+            pair = ops.vp_schedule(t.reshape(1), ak, self.eta, k, kind)
+            return pair[0].reshape(t.shape), pair[1].reshape(t.shape)
+        return self.mu(t), self.sigma(t)
 
     def forward(self, x: Tensor, t: Tensor, train: bool = False) -> Tensor:
         r"""Samples from the perturbation kernel p(x(t) | x)."""
@@ -424,6 +439,15 @@ class SubSubVPSDE(VPSDE):
         return 1 - self.alpha(t) + self.eta
 
 
+_ALPHA_KINDS = {'lin': 0, 'cos': 1, 'exp': 2}
+_SIGMA_KINDS = {VPSDE.sigma: 0, SubVPSDE.sigma: 1, SubSubVPSDE.sigma: 2}
+
+
+def _mu_sigma(sde, t: Tensor):
+    f = getattr(sde, 'mu_sigma', None)
+    return f(t) if f is not None else (sde.mu(t), sde.sigma(t))
+
+
 def _eps_with_vjp(sde: VPSDE, x: Tensor, t: Tensor, c, detach: bool):
     """eps = sde.eps(x) and a closure computing J_eps^T g (None when detached)."""
     if detach:
@@ -453,7 +477,7 @@ class DPSGaussianScore(nn.Module):
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
         # (the reference's signature is (x, t); ``c`` is accepted and ignored so that VPSDE.sample, which always
         # passes it, can drive this module)
-        mu, sigma = self.sde.mu(t), self.sde.sigma(t)
+        mu, sigma = _mu_sigma(self.sde, t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, None, False)
         eps_d = eps.detach().contiguous()
         xhat = torch.empty_like(eps_d)
@@ -533,7 +557,7 @@ class GaussianScore(nn.Module):
         return out
 
     def _guided(self, x: Tensor, t: Tensor, c, rows, out: Tensor = None) -> Tensor:
-        mu, sigma = self.sde.mu(t), self.sde.sigma(t)
+        mu, sigma = _mu_sigma(self.sde, t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
         eps_d = eps.detach().contiguous()
         xhat = torch.empty_like(eps_d)
@@ -555,10 +579,14 @@ class GaussianScore(nn.Module):
             with torch.enable_grad():
                 xhat.requires_grad_(True)
                 ax = self.A(xhat)
-                err = observed(ax) - ax
-                var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
-                log_p = -(err ** 2 / var).sum() / 2
-            ghat, = torch.autograd.grad(log_p, xhat)
+            # d/dx_hat of log p = -sum(err^2 / var) / 2 is A's VJP with cotangent err / var: autograd only has to go
+            # through A itself, not through the scalar reduction (same value, a third of the launches)
+            err = observed(ax) - ax.detach()
+            var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
+            cot = err / var
+            if cot.shape != ax.shape:
+                cot = cot.sum_to_size(ax.shape)
+            ghat, = torch.autograd.grad(ax, xhat, cot)
             ghat = ghat.contiguous()
         if out is None:
             out = torch.empty_like(eps_d)

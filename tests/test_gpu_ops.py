@@ -286,3 +286,33 @@ def test_conv_randomised_sweep(dev):
         if msg:
             failures.append((cfg, msg))
     assert not failures, failures[:3]
+
+
+def test_vp_schedule_kernel(dev):
+    """mu_sigma(t) for a device scalar == the schedule tables of every SDE flavour (oracle Schedule, pinned to the
+    reference's own tables in tests/golden/schedule.npz), and the pair is handed to the kernels without a copy."""
+    from sda_amd import ops
+    from sda_amd.score import SubSubVPSDE, SubVPSDE, VPSDE
+    for cls, kind in ((VPSDE, 'vp'), (SubVPSDE, 'subvp'), (SubSubVPSDE, 'subsubvp')):
+        for alpha in ('cos', 'lin', 'exp'):
+            sde = cls(torch.nn.Identity(), shape=(), alpha=alpha)
+            sched = O.Schedule(alpha, kind=kind)
+            for tv in (0.0, 0.013, 0.5, 0.987, 1.0):
+                t = torch.tensor(tv)
+                mu, sigma = sde.mu_sigma(t.to(dev))
+                # (tolerance: mu = cos(k t)^2 near t = 1 is ~1e-3, where one ulp of the cosine is ~5e-6 of mu, and 1 - a^2 near t = 0 cancels -- for torch's own ops too: atol = a few fp32 ulps of 1)
+                assert mu.shape == t.shape and ops._adjacent_pair(mu, sigma) is not None
+                assert_close(mu.cpu(), sched.mu(t), 2e-5, atol=3e-6)
+                assert_close(sigma.cpu(), sched.sigma(t), 2e-5, atol=3e-6)
+                assert_close(mu.cpu(), sde.mu(t), 2e-5, atol=3e-6)          # == the torch-op path
+                assert_close(sigma.cpu(), sde.sigma(t), 2e-5, atol=3e-6)
+    # batched t and overridden schedules keep the generic path
+    sde = VPSDE(torch.nn.Identity(), shape=())
+    tb = torch.rand(4, device=dev)
+    mu, sigma = sde.mu_sigma(tb)
+    assert mu.shape == tb.shape and torch.equal(mu, sde.mu(tb)) and torch.equal(sigma, sde.sigma(tb))
+
+    class Custom(VPSDE):
+        def sigma(self, t):
+            return t * 0 + 0.5
+    assert float(Custom(torch.nn.Identity(), shape=()).mu_sigma(torch.tensor(0.3, device=dev))[1]) == 0.5
