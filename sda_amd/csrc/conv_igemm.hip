@@ -366,9 +366,8 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
 //
 // Compile-time: MT (cout tile = 32 MT), NT (pixel tile = 128 NT; each consumer wave owns 32 NT pixels x all MT cout
 // sub-tiles), SPAD (LDS stride between channel planes of the halo tile, >= S), KH x KW.
-template <int MT, int NT, int SPAD, int KH, int KW>
-__global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2)) void conv_igemm_ws_kernel(const sda_conv_desc d, const ConvGeom g) {
-    constexpr int CK = SDA_CONV_CK;
+template <int MT, int NT, int SPAD, int KH, int KW, int CK = SDA_CONV_CK>
+__global__ __launch_bounds__(512, ((CK == SDA_CONV_CK && NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2)) void conv_igemm_ws_kernel(const sda_conv_desc d, const ConvGeom g) {
     constexpr int BM = MT * 32;
     constexpr int NTAPS = KH * KW;
     constexpr int NPOS = (SPAD + 255) / 256;
@@ -695,13 +694,13 @@ __global__ __launch_bounds__(512, ((NT == 1 && MT <= 3 && SPAD <= 392) ? 4 : 2))
     }
 }
 
-template <int MT, int NT, int SPAD, int KH, int KW>
+template <int MT, int NT, int SPAD, int KH, int KW, int CK = SDA_CONV_CK>
 static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
-    constexpr int BUF = KH * KW * SDA_CONV_CK * MT * 32 + SDA_CONV_CK * SPAD;
+    constexpr int BUF = KH * KW * CK * MT * 32 + CK * SPAD;
     constexpr int slab = (NT == 2 && 2 * BUF * 4 + 4 * 16 * 32 * NT * 4 <= 160 * 1024) ? 4 * 16 * 32 * NT * 4 : 0;
     constexpr int lds = 2 * BUF * 4 + slab;
     static_assert(lds <= 160 * 1024, "stage buffers exceed the LDS");
-    auto kern = conv_igemm_ws_kernel<MT, NT, SPAD, KH, KW>;
+    auto kern = conv_igemm_ws_kernel<MT, NT, SPAD, KH, KW, CK>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -716,7 +715,7 @@ static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SDA_E_BADARG;
         cus = prop.multiProcessorCount;
     }
-    const int per_cu = (NT == 1 && 2 * lds <= 160 * 1024 && MT <= 3 && SPAD <= 392) ? 2 : 1;
+    const int per_cu = (CK == SDA_CONV_CK && NT == 1 && 2 * lds <= 160 * 1024 && MT <= 3 && SPAD <= 392) ? 2 : 1;
     int grid = cus * per_cu;
     grid -= grid % 8;
     const int need = (g.grid + 7) / 8 * 8;            // never launch more workgroups than there are tiles (x8 for the XCD map)
@@ -789,6 +788,15 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         static const int nt_env = getenv("SDA_CONV_NT") ? atoi(getenv("SDA_CONV_NT")) : 0;
         int rc2 = nt_env == 1 ? SDA_E_LDS : conv_plan(d, &g2, 256, 1280, false);
         if (nt_env != 2 && (rc2 != SDA_OK || g2.grid < 256)) rc2 = conv_plan(d, &g2, 128, 1024, false);
+        // 1-D nets with a tile or less per CU are latency-bound: every K-stage costs one exposed global-load round trip
+        // (12 of the 21 us of a 64-channel, 64-pixel Lorenz layer), so they take 32-channel stages -- a quarter of the trips
+        static const bool no_ck32 = getenv("SDA_CONV_CK32") != nullptr && atoi(getenv("SDA_CONV_CK32")) == 0;
+        if (rc2 == SDA_OK && !no_ck32 && d->kh == 1 && d->kw == 3 && g2.grid <= 256 && g2.tn * g2.tr * g2.tw == 128 &&
+            g2.S <= 392 && d->cin_pad % 32 == 0 && d->mt <= 2) {
+            g2.nstage = d->cin_pad / 32;
+            if (d->mt == 1) return g2.S <= 272 ? conv_launch_ws<1, 1, 272, 1, 3, 32>(d, g2, s) : conv_launch_ws<1, 1, 392, 1, 3, 32>(d, g2, s);
+            return g2.S <= 272 ? conv_launch_ws<2, 1, 272, 1, 3, 32>(d, g2, s) : conv_launch_ws<2, 1, 392, 1, 3, 32>(d, g2, s);
+        }
         if (rc2 == SDA_OK) {
             if (d->kw == 3) rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
             else if (d->kh == 1) rc2 = d->kw == 1 ? conv_launch_ws_s<3, 1, 1>(d, g2, s) : conv_launch_ws_s<3, 1, 2>(d, g2, s);
