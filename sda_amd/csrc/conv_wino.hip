@@ -243,9 +243,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                     }
                     float v[16];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) v[a * 4 + b] = priv[pbase + a * g.hcols + b];
+                    for (int a = 0; a < 4; ++a) {                  // pbase and hcols are even: two 8-byte LDS reads per patch row
+                        const f32x2* row = reinterpret_cast<const f32x2*>(priv + pbase + a * g.hcols);
+                        const f32x2 lo = row[0], hi = row[1];
+                        v[a * 4 + 0] = lo[0]; v[a * 4 + 1] = lo[1]; v[a * 4 + 2] = hi[0]; v[a * 4 + 3] = hi[1];
+                    }
                     // B^T d B  (rows then columns)
                     float u[16];
 #pragma unroll
