@@ -218,14 +218,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
 #pragma unroll
                     for (int i = 0; i < NH; ++i) hv_[i] = xtile[hoff[i] + (((hsel >> i) & 1u) ? offb : offa)];
                     {
-                        const float ma = (d.mod && ca < g.cin) ? d.mod[ca] : 0.f;
-                        const float mb = (d.mod && cb < g.cin) ? d.mod[cb] : 0.f;
+                        // (each fusion is a wave-uniform branch: a launch without it does not pay its VALU slots)
+                        if (d.mod) {
+                            const float ma = ca < g.cin ? d.mod[ca] : 0.f;
+                            const float mb = cb < g.cin ? d.mod[cb] : 0.f;
 #pragma unroll
-                        for (int i = 0; i < NH; ++i) {
-                            const bool second = (hsel >> i) & 1u;
-                            float x_ = hv_[i] + (second ? mb : ma);
-                            if (d.ln_mean) x_ = (x_ - hmean[i]) * hrstd[i];
-                            hv_[i] = x_;
+                            for (int i = 0; i < NH; ++i) hv_[i] += ((hsel >> i) & 1u) ? mb : ma;
+                        }
+                        if (d.ln_mean) {
+#pragma unroll
+                            for (int i = 0; i < NH; ++i) hv_[i] = (hv_[i] - hmean[i]) * hrstd[i];
                         }
                         if (d.act_in == SDA_ACT_SILU) {
 #pragma unroll
@@ -234,12 +236,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
 #pragma unroll
                             for (int i = 0; i < NH; ++i) hv_[i] = sda_act(d.act_in, hv_[i]);
                         }
+                        // padding / out-of-range positions (and, in a partial last stage, padded channels) stage zeros
+                        const unsigned livem = cb < g.cin ? hmask : (ca < g.cin ? hmask & ~hsel : 0u);
 #pragma unroll
-                        for (int i = 0; i < NH; ++i) {
-                            const bool second = (hsel >> i) & 1u;
-                            const bool live = ((hmask >> i) & 1u) && ((second ? cb : ca) < g.cin);
-                            if (lane + 64 * i < 2 * g.sh) priv[lane + 64 * i] = live ? hv_[i] : 0.f;
-                        }
+                        for (int i = 0; i < NH; ++i)
+                            if (lane + 64 * i < 2 * g.sh) priv[lane + 64 * i] = ((livem >> i) & 1u) ? hv_[i] : 0.f;
                     }
                     float v[16];
 #pragma unroll
