@@ -152,13 +152,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
             constexpr int NH = 9;                          // ceil(2 * 288 / 64)
             const int pw = wave - 4;
             float* priv = smem + 2 * BUF + 4 * 2 * 32 * WINO_T + pw * (2 * 288);
-            unsigned hoff[NH];
+            unsigned hoff[NH], hoffx[NH];                  // hoffx: + one channel stride for the wave's second channel
             float hmean[NH], hrstd[NH];
+            bool hlive[NH], hinb[NH];                      // per-tile lane masks: position carries data / slot exists
             unsigned hmask = 0, hsel = 0;
 #pragma unroll
             for (int i = 0; i < NH; ++i) {
                 const int e = lane + 64 * i;
-                hoff[i] = 0; hmean[i] = 0.f; hrstd[i] = 1.f;
+                hoff[i] = 0; hoffx[i] = 0; hmean[i] = 0.f; hrstd[i] = 1.f; hlive[i] = false; hinb[i] = e < 2 * g.sh;
                 if (e < 2 * g.sh) {
                     const int chsel = e >= g.sh ? 1 : 0;
                     const int hp = e - chsel * g.sh;
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                         const int ng = n + d.x_n_off;
                         const int64_t nb = (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
                         hoff[i] = (unsigned)(nb - nb0 + (int64_t)sy * d.x_sy + (int64_t)sx * d.x_sx);
+                        hoffx[i] = hoff[i] + (chsel ? (unsigned)d.x_sc : 0u);
+                        hlive[i] = true;
                         hmask |= 1u << i;
                         if (d.ln_mean) {
                             const int64_t st = (int64_t)n * d.hs * d.ws + (int64_t)sy * d.ws + sx;
@@ -215,8 +218,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                     const unsigned offa = ca < g.cin ? (unsigned)((int64_t)ca * d.x_sc) : 0u;
                     const unsigned offb = cb < g.cin ? (unsigned)((int64_t)cb * d.x_sc) : 0u;
                     float hv_[NH];
+                    const bool full = cb < g.cin;              // both channels real (always, unless cin is not a multiple of 8)
+                    if (full) {
+                        const float* xa = xtile + (int64_t)ca * d.x_sc;        // wave-uniform base: no per-stage address VALU
 #pragma unroll
-                    for (int i = 0; i < NH; ++i) hv_[i] = xtile[hoff[i] + (((hsel >> i) & 1u) ? offb : offa)];
+                        for (int i = 0; i < NH; ++i) hv_[i] = xa[hoffx[i]];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) hv_[i] = xtile[hoff[i] + (((hsel >> i) & 1u) ? offb : offa)];
+                    }
                     {
                         // (each fusion is a wave-uniform branch: a launch without it does not pay its VALU slots)
                         if (d.mod) {
@@ -237,10 +247,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                             for (int i = 0; i < NH; ++i) hv_[i] = sda_act(d.act_in, hv_[i]);
                         }
                         // padding / out-of-range positions (and, in a partial last stage, padded channels) stage zeros
-                        const unsigned livem = cb < g.cin ? hmask : (ca < g.cin ? hmask & ~hsel : 0u);
+                        if (full) {
 #pragma unroll
-                        for (int i = 0; i < NH; ++i)
-                            if (lane + 64 * i < 2 * g.sh) priv[lane + 64 * i] = ((livem >> i) & 1u) ? hv_[i] : 0.f;
+                            for (int i = 0; i < NH; ++i)
+                                if (hinb[i]) priv[lane + 64 * i] = hlive[i] ? hv_[i] : 0.f;
+                        } else {
+                            const unsigned livem = ca < g.cin ? hmask & ~hsel : 0u;
+#pragma unroll
+                            for (int i = 0; i < NH; ++i)
+                                if (hinb[i]) priv[lane + 64 * i] = ((livem >> i) & 1u) ? hv_[i] : 0.f;
+                        }
                     }
                     float v[16];
 #pragma unroll
