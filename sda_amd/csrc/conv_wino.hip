@@ -52,6 +52,7 @@ int sda_wino_plan(const sda_conv_desc* d, WinoGeom* g) {
     if (d->cctx > 0 || d->mt != WINO_MT || d->cout % WINO_BM || d->cout_pad != d->cout || d->cin_pad % WINO_CK)
         return SDA_E_UNSUPPORTED;
     if ((d->ho & 1) || (d->wo & 1) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
+    if (d->up_h > 2 || d->up_w > 2) return SDA_E_UNSUPPORTED;                        // the loader shifts by log2(up)
     if (d->mod && d->mod_sn != 0) return SDA_E_UNSUPPORTED;            // per-image modulation: direct path
     if ((reinterpret_cast<uintptr_t>(d->out) & 7) || (d->res && (reinterpret_cast<uintptr_t>(d->res) & 7)) ||
         (d->dact_z && (reinterpret_cast<uintptr_t>(d->dact_z) & 7)))
@@ -138,6 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
         const int ck = ptid >> 5, t = ptid & 31;
         int pb = 0;                                  // barriers executed so far
         int gs = 0, tile_idx = 0;
+        // halo slot e = lane + 64 i of this wave's two channels -> (channel select, image in tile, halo row, halo column):
+        // tile-independent, so the divisions are paid once per kernel, not once per tile
+        constexpr int NH = 9;                          // ceil(2 * 288 / 64)
+        int hpk[NH];
+        bool hinb[NH];
+        unsigned hsel = 0;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = lane + 64 * i;
+            hinb[i] = e < 2 * g.sh;
+            const int chsel = e >= g.sh ? 1 : 0;
+            const int hp = e - chsel * g.sh;
+            const int plane = g.hrows * g.hcols;
+            const int in = hp / plane;
+            const int rem = hp - in * plane;
+            const int hy = rem / g.hcols, hx = rem - hy * g.hcols;
+            hpk[i] = (in << 20) | (hy << 10) | hx;
+            hsel |= (unsigned)chsel << i;
+        }
+        const int up_sh_h = d.up_h == 2 ? 1 : 0, up_sh_w = d.up_w == 2 ? 1 : 0;      // up factors are 1 or 2 (plan)
         for (int tile = t_begin + slot; tile < t_end; tile += per_xcd, ++tile_idx) {
             int ct, n0, ty0, tx0;
             wino_decode_tile(g, tile, ct, n0, ty0, tx0);
@@ -149,40 +170,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
             // wave-private LDS area: every input pixel is fetched once per channel with row-contiguous loads (a patch-wise
             // gather would fetch it four times with 8-byte lane strides), the loader fusions run once per pixel, and each
             // lane then reads its 4x4 patch back from LDS.
-            constexpr int NH = 9;                          // ceil(2 * 288 / 64)
             const int pw = wave - 4;
             float* priv = smem + 2 * BUF + 4 * 2 * 32 * WINO_T + pw * (2 * 288);
             unsigned hoff[NH], hoffx[NH];                  // hoffx: + one channel stride for the wave's second channel
             float hmean[NH], hrstd[NH];
-            bool hlive[NH], hinb[NH];                      // per-tile lane masks: position carries data / slot exists
-            unsigned hmask = 0, hsel = 0;
+            bool hlive[NH];                                // per-tile lane mask: the position carries data
+            unsigned hmask = 0;
+            const int q0 = ng0 / d.n_inner, r0 = ng0 - q0 * d.n_inner;      // wave-uniform: image n0 of the tile
 #pragma unroll
             for (int i = 0; i < NH; ++i) {
-                const int e = lane + 64 * i;
-                hoff[i] = 0; hoffx[i] = 0; hmean[i] = 0.f; hrstd[i] = 1.f; hlive[i] = false; hinb[i] = e < 2 * g.sh;
-                if (e < 2 * g.sh) {
-                    const int chsel = e >= g.sh ? 1 : 0;
-                    const int hp = e - chsel * g.sh;
-                    const int plane = g.hrows * g.hcols;
-                    const int in = hp / plane;
-                    const int rem = hp - in * plane;
-                    const int hy = rem / g.hcols, hx = rem - hy * g.hcols;
+                hoff[i] = 0; hoffx[i] = 0; hmean[i] = 0.f; hrstd[i] = 1.f; hlive[i] = false;
+                if (hinb[i]) {
+                    const int in = hpk[i] >> 20, hy = (hpk[i] >> 10) & 1023, hx = hpk[i] & 1023;
                     const int n = n0 + in;
                     int vy = 2 * ty0 - 1 + hy, vx = 2 * tx0 - 1 + hx;
                     bool ok = n < d.n;
-                    if (d.circular) {
-                        vy = conv_wrap_i(vy, g.hv);
-                        vx = conv_wrap_i(vx, g.wv);
+                    if (d.circular) {                      // |overshoot| is at most a tile: compare-and-add instead of %
+                        if (vy < 0) vy += g.hv;
+                        if (vx < 0) vx += g.wv;
+                        while (vy >= g.hv) vy -= g.hv;
+                        while (vx >= g.wv) vx -= g.wv;
                     } else {
                         ok = ok && vy >= 0 && vy < g.hv && vx >= 0 && vx < g.wv;
                     }
-                    hsel |= (unsigned)chsel << i;
                     if (ok) {
-                        const int sy = vy / d.up_h, sx = vx / d.up_w;
-                        const int ng = n + d.x_n_off;
-                        const int64_t nb = (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
+                        const int sy = vy >> up_sh_h, sx = vx >> up_sh_w;
+                        int q = q0, r = r0 + in;           // (n + x_n_off) / n_inner and % n_inner, carried from image n0
+                        while (r >= d.n_inner) { r -= d.n_inner; ++q; }
+                        const int64_t nb = (int64_t)q * d.x_sn_outer + (int64_t)r * d.x_sn_inner;
                         hoff[i] = (unsigned)(nb - nb0 + (int64_t)sy * d.x_sy + (int64_t)sx * d.x_sx);
-                        hoffx[i] = hoff[i] + (chsel ? (unsigned)d.x_sc : 0u);
+                        hoffx[i] = hoff[i] + (((hsel >> i) & 1u) ? (unsigned)d.x_sc : 0u);
                         hlive[i] = true;
                         hmask |= 1u << i;
                         if (d.ln_mean) {
