@@ -136,7 +136,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
 
     if (producer) {
         const int ptid = tid - 256;
-        const int ck = ptid >> 5, t = ptid & 31;
+        const int t = ptid & 31;
+        const int ck = 2 * (__builtin_amdgcn_readfirstlane(wave) - 4) + khalf;     // = ptid >> 5
         int pb = 0;                                  // barriers executed so far
         int gs = 0, tile_idx = 0;
         // halo slot e = lane + 64 i of this wave's two channels -> (channel select, image in tile, halo row, halo column):
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
             // wave-private LDS area: every input pixel is fetched once per channel with row-contiguous loads (a patch-wise
             // gather would fetch it four times with 8-byte lane strides), the loader fusions run once per pixel, and each
             // lane then reads its 4x4 patch back from LDS.
-            const int pw = wave - 4;
+            const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;    // scalar: channel bases / mod values become SGPR work
             float* priv = smem + 2 * BUF + 4 * 2 * 32 * WINO_T + pw * (2 * 288);
             unsigned hoff[NH], hoffx[NH];                  // hoffx: + one channel stride for the wave's second channel
             float hmean[NH], hrstd[NH];
