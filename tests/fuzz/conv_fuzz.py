@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of sda_conv_igemm (direct, Winograd, parity-class and fallback kernels) against torch fp64.
 
-    python tools/conv_fuzz.py [--cases 300] [--seed 0]
+    python tests/fuzz/conv_fuzz.py [--cases 300] [--seed 0]
 
 Every case draws a layer shape and a random subset of the loader / epilogue fusions, runs the HIP path and compares with
 a float64 torch restatement at 1e-4 scale-relative (the north_star tolerance).  Prints failures with their configuration."""
@@ -10,7 +10,7 @@ import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 

@@ -2,7 +2,7 @@
 """Randomised parity sweep of whole score networks: ScoreUNet / MCScoreNet forward and input-VJP on the GPU against the
 oracle evaluated in float64 (autograd through the oracle for the VJP).
 
-    python tools/net_fuzz.py [--cases 60] [--seed 0]
+    python tests/fuzz/net_fuzz.py [--cases 60] [--seed 0]
 
 Random architectures (1-3 levels, 1-3 blocks, channel widths incl. the 96-multiples that take the Winograd kernel,
 1-D / 2-D, zero / circular padding, any activation), random batch / window shapes, shared or per-sample times."""
@@ -11,11 +11,11 @@ import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
-from oracle import sda_oracle as O  # noqa: E402  (tools/ are test infrastructure, like tests/)
+from oracle import sda_oracle as O  # noqa: E402
 from sda_amd.score import MCScoreNet, ScoreUNet  # noqa: E402
 
 ACTS = {'SiLU': nn.SiLU, 'GELU': nn.GELU, 'ELU': nn.ELU, 'ReLU': nn.ReLU, 'SELU': nn.SELU}

@@ -3,14 +3,14 @@
 the windows, to keep only part of the activations (recompute path) and to stream the batch in groups -- against the float64
 oracle's gaussian_score; and the Lorenz local path (MCScoreNet over a ResMLP kernel), forward + VJP.
 
-    python tools/path_fuzz.py [--cases 40] [--seed 0]
+    python tests/fuzz/path_fuzz.py [--cases 40] [--seed 0]
 """
 import argparse
 import os
 import random
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 

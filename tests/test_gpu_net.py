@@ -396,14 +396,14 @@ def test_fused_observation_operators_match_autograd(dev):
 
 
 def test_random_architectures_forward_and_vjp():
-    """A bounded sample of tools/net_fuzz.py: random U-Net architectures / shapes (1-D, 2-D, 1-3 levels, MC windows,
+    """A bounded sample of tests/fuzz/net_fuzz.py: random U-Net architectures / shapes (1-D, 2-D, 1-3 levels, MC windows,
     context, every activation), forward and input-VJP against the float64 oracle.  Seed 0 contains 2-D nets whose deepest
     level is one row high -- the shape that once took the 1-D (length-only) upsample-backward path."""
     import importlib.util
     import os
     import random
     spec = importlib.util.spec_from_file_location(
-        'net_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'net_fuzz.py'))
+        'net_fuzz', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz', 'net_fuzz.py'))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     from sda_amd import _lib
@@ -418,13 +418,13 @@ def test_random_architectures_forward_and_vjp():
 
 
 def test_random_guided_and_local_paths():
-    """A bounded sample of tools/path_fuzz.py: GaussianScore(MCScoreNet) with the engine forced through its chunked,
+    """A bounded sample of tests/fuzz/path_fuzz.py: GaussianScore(MCScoreNet) with the engine forced through its chunked,
     partial-keep/recompute and group-streamed paths, and MCScoreNet over a ResMLP kernel, against the float64 oracle."""
     import importlib.util
     import os
     import random
     spec = importlib.util.spec_from_file_location(
-        'path_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'path_fuzz.py'))
+        'path_fuzz', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz', 'path_fuzz.py'))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     from sda_amd import _lib

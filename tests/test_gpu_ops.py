@@ -270,13 +270,13 @@ def test_linear_and_row_layernorm(dev):
 
 
 def test_conv_randomised_sweep(dev):
-    """A bounded sample of tools/conv_fuzz.py (random layer shapes x random loader / epilogue fusions, every conv kernel
+    """A bounded sample of tests/fuzz/conv_fuzz.py (random layer shapes x random loader / epilogue fusions, every conv kernel
     family) -- the full sweep (2000 cases) is run by hand on the GPU box."""
     import importlib.util
     import os
     import random
     spec = importlib.util.spec_from_file_location(
-        'conv_fuzz', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'conv_fuzz.py'))
+        'conv_fuzz', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz', 'conv_fuzz.py'))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     rng = random.Random(2024)
