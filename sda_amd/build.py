@@ -17,6 +17,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 ARCH = 'gfx950'
 SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+CONV_PARTS = 4                                       # see SDA_CONV_PART in csrc/conv_igemm.hip
 
 
 def _newer(target, deps):
@@ -37,17 +38,23 @@ def build(force=False, verbose=False):
     objs = []
     hdrs = _headers()
     procs = []
+    units = []                                       # (source, object suffix, extra flags)
     for src in SOURCES:
+        if src == 'conv_igemm.hip':                  # its kernel families compile as separate, parallel units
+            units += [(src, f'_p{k}', [f'-DSDA_CONV_PART={k}']) for k in range(CONV_PARTS)]
+        else:
+            units.append((src, '', []))
+    for src, suffix, flags in units:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        obj = os.path.join(LIBDIR, src.replace('.hip', suffix + '.o'))
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):
-            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-c', sp, '-o', obj]
+            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off'] + flags + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            procs.append((src + suffix, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

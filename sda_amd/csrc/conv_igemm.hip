@@ -25,6 +25,12 @@
 #ifndef SDA_CONV_CK
 #define SDA_CONV_CK 8
 #endif
+// This file is compiled once per SDA_CONV_PART (sda_amd/build.py) so that the ~60 kernel instantiations build in parallel:
+//   part 0: the C ABI, planner, generic kernel, parity / 32-channel-stage variants;   part 1: 3x3 kernels, cout tiles 32/64;
+//   part 2: 3x3 kernels, cout tiles 96/128;   part 3: 1x3 kernels (1-D nets)
+#ifndef SDA_CONV_PART
+#define SDA_CONV_PART 0
+#endif
 #define SDA_CONV_BP 128
 #define SDA_CONV_THREADS 256
 #define SDA_CONV_MAXPOS 4
@@ -741,15 +747,30 @@ static int conv_launch_ws_s(const sda_conv_desc* d, const ConvGeom& g, hipStream
     return SDA_E_LDS;
 }
 
-template <int KH, int KW>
-static int conv_launch_ws_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+// the big instantiation families live in their own translation units (parts 1-3)
+int sda_conv_ws_k33_lo(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream);    // 3x3, mt 1..2
+int sda_conv_ws_k33_hi(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream);    // 3x3, mt 3..4
+int sda_conv_ws_k13(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream);       // 1x3, mt 1..4
+#if SDA_CONV_PART == 1
+int sda_conv_ws_k33_lo(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    return d->mt == 1 ? conv_launch_ws_s<1, 3, 3>(d, g, stream) : conv_launch_ws_s<2, 3, 3>(d, g, stream);
+}
+#elif SDA_CONV_PART == 2
+int sda_conv_ws_k33_hi(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
+    return d->mt == 3 ? conv_launch_ws_s<3, 3, 3>(d, g, stream) : conv_launch_ws_s<4, 3, 3>(d, g, stream);
+}
+#elif SDA_CONV_PART == 3
+int sda_conv_ws_k13(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
     switch (d->mt) {
-        case 1: return conv_launch_ws_s<1, KH, KW>(d, g, stream);
-        case 2: return conv_launch_ws_s<2, KH, KW>(d, g, stream);
-        case 3: return conv_launch_ws_s<3, KH, KW>(d, g, stream);
-        default: return conv_launch_ws_s<4, KH, KW>(d, g, stream);
+        case 1: return conv_launch_ws_s<1, 1, 3>(d, g, stream);
+        case 2: return conv_launch_ws_s<2, 1, 3>(d, g, stream);
+        case 3: return conv_launch_ws_s<3, 1, 3>(d, g, stream);
+        default: return conv_launch_ws_s<4, 1, 3>(d, g, stream);
     }
 }
+#endif
+
+#if SDA_CONV_PART == 0
 
 template <int MT, int NPOS>
 static int conv_launch_t(const sda_conv_desc* d, const ConvGeom& g, hipStream_t stream) {
@@ -798,7 +819,7 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
             return g2.S <= 272 ? conv_launch_ws<2, 1, 272, 1, 3, 32>(d, g2, s) : conv_launch_ws<2, 1, 392, 1, 3, 32>(d, g2, s);
         }
         if (rc2 == SDA_OK) {
-            if (d->kw == 3) rc2 = d->kh == 3 ? conv_launch_ws_m<3, 3>(d, g2, s) : conv_launch_ws_m<1, 3>(d, g2, s);
+            if (d->kw == 3) rc2 = d->kh == 3 ? (d->mt <= 2 ? sda_conv_ws_k33_lo(d, g2, s) : sda_conv_ws_k33_hi(d, g2, s)) : sda_conv_ws_k13(d, g2, s);
             else if (d->kh == 1) rc2 = d->kw == 1 ? conv_launch_ws_s<3, 1, 1>(d, g2, s) : conv_launch_ws_s<3, 1, 2>(d, g2, s);
             else rc2 = d->kw == 1 ? conv_launch_ws_s<3, 2, 1>(d, g2, s) : conv_launch_ws_s<3, 2, 2>(d, g2, s);
             if (rc2 != SDA_E_LDS) return rc2;
@@ -858,6 +879,7 @@ extern "C" int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, i
     return sda_launch_status();
 }
 
+#endif  // SDA_CONV_PART == 0
 #endif  // !SDA_HOST_EMU
 
 // ---------------------------------------------------------------- CPU emulator (tests only; libsda_emu.so)
