@@ -41,6 +41,42 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const float* __res
     rstd[idx] = 1.0f / sqrtf(var + eps);
 }
 
+// c <= LN_REG_C (the 96-channel level of the Kolmogorov net carries most of the LayerNorm traffic): the pixel's channel
+// vector stays in registers between the two passes, so x is read from HBM exactly once (the generic kernel re-reads it;
+// a 256-pixel workgroup's 96 KB slice does not survive in L2 next to 255 other workgroups').
+#define LN_REG_C 96
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_reg_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
+                                                                  const float* __restrict__ mod, int64_t mod_sn, float eps,
+                                                                  int unbiased, float* __restrict__ mean,
+                                                                  float* __restrict__ rstd) {
+    const int64_t idx = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
+    if (idx >= npix) return;
+    const int64_t n = idx / hw;
+    const int p = (int)(idx - n * hw);
+    const float* xp = x + n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    float v[LN_REG_C];
+#pragma unroll
+    for (int k = 0; k < LN_REG_C; ++k) v[k] = k < c ? xp[(int64_t)k * hw] : 0.f;
+    if (mp) {
+#pragma unroll
+        for (int k = 0; k < LN_REG_C; ++k) if (k < c) v[k] += mp[k];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_REG_C; ++k) s += v[k];                 // (padded entries are 0; same summation order as the generic kernel)
+    const float m = s / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_REG_C; ++k) {
+        const float dlt = v[k] - m;
+        q += k < c ? dlt * dlt : 0.f;
+    }
+    const float var = q / (float)(unbiased ? c - 1 : c);
+    mean[idx] = m;
+    rstd[idx] = 1.0f / sqrtf(var + eps);
+}
+
 // Few pixels (the 1-D Lorenz nets: n*hw in the hundreds): one thread per pixel would leave the chip idle and serialise a
 // dependent load per channel, so one WAVEFRONT takes a pixel, its 64 lanes stride the channel axis and reduce with shuffles.
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_wave_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
@@ -80,6 +116,11 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
     }
     const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    if (c <= LN_REG_C && c > LN_REG_C / 2) {
+        hipLaunchKernelGGL(ln_stats_reg_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
+                           mod, mod_sn, eps, unbiased, mean, rstd);
+        return sda_launch_status();
+    }
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
                        mod, mod_sn, eps, unbiased, mean, rstd);
     return sda_launch_status();
