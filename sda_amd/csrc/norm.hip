@@ -45,36 +45,52 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_kernel(const float* __res
 // vector stays in registers between the two passes, so x is read from HBM exactly once (the generic kernel re-reads it;
 // a 256-pixel workgroup's 96 KB slice does not survive in L2 next to 255 other workgroups').
 #define LN_REG_C 96
+// SPLIT adjacent lanes share a pixel (channels k = sub + SPLIT j each), so c <= SPLIT * LN_REG_C: 192- and 384-channel levels too.
+template <int SPLIT>
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_reg_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
                                                                   const float* __restrict__ mod, int64_t mod_sn, float eps,
                                                                   int unbiased, float* __restrict__ mean,
                                                                   float* __restrict__ rstd) {
-    const int64_t idx = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
-    if (idx >= npix) return;
-    const int64_t n = idx / hw;
-    const int p = (int)(idx - n * hw);
+    const int64_t gt = (int64_t)blockIdx.x * LN_THREADS + threadIdx.x;
+    const int64_t idx = gt / SPLIT;
+    const int sub = (int)(gt - idx * SPLIT);
+    const bool live = idx < npix;                       // (whole lane groups: no lane of a live group exits before the shuffles)
+    const int64_t ii = live ? idx : 0;
+    const int64_t n = ii / hw;
+    const int p = (int)(ii - n * hw);
     const float* xp = x + n * (int64_t)c * hw + p;
     const float* mp = mod ? mod + n * mod_sn : nullptr;
     float v[LN_REG_C];
 #pragma unroll
-    for (int k = 0; k < LN_REG_C; ++k) v[k] = k < c ? xp[(int64_t)k * hw] : 0.f;
+    for (int j = 0; j < LN_REG_C; ++j) {
+        const int k = sub + SPLIT * j;
+        v[j] = k < c ? xp[(int64_t)k * hw] : 0.f;
+    }
     if (mp) {
 #pragma unroll
-        for (int k = 0; k < LN_REG_C; ++k) if (k < c) v[k] += mp[k];
+        for (int j = 0; j < LN_REG_C; ++j) {
+            const int k = sub + SPLIT * j;
+            if (k < c) v[j] += mp[k];
+        }
     }
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_REG_C; ++k) s += v[k];                 // (padded entries are 0; same summation order as the generic kernel)
+    for (int j = 0; j < LN_REG_C; ++j) s += v[j];
+#pragma unroll
+    for (int o = 1; o < SPLIT; o <<= 1) s += __shfl_xor(s, o, 64);
     const float m = s / (float)c;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_REG_C; ++k) {
-        const float dlt = v[k] - m;
-        q += k < c ? dlt * dlt : 0.f;
+    for (int j = 0; j < LN_REG_C; ++j) {
+        const float dlt = v[j] - m;
+        q += (sub + SPLIT * j) < c ? dlt * dlt : 0.f;
     }
-    const float var = q / (float)(unbiased ? c - 1 : c);
-    mean[idx] = m;
-    rstd[idx] = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int o = 1; o < SPLIT; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (live && sub == 0) {
+        mean[idx] = m;
+        rstd[idx] = 1.0f / sqrtf(q / (float)(unbiased ? c - 1 : c) + eps);
+    }
 }
 
 // Few pixels (the 1-D Lorenz nets: n*hw in the hundreds): one thread per pixel would leave the chip idle and serialise a
@@ -116,9 +132,13 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
     }
     const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
-    if (c <= LN_REG_C && c > LN_REG_C / 2) {
-        hipLaunchKernelGGL(ln_stats_reg_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
-                           mod, mod_sn, eps, unbiased, mean, rstd);
+    if (c > LN_REG_C / 2 && c <= 4 * LN_REG_C && blocks * 4 <= 0x7fffffffLL) {
+        const int split = c <= LN_REG_C ? 1 : (c <= 2 * LN_REG_C ? 2 : 4);
+        dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS)), bl(LN_THREADS);
+        hipStream_t st = (hipStream_t)stream;
+        if (split == 1) hipLaunchKernelGGL(ln_stats_reg_kernel<1>, gr, bl, 0, st, x, npix, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else if (split == 2) hipLaunchKernelGGL(ln_stats_reg_kernel<2>, gr, bl, 0, st, x, npix, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else hipLaunchKernelGGL(ln_stats_reg_kernel<4>, gr, bl, 0, st, x, npix, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         return sda_launch_status();
     }
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)blocks), dim3(LN_THREADS), 0, (hipStream_t)stream, x, npix, c, hw,
