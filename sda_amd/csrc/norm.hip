@@ -232,8 +232,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
 // gh and normalised activations in LN_BWD_CPL registers apiece between the reduction and the update -- gh, x, res are read
 // once and gx written once (4 streams instead of the generic kernel's 6) at full occupancy (a one-lane-per-pixel register
 // kernel needs 214-256 VGPRs and measured 1.5-2x SLOWER than the generic loop).
-#define LN_BWD_CPL 24
-template <int SPLIT>
+template <int SPLIT, int LN_BWD_CPL>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* __restrict__ gh, const float* __restrict__ x,
                                                                   int64_t npix, int c, int hw,
                                                                   const float* __restrict__ mod, int64_t mod_sn,
@@ -355,13 +354,15 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
                                unbiased, res, gx);
         return sda_launch_status();
     }
-    if (shape == 11 && c > 2 * LN_BWD_CPL && c <= 16 * LN_BWD_CPL && blocks * 16 <= 0x7fffffffLL) {
-        const int split = c <= 4 * LN_BWD_CPL ? 4 : (c <= 8 * LN_BWD_CPL ? 8 : 16);
-        dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS));
+    if (shape == 11 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
+        // lanes per pixel x channels per lane, picked per width from measurements on the Kolmogorov net's three levels
+        // (c = 96: 4 x 24 1.57 ms vs 2 x 48 2.43, 8 x 12 1.85;  c = 192: 8 x 24 0.86 vs 4 x 48 1.13;  c = 384: 8 x 48 0.59 vs 16 x 24 0.82)
         const int hw = h * w;
-        if (split == 4) hipLaunchKernelGGL(ln_bwd_split_kernel<4>, gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        else if (split == 8) hipLaunchKernelGGL(ln_bwd_split_kernel<8>, gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        else hipLaunchKernelGGL(ln_bwd_split_kernel<16>, gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        const int split = c <= 96 ? 4 : 8;
+        dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS));
+        if (c <= 96) hipLaunchKernelGGL((ln_bwd_split_kernel<4, 24>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else if (c <= 192) hipLaunchKernelGGL((ln_bwd_split_kernel<8, 24>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else hipLaunchKernelGGL((ln_bwd_split_kernel<8, 48>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
     } else if (shape == 11) {
         hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                            unbiased, res, gx);
