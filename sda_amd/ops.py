@@ -267,8 +267,14 @@ def pc_predict(x: Tensor, eps: Tensor, r: float, c1: float, coef_dev: Optional[T
 SUMSQ_CHUNKS = 64
 
 
+def _check_partial(partial: Tensor, b: int):
+    if partial.numel() < b * SUMSQ_CHUNKS or not partial.is_contiguous():
+        raise _lib.SdaHipError(f'partial-sum buffer needs {b} x {SUMSQ_CHUNKS} contiguous floats, got {tuple(partial.shape)}')
+
+
 def sumsq_partial(eps: Tensor, b: int, partial: Tensor):
     _dev(eps, partial)
+    _check_partial(partial, b)
     per = eps.numel() // b
     _lib.check(_lib.load().sda_sumsq_partial(eps.data_ptr(), b, per, partial.data_ptr(), SUMSQ_CHUNKS, _stream()),
                'sda_sumsq_partial')
@@ -277,6 +283,7 @@ def sumsq_partial(eps: Tensor, b: int, partial: Tensor):
 def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: float, sigma: float,
                coef_dev: Optional[Tensor] = None):
     _dev(x, eps, z, partial, coef_dev)
+    _check_partial(partial, b)
     per = x.numel() // b
     _lib.check(_lib.load().sda_pc_correct(x.data_ptr(), eps.data_ptr(), z.data_ptr(), b, per, partial.data_ptr(),
                                           SUMSQ_CHUNKS, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')

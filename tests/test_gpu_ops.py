@@ -319,3 +319,26 @@ def test_vp_schedule_kernel(dev):
         def sigma(self, t):
             return t * 0 + 0.5
     assert float(Custom(torch.nn.Identity(), shape=()).mu_sigma(torch.tensor(0.3, device=dev))[1]) == 0.5
+
+
+def test_small_operators_randomised_sweep(dev):
+    """A bounded sample of tests/fuzz/ops_fuzz.py: observation operators (value, adjoint vs autograd, <A x, r> = <x, A^T r>),
+    fold / unfold adjoints and the PC / guidance elementwise kernels on random shapes."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'ops_fuzz', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz', 'ops_fuzz.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = random.Random(77)
+    failures = []
+    for i in range(90):
+        cfg, msg = (fuzz.observe_case, fuzz.fold_case, fuzz.pc_case)[i % 3](rng, dev, 9000 + i)
+        if msg:
+            failures.append((cfg, msg))
+    assert not failures, failures[:3]
+    from sda_amd._lib import SdaHipError
+    with pytest.raises(SdaHipError):                       # an undersized partial-sum buffer is refused, not overrun
+        ops_ = __import__('sda_amd.ops', fromlist=['ops'])
+        ops_.sumsq_partial(torch.randn(4, 10, device=dev), 4, torch.empty(4, 8, device=dev))
