@@ -232,9 +232,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
 // gh and normalised activations in LN_BWD_CPL registers apiece between the reduction and the update -- gh, x, res are read
 // once and gx written once (4 streams instead of the generic kernel's 6) at full occupancy (a one-lane-per-pixel register
 // kernel needs 214-256 VGPRs and measured 1.5-2x SLOWER than the generic loop).
-template <int SPLIT, int LN_BWD_CPL>
+template <int SPLIT, int LN_BWD_CPL, int POOL = 1>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* __restrict__ gh, const float* __restrict__ x,
-                                                                  int64_t npix, int c, int hw,
+                                                                  int64_t npix, int c, int hw, int w,
                                                                   const float* __restrict__ mod, int64_t mod_sn,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, int unbiased,
@@ -249,11 +249,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* _
     const int64_t base = n * (int64_t)c * hw + p;
     const float* mp = mod ? mod + n * mod_sn : nullptr;
     const float m = mean[ii], r = rstd[ii];
+    const int py = p / w, px = p - py * w;
+    const int64_t gbase = n * (int64_t)c * (4 * (int64_t)hw) + (int64_t)(2 * py) * (2 * w) + 2 * px;     // (POOL == 2 only)
     float g[LN_BWD_CPL], hh[LN_BWD_CPL];
 #pragma unroll
     for (int j = 0; j < LN_BWD_CPL; ++j) {
         const int k = sub + SPLIT * j;
-        g[j] = k < c ? gh[base + (int64_t)k * hw] : 0.f;
+        if (POOL == 1) {
+            g[j] = k < c ? gh[base + (int64_t)k * hw] : 0.f;
+        } else {                                        // gh at 2x resolution: sum of the 2x2 cell (backward of nearest upsample)
+            const float* gp = gh + gbase + (int64_t)k * (4 * (int64_t)hw);
+            g[j] = k < c ? (gp[0] + gp[1]) + (gp[2 * w] + gp[2 * w + 1]) : 0.f;
+        }
         hh[j] = k < c ? x[base + (int64_t)k * hw] : 0.f;
     }
     if (mp) {
@@ -360,9 +367,16 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         const int hw = h * w;
         const int split = c <= 96 ? 4 : 8;
         dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS));
-        if (c <= 96) hipLaunchKernelGGL((ln_bwd_split_kernel<4, 24>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        else if (c <= 192) hipLaunchKernelGGL((ln_bwd_split_kernel<8, 24>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        else hipLaunchKernelGGL((ln_bwd_split_kernel<8, 48>), gr, block, 0, s, gh, x, npix, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        if (c <= 96) hipLaunchKernelGGL((ln_bwd_split_kernel<4, 24>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else if (c <= 192) hipLaunchKernelGGL((ln_bwd_split_kernel<8, 24>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else hipLaunchKernelGGL((ln_bwd_split_kernel<8, 48>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+    } else if (shape == 22 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
+        const int hw = h * w;
+        const int split = c <= 96 ? 4 : 8;
+        dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS));
+        if (c <= 96) hipLaunchKernelGGL((ln_bwd_split_kernel<4, 24, 2>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else if (c <= 192) hipLaunchKernelGGL((ln_bwd_split_kernel<8, 24, 2>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        else hipLaunchKernelGGL((ln_bwd_split_kernel<8, 48, 2>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
     } else if (shape == 11) {
         hipLaunchKernelGGL((ln_bwd_kernel<1, 1>), grid, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,
                            unbiased, res, gx);
