@@ -211,6 +211,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                     }
                 }
             }
+            // every existing slot of this wave carries data (always, for circular padding away from the batch end): the
+            // per-slot zero-select can be skipped for the whole tile
+            bool some_dead = false;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) some_dead |= hinb[i] && !hlive[i];
+            const bool all_live = __builtin_amdgcn_readfirstlane(__any((int)some_dead)) == 0;
             // where this lane's patch starts inside the wave-private halo
             int pbase;
             {
@@ -265,7 +271,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                             for (int i = 0; i < NH; ++i) hv_[i] = sda_act(d.act_in, hv_[i]);
                         }
                         // padding / out-of-range positions (and, in a partial last stage, padded channels) stage zeros
-                        if (full) {
+                        if (full && all_live) {
+#pragma unroll
+                            for (int i = 0; i < NH; ++i)
+                                if (hinb[i]) priv[lane + 64 * i] = hv_[i];
+                        } else if (full) {
 #pragma unroll
                             for (int i = 0; i < NH; ++i)
                                 if (hinb[i]) priv[lane + 64 * i] = hlive[i] ? hv_[i] : 0.f;
@@ -276,30 +286,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                                 if (hinb[i]) priv[lane + 64 * i] = ((livem >> i) & 1u) ? hv_[i] : 0.f;
                         }
                     }
-                    float v[16];
+                    // patch rows as float2 pairs (pbase and hcols are even: two 8-byte LDS reads per row); B^T d B on packed
+                    // pairs -- v_pk_add_f32 does two of the 32 adds per instruction
+                    f32x2 lo[4], hi[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {                  // pbase and hcols are even: two 8-byte LDS reads per patch row
+                    for (int a = 0; a < 4; ++a) {
                         const f32x2* row = reinterpret_cast<const f32x2*>(priv + pbase + a * g.hcols);
-                        const f32x2 lo = row[0], hi = row[1];
-                        v[a * 4 + 0] = lo[0]; v[a * 4 + 1] = lo[1]; v[a * 4 + 2] = hi[0]; v[a * 4 + 3] = hi[1];
+                        lo[a] = row[0]; hi[a] = row[1];
                     }
-                    // B^T d B  (rows then columns)
-                    float u[16];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        u[0 * 4 + b] = v[0 * 4 + b] - v[2 * 4 + b];
-                        u[1 * 4 + b] = v[1 * 4 + b] + v[2 * 4 + b];
-                        u[2 * 4 + b] = v[2 * 4 + b] - v[1 * 4 + b];
-                        u[3 * 4 + b] = v[1 * 4 + b] - v[3 * 4 + b];
-                    }
+                    // rows: u0 = v0 - v2, u1 = v1 + v2, u2 = v2 - v1, u3 = v1 - v3
+                    const f32x2 ul[4] = {lo[0] - lo[2], lo[1] + lo[2], lo[2] - lo[1], lo[1] - lo[3]};
+                    const f32x2 uh[4] = {hi[0] - hi[2], hi[1] + hi[2], hi[2] - hi[1], hi[1] - hi[3]};
                     // V[p][khalf = ck & 1][t][k2 = ck >> 1]
                     float* s_v = buf + ((ck & 1) * WINO_T + t) * 4 + (ck >> 1);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        s_v[(a * 4 + 0) * (2 * WINO_T * 4)] = u[a * 4 + 0] - u[a * 4 + 2];
-                        s_v[(a * 4 + 1) * (2 * WINO_T * 4)] = u[a * 4 + 1] + u[a * 4 + 2];
-                        s_v[(a * 4 + 2) * (2 * WINO_T * 4)] = u[a * 4 + 2] - u[a * 4 + 1];
-                        s_v[(a * 4 + 3) * (2 * WINO_T * 4)] = u[a * 4 + 1] - u[a * 4 + 3];
+                        // columns: (w0, w1) = (u0 - u2, u1 + u2);  (w2, w3) = (u2 - u1, u1 - u3)
+                        const f32x2 w01 = ul[a] + f32x2{-uh[a][0], uh[a][0]};
+                        const f32x2 w23 = f32x2{-ul[a][1], ul[a][1]} + f32x2{uh[a][0], -uh[a][1]};
+                        s_v[(a * 4 + 0) * (2 * WINO_T * 4)] = w01[0];
+                        s_v[(a * 4 + 1) * (2 * WINO_T * 4)] = w01[1];
+                        s_v[(a * 4 + 2) * (2 * WINO_T * 4)] = w23[0];
+                        s_v[(a * 4 + 3) * (2 * WINO_T * 4)] = w23[1];
                     }
                 }
             }
