@@ -24,7 +24,7 @@ cnt = collections.Counter()
 for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        if 'conv_igemm' not in k: continue
+        if 'conv_igemm' not in k and 'conv_wino' not in k: continue
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
 for k, d in agg.items():
