@@ -140,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
         const int ck = 2 * (__builtin_amdgcn_readfirstlane(wave) - 4) + khalf;     // = ptid >> 5
         int pb = 0;                                  // barriers executed so far
         int gs = 0, tile_idx = 0;
+        int t2 = 0, s2 = 0;                          // tile and stage-in-tile of global stage gs - 2
         // halo slot e = lane + 64 i of this wave's two channels -> (channel select, image in tile, halo row, halo column):
         // tile-independent, so the divisions are paid once per kernel, not once per tile
         constexpr int NH = 9;                          // ceil(2 * 288 / 64)
@@ -228,10 +229,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
             for (int st = 0; st < g.nstage; ++st, ++gs) {
                 // this ring slot was last read in global stage gs-2: wait for the barrier the consumers pass after it
                 if (gs >= 2) {
-                    const int g2 = gs - 2;
-                    const int t2 = g2 / g.nstage;
-                    const int need = 1 + g2 + t2 * EPI_BARRIERS;      // index of that barrier
+                    const int need = 1 + (gs - 2) + t2 * EPI_BARRIERS;      // index of that barrier; t2 = (gs - 2) / nstage
                     while (pb <= need) { __syncthreads(); ++pb; }
+                    if (++s2 == g.nstage) { s2 = 0; ++t2; }                  // (kept incrementally: no division per stage)
                 }
                 float* buf = smem + (gs & 1) * BUF;
                 const int c0 = st * CK;
