@@ -114,6 +114,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// NH: halo slots per producer lane, ceil(2 sh / 64) -- 6 covers the usual 8 x 4-tile workgroup tile (sh = 180), 9 the maximum (288)
+template <int NH>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d, const WinoGeom g) {
     constexpr int CK = WINO_CK, BM = WINO_BM, MT = WINO_MT;
     // LDS carries only V (the transformed input patches).  U is read by exactly one wave each (wave w owns positions
@@ -143,7 +145,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
         int t2 = 0, s2 = 0;                          // tile and stage-in-tile of global stage gs - 2
         // halo slot e = lane + 64 i of this wave's two channels -> (channel select, image in tile, halo row, halo column):
         // tile-independent, so the divisions are paid once per kernel, not once per tile
-        constexpr int NH = 9;                          // ceil(2 * 288 / 64)
         int hpk[NH];
         bool hinb[NH];
         unsigned hsel = 0;
@@ -425,16 +426,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
     }
 }
 
-int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t stream) {
+template <int NH>
+static int wino_launch_nh(const sda_conv_desc* d, const WinoGeom& g, int grid, hipStream_t stream) {
     constexpr int lds = (2 * (16 * WINO_CK * WINO_T) + 4 * 2 * 32 * WINO_T + 4 * 2 * 288) * 4;   // 2 V stages + exchange + halos = 73 KiB
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    hipLaunchKernelGGL(conv_wino_kernel<NH>, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
+    return sda_launch_status();
+}
+
+int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t stream) {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -446,8 +453,8 @@ int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t strea
     const int need = (g.grid + 7) / 8 * 8;
     if (grid > need) grid = need;
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
-    return sda_launch_status();
+    // the usual 8 x 4-tile workgroup tile has sh = 180 -> 6 halo slots per lane; only odd shapes need all 9
+    return 2 * g.sh <= 6 * 64 ? wino_launch_nh<6>(d, g, grid, stream) : wino_launch_nh<9>(d, g, grid, stream);
 }
 
 int sda_wino_try(const sda_conv_desc* d, hipStream_t stream) {
