@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 2
+#define SDA_ABI_VERSION 3
 
 enum {
     SDA_OK = 0,
@@ -201,6 +201,16 @@ int sda_pc_predict(float* x, const float* eps, int64_t numel, float r, float c1,
 int sda_sumsq_partial(const float* eps, int b, int64_t per_sample, float* partial, int nchunk, void* stream);
 int sda_pc_correct(float* x, const float* eps, const float* z, int b, int64_t per_sample, const float* partial,
                    int nchunk, float tau, float sigma, const float* coef_dev, void* stream);
+
+/* Corrector noise z ~ N(0, I) (the torch.randn_like(x) of sda/score.py:257) keyed per ROW, for batch-sharded runs:
+ *   out[r][j], r in [0, rows), depends on (seed, row0 + r, draw, j) only -- Philox4x32-10 with counter
+ *   {j/4, row, draw} and key = seed, Box-Muller on 24-bit uniforms -- so every world size draws the same noise for the
+ *   same trajectory and each rank generates its own rows only.  draw_dev (optional): the draw index is
+ *   draw_dev[0] * draw_mul + draw_add, read on the device (a step counter) => the launch is hipGraph-replayable.
+ * sda_philox_words: the raw generator words for counter {i, c1, c2, c3}, i in [0, n) (4 uint32 each; tests). */
+int sda_randn_rows(float* out, int rows, int64_t per_row, uint64_t seed, int64_t row0, int64_t draw,
+                   const int64_t* draw_dev, int64_t draw_mul, int64_t draw_add, void* stream);
+int sda_philox_words(uint32_t* out, int64_t n, uint64_t seed, uint32_t c1, uint32_t c2, uint32_t c3, void* stream);
 
 /* Gaussian-guidance elementwise pieces (sda/score.py:387,396):
  *   xhat = (x - sigma*eps)/mu ;   out = eps - (sigma/mu)*(ghat - sigma*vjp),  vjp = J_eps^T ghat

@@ -5,7 +5,7 @@ loading raises -- nothing in sda_amd computes on the CPU or through the oracle.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch  # noqa: F401  -- must be imported first: the library binds to the HIP runtime torch loaded
 
@@ -83,6 +83,8 @@ SIGNATURES = {
     'sda_pc_predict': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_void_p]),
     'sda_sumsq_partial': (c_int, [c_fp, c_int, c_int64, c_fp, c_int, c_void_p]),
     'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),
+    'sda_randn_rows': (c_int, [c_fp, c_int, c_int64, c_uint64, c_int64, c_int64, c_fp, c_int64, c_int64, c_void_p]),
+    'sda_philox_words': (c_int, [c_fp, c_int64, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
     'sda_denoise': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_guided_combine': (c_int, [c_fp, c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_pairwise_dist': (c_int, [c_fp, c_int, c_fp, c_int, c_int64, c_int, c_fp, c_void_p]),

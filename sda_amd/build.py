@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 ARCH = 'gfx950'
-SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip', 'noise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 CONV_PARTS = 4                                       # see SDA_CONV_PART in csrc/conv_igemm.hip
 

@@ -707,20 +707,14 @@ static int conv_launch_ws(const sda_conv_desc* d, const ConvGeom& g, hipStream_t
     constexpr int lds = 2 * BUF * 4 + slab;
     static_assert(lds <= 160 * 1024, "stage buffers exceed the LDS");
     auto kern = conv_igemm_ws_kernel<MT, NT, SPAD, KH, KW, CK>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static bool attr_set[SDA_MAX_DEVICES];           // per device: a process may use several GPUs
+    if (lds > 48 * 1024) {
+        const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_set);
+        if (rc != SDA_OK) return rc;
     }
     // persistent grid: as many workgroups as stay co-resident
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SDA_E_BADARG;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = sda_cu_count();
+    if (!cus) return SDA_E_BADARG;
     const int per_cu = (CK == SDA_CONV_CK && NT == 1 && 2 * lds <= 160 * 1024 && MT <= 3 && SPAD <= 392) ? 2 : 1;
     int grid = cus * per_cu;
     grid -= grid % 8;

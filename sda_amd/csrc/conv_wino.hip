@@ -430,25 +430,16 @@ template <int NH>
 static int wino_launch_nh(const sda_conv_desc* d, const WinoGeom& g, int grid, hipStream_t stream) {
     constexpr int lds = (2 * (16 * WINO_CK * WINO_T) + 4 * 2 * 32 * WINO_T + 4 * 2 * 288) * 4;   // 2 V stages + exchange + halos = 73 KiB
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static bool attr_set[SDA_MAX_DEVICES];           // per device: a process may use several GPUs
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino_kernel<NH>), lds, attr_set);
+    if (rc != SDA_OK) return rc;
     hipLaunchKernelGGL(conv_wino_kernel<NH>, dim3(grid), dim3(512), (size_t)lds, stream, *d, g);
     return sda_launch_status();
 }
 
 int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t stream) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SDA_E_BADARG;
-        cus = prop.multiProcessorCount;
-    }
+    const int cus = sda_cu_count();
+    if (!cus) return SDA_E_BADARG;
     int grid = cus - cus % 8;
     const int need = (g.grid + 7) / 8 * 8;
     if (grid > need) grid = need;

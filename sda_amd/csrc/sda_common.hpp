@@ -11,6 +11,38 @@ static inline int sda_launch_status() {
     return e == hipSuccess ? SDA_OK : (int)e;
 }
 
+// ---- per-device launch state.  A process may drive several GPUs (one after the other or from several threads), so what a
+// launcher caches -- "this kernel's dynamic-LDS limit is raised", "this many CUs" -- is indexed by the current device.
+#define SDA_MAX_DEVICES 64
+static inline int sda_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SDA_MAX_DEVICES) return -1;
+    return dev;
+}
+// CU count of the current device (0 on error)
+static inline int sda_cu_count() {
+    static int cus[SDA_MAX_DEVICES];
+    const int dev = sda_current_device();
+    if (dev < 0) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+// raise a kernel's dynamic-LDS limit once per device; `done` is the caller's per-kernel (function-local static) flag array
+static inline int sda_raise_dyn_lds(const void* kern, int lds, bool (&done)[SDA_MAX_DEVICES]) {
+    const int dev = sda_current_device();
+    if (dev < 0) return SDA_E_BADARG;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        done[dev] = true;
+    }
+    return SDA_OK;
+}
+
 // ---- activations (sda/utils.py:19-25) and their derivatives w.r.t. the pre-activation ----
 // sigmoid: on the device exp and the reciprocal are the hardware v_exp_f32 / v_rcp_f32 (1 ulp each; measured
 // end-to-end error of SiLU ~1e-7 relative) -- the accurate libm sequences cost ~30 VALU per element, which made the

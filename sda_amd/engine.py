@@ -89,10 +89,15 @@ class _ConvCache:
         self._parity = None
 
     def _sync(self):
+        # (data_ptr, _version) catches optimiser steps, .to(), load_state_dict and in-place ops on the parameter; writes
+        # through `.data` (EMA swaps: p.data.copy_(ema)) bump neither -- those callers use UNet.invalidate_engine()
         w = self.conv.weight
         key = (w.data_ptr(), w._version, str(w.device), None if self.conv.bias is None else self.conv.bias._version)
         if key != self._key:
             self._key, self._fwd, self._bwd, self._parity = key, None, {}, None
+
+    def invalidate(self):
+        self._key = None
 
     def fwd(self) -> PackedConv:
         self._sync()
@@ -219,6 +224,18 @@ class UNetEngine:
         self._proj = None
         st = unet.stride
         self.sh, self.sw = (1, st[0]) if len(st) == 1 else st
+
+    def invalidate(self):
+        """Drop every packed-weight cache (forward / backward-data / Winograd / parity packs, the concatenated projection
+        matrix).  The caches re-key themselves on parameter pointer and version, which in-place writes through ``.data``
+        (``p.data.copy_(ema)``) do not change: call this after such a write."""
+        for lev in self.levels:
+            lev.head.invalidate()
+            lev.tail.invalidate()
+            for blk in lev.descent + lev.ascent:
+                blk.conv1.invalidate()
+                blk.conv2.invalidate()
+        self._proj_key = None
 
     # -------------------------------------------------------------------------------- modulation vectors
     def _blocks(self):

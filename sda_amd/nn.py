@@ -202,6 +202,13 @@ class UNet(nn.Module):
             object.__setattr__(self, '_engine', UNetEngine(self))
         return self._engine
 
+    def invalidate_engine(self):
+        r"""Drop the engine's packed-weight caches.  They follow parameter updates on their own (pointer + version keys:
+        optimiser steps, ``.to()``, ``load_state_dict``); only writes through ``.data`` -- e.g. an EMA swap
+        ``p.data.copy_(ema)`` -- need this call."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
     def forward(self, x: Tensor, y: Tensor) -> Tensor:
         r"""x: ``(N, in_channels, *spatial)``; y: ``(N | 1, mod_features)`` -> ``(N, out_channels, *spatial)``."""
         from .engine import unet_apply

@@ -289,6 +289,21 @@ def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: 
                                           SUMSQ_CHUNKS, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
 
 
+def randn_rows(out: Tensor, seed: int, row0: int, draw: int = 0, draw_dev: Optional[Tensor] = None, draw_mul: int = 1,
+               draw_add: int = 0):
+    """out (rows, ...) <- N(0, 1) draws keyed per row: out[r] depends on (seed, row0 + r, draw) only.  With ``draw_dev`` (a
+    device int64 scalar) the draw index is ``draw_dev * draw_mul + draw_add``, read on the device (graph replay)."""
+    _dev(out)
+    if not out.is_contiguous():
+        raise _lib.SdaHipError('randn_rows writes a contiguous tensor')
+    if draw_dev is not None and (not draw_dev.is_cuda or draw_dev.dtype != torch.int64):
+        raise _lib.SdaHipError('draw_dev must be a device int64 scalar')
+    rows = out.shape[0]
+    _lib.check(_lib.load().sda_randn_rows(out.data_ptr(), rows, out.numel() // max(rows, 1), seed & 0xffffffffffffffff, row0,
+                                          draw, _ptr(draw_dev), draw_mul, draw_add, _stream()), 'sda_randn_rows')
+    return out
+
+
 def vp_schedule(t: Tensor, alpha_kind: int, eta: float, k: float, sigma_kind: int) -> Tensor:
     """Device scalar t -> device pair {mu(t), sigma(t)} in one launch."""
     _dev(t)

@@ -44,20 +44,32 @@ def sharded_initial_noise(batch: int, event: tuple, seed: int, rank: int, world_
     return torch.stack(rows)
 
 
-class ShardedNoise:
-    """Corrector noise ``z`` for this rank's rows: draw i of the stream is ``randn(batch, *event)`` from a generator
-    seeded identically on every rank; each rank keeps only its slice, so the union over ranks equals the
-    single-process stream draw for draw."""
+class KeyedNoise:
+    """Corrector noise ``z`` (score.py:257) for this rank's rows, keyed per trajectory: row ``lo + r`` of draw
+    ``step * corrections + correction`` is a function of (seed, global row, draw) only (``sda_randn_rows``: Philox4x32-10 +
+    Box-Muller on the device).  The union over ranks is therefore independent of the world size, every rank generates
+    exactly its own rows -- nothing scales with the global batch -- and, since the draw index can be read from the
+    sampler's device-side step counter, a sharded diffusion step stays hipGraph-capturable (``graph_safe``)."""
 
-    def __init__(self, batch: int, event: tuple, seed: int, rank: int, world_size: int, device):
-        self.batch, self.event = batch, tuple(event)
-        self.lo, self.hi = shard_range(batch, rank, world_size)
-        self.gen = torch.Generator(device=device).manual_seed(seed)
+    graph_safe = True
+
+    def __init__(self, rows: Tuple[int, int], event: tuple, seed: int, corrections: int, device):
+        self.lo, self.hi = rows
+        self.event, self.seed, self.corrections = tuple(event), int(seed), max(int(corrections), 1)
         self.device = device
 
+    def _out(self) -> Tensor:
+        return torch.empty((self.hi - self.lo,) + self.event, device=self.device, dtype=torch.float32)
+
     def __call__(self, step: int, correction: int) -> Tensor:
-        full = torch.randn((self.batch,) + self.event, generator=self.gen, device=self.device)
-        return full[self.lo:self.hi]
+        from . import ops
+        return ops.randn_rows(self._out(), self.seed, self.lo, draw=step * self.corrections + correction)
+
+    def draw_dev(self, step_dev: Tensor, correction: int) -> Tensor:
+        """Same draw with the step index read from device memory (graph replay)."""
+        from . import ops
+        return ops.randn_rows(self._out(), self.seed, self.lo, draw_dev=step_dev, draw_mul=self.corrections,
+                              draw_add=correction)
 
 
 def all_gather_samples(local: Tensor, batch: int) -> Tensor:
@@ -75,14 +87,23 @@ def all_gather_samples(local: Tensor, batch: int) -> Tensor:
 
 
 def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64, corrections: int = 0, tau: float = 1.0,
-                   seed: int = 0, gather: bool = True) -> Tensor:
-    """``sde.sample((batch,), ...)`` with the batch split over the ranks of the default process group."""
-    rank, ws = world()
-    lo, hi = shard_range(batch, rank, ws)
+                   seed: int = 0, gather: bool = True, rank: Optional[int] = None,
+                   world_size: Optional[int] = None) -> Tensor:
+    """``sde.sample((batch,), ...)`` with the batch split over the ranks of the default process group: this rank's rows of
+    the row-keyed noise streams, no collective inside the loop, one all-gather of the samples at the end.
+
+    ``rank`` / ``world_size`` override the process group (and imply ``gather=False``): a single process can then compute
+    any rank's shard, which is how the one-GPU test checks that the shards of a 2-rank job concatenate to the 1-rank job
+    bit for bit."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    else:
+        gather = False
+    lo, hi = shard_range(batch, rank, world_size)
     event = tuple(sde.shape)
-    sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, ws)
+    sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, world_size)
     if corrections > 0:
-        sde.noise_source = ShardedNoise(batch, event, seed + 1, rank, ws, sde.device.device)
+        sde.noise_source = KeyedNoise((lo, hi), event, seed + 1, corrections, sde.device.device)
     try:
         local = sde.sample((hi - lo,), c=c, steps=steps, corrections=corrections, tau=tau)
     finally:

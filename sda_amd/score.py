@@ -265,6 +265,8 @@ class VPSDE(nn.Module):
             self.alpha = lambda t: torch.exp(math.log(eta) * t**2)
         else:
             raise ValueError()
+        # the stock schedule lambda: mu_sigma() takes the fused-kernel path only while `alpha` is still this object
+        object.__setattr__(self, '_alpha_stock', self.alpha)
         self.register_buffer('device', torch.empty(()))
 
     def mu(self, t: Tensor) -> Tensor:
@@ -279,8 +281,9 @@ class VPSDE(nn.Module):
         else -- batched t, CPU tensors, subclasses overriding mu / sigma / alpha -- goes through mu() and sigma()."""
         cls = type(self)
         kind = _SIGMA_KINDS.get(cls.sigma)
+        stock_alpha = self.alpha is self._alpha_stock and not any('alpha' in k.__dict__ for k in cls.__mro__)
         if (torch.is_tensor(t) and t.is_cuda and t.numel() == 1 and t.dtype == torch.float32 and kind is not None
-                and cls.mu is VPSDE.mu and self.alpha_kind in _ALPHA_KINDS):
+                and cls.mu is VPSDE.mu and stock_alpha and self.alpha_kind in _ALPHA_KINDS):
             ak = _ALPHA_KINDS[self.alpha_kind]
             k = (0.0, math.acos(math.sqrt(self.eta)), math.log(self.eta))[ak]
             pair = ops.vp_schedule(t.reshape(1), ak, self.eta, k, kind)
@@ -311,7 +314,7 @@ class VPSDE(nn.Module):
                tau: float = 1.0) -> Tensor:
         r"""Samples from p(x(0)) with ``steps`` predictor steps and ``corrections`` Langevin corrections each."""
         sampler = self.sampler(shape, c, steps, corrections, tau)
-        if self.use_graph and self.noise_source is None:
+        if self.use_graph and (self.noise_source is None or getattr(self.noise_source, 'graph_safe', False)):
             sampler.capture()
         for _ in tqdm(range(steps), ncols=88):
             sampler.step()
@@ -379,8 +382,8 @@ class PCSampler:
         sde, x, cur = self.sde, self.x, self._cur
         cur.copy_(self._table.index_select(0, self._istep).reshape(-1))      # this step's scalars, device side
         ops.pc_predict(x, sde.eps(x, cur[0], self.c).contiguous(), 0.0, 0.0, coef_dev=cur[2:4])
-        for _ in range(self.corrections):
-            z = torch.randn_like(x)
+        for j in range(self.corrections):
+            z = torch.randn_like(x) if sde.noise_source is None else sde.noise_source.draw_dev(self._istep, j)
             eps = sde.eps(x, cur[1], self.c).contiguous()
             ops.sumsq_partial(eps, self.nb, self.partial)
             ops.pc_correct(x, eps, z, self.nb, self.partial, self.tau, 0.0, coef_dev=cur[4:5])
@@ -389,8 +392,9 @@ class PCSampler:
     def capture(self):
         """Record one diffusion step into a hipGraph (torch.cuda.CUDAGraph).  Leaves x, the RNG streams and the step
         counter exactly as they were."""
-        if self.sde.noise_source is not None:
-            raise SdaHipError('an injected noise_source cannot be captured into a graph')
+        if self.sde.noise_source is not None and not getattr(self.sde.noise_source, 'graph_safe', False):
+            raise SdaHipError('an injected noise_source cannot be captured into a graph (only device-keyed sources that '
+                              'implement draw_dev, e.g. parallel.KeyedNoise, can)')
         dev = self.x.device
         self._table = self._table_cpu.to(dev)
         self._cur = torch.zeros(self.ROW, device=dev, dtype=torch.float32)
@@ -545,18 +549,27 @@ class GaussianScore(nn.Module):
         return -(-B // ngroups)
 
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        return self._run(x, t, c, False)
+
+    def log_p_grad(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        r""":math:`\nabla_x \log p(y | x)` alone -- the ``s`` of score.py:394 -- through the same kernels as :meth:`forward`
+        (which returns ``eps - sigma s``); lets parity tests compare the guidance gradient without the cancellation of
+        ``(eps - forward) / sigma``."""
+        return self._run(x, t, c, True)
+
+    def _run(self, x: Tensor, t: Tensor, c, grad_only: bool) -> Tensor:
         g = self._groups(x, t, c)
         if g is None:
-            return self._guided(x, t, c, None)
+            return self._guided(x, t, c, None, None, grad_only)
         x = x.contiguous()
         out = torch.empty_like(x, dtype=torch.float32)
         B = x.shape[0]
         for lo in range(0, B, g):
             hi = min(B, lo + g)
-            self._guided(x[lo:hi], t, c, (lo, hi, B), out[lo:hi])
+            self._guided(x[lo:hi], t, c, (lo, hi, B), out[lo:hi], grad_only)
         return out
 
-    def _guided(self, x: Tensor, t: Tensor, c, rows, out: Tensor = None) -> Tensor:
+    def _guided(self, x: Tensor, t: Tensor, c, rows, out: Tensor = None, grad_only: bool = False) -> Tensor:
         mu, sigma = _mu_sigma(self.sde, t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
         eps_d = eps.detach().contiguous()
@@ -590,5 +603,10 @@ class GaussianScore(nn.Module):
             ghat = ghat.contiguous()
         if out is None:
             out = torch.empty_like(eps_d)
-        ops.guided_combine(eps_d, ghat, None if vjp is None else vjp(ghat).contiguous(), mu, sigma, out)
+        v = None if vjp is None else vjp(ghat).contiguous()
+        if grad_only:
+            # combine(0, ghat, vjp) = -(sigma/mu)(ghat - sigma vjp) = -sigma s
+            ops.guided_combine(torch.zeros_like(eps_d), ghat, v, mu, sigma, out)
+            return out.div_(-torch.as_tensor(sigma, device=out.device))
+        ops.guided_combine(eps_d, ghat, v, mu, sigma, out)
         return out

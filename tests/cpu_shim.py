@@ -157,7 +157,16 @@ def install(monkeypatch):
             out = out + res
         gx.copy_(out)
 
-    for name, fn in dict(_dev=_dev, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
+    def randn_rows(out, seed, row0, draw=0, draw_dev=None, draw_mul=1, draw_add=0):
+        from tests import philox_ref
+        if draw_dev is not None:
+            draw = int(draw_dev.item()) * draw_mul + draw_add
+        rows = out.shape[0]
+        z = philox_ref.randn_rows(rows, out.numel() // max(rows, 1), seed, row0, draw)
+        out.copy_(torch.from_numpy(z).reshape(out.shape))
+        return out
+
+    for name, fn in dict(_dev=_dev, randn_rows=randn_rows, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
                          ln_bwd=ln_bwd, time_embed=time_embed, linear_small=linear_small, fold=fold,
                          fold_adjoint=fold_adjoint, unfold_adjoint=unfold_adjoint, pc_predict=pc_predict,
                          sumsq_partial=sumsq_partial, pc_correct=pc_correct, denoise=denoise,

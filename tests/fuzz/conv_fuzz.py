@@ -27,14 +27,20 @@ def ref_conv(x, w, b, stride, circular, kh, kw):
     return F.conv2d(xp, w, b, stride=stride)
 
 
-def one_case(rng, dev, idx):
+def one_case(rng, dev, idx, large=False):
+    """large=True: images of 128 / 256 pixels per side (the configs[3] / [4] U-Net levels), one image, fewer channels."""
     mode = rng.choice(['plain', 'plain', 'wino', 'wino', 'stride2', 'up', 'zins', 'oned'])
+    if large and mode == 'oned':
+        mode = 'wino'
     circular = rng.random() < 0.6
     cfg = dict(mode=mode, circular=circular)
     if mode == 'wino':
         cin = rng.choice([8, 24, 96, 100, 192])
         cout = rng.choice([96, 192])
         h, w_ = rng.choice([2, 4, 6, 8, 16, 18, 32, 64]), rng.choice([2, 4, 8, 10, 16, 32, 64])
+        if large:
+            cin, cout = rng.choice([8, 24, 96]), 96
+            h, w_ = rng.choice([128, 256]), rng.choice([128, 256])
         kh = kw = 3
     elif mode == 'oned':
         cin, cout = rng.choice([3, 5, 64, 70]), rng.choice([3, 64, 96, 130])
@@ -43,6 +49,11 @@ def one_case(rng, dev, idx):
     else:
         cin, cout = rng.choice([1, 2, 7, 11, 24, 96, 97]), rng.choice([1, 3, 10, 32, 33, 96, 128, 160])
         h, w_ = rng.choice([1, 2, 3, 5, 8, 16, 31, 64]), rng.choice([1, 2, 4, 5, 9, 16, 33, 64])
+        if large:
+            cin, cout = rng.choice([2, 11, 21, 96]), rng.choice([10, 20, 33, 96])
+            h, w_ = rng.choice([128, 256]), rng.choice([128, 256])
+            if mode in ('up', 'zins'):
+                h, w_ = h // 2, w_ // 2
         kh = kw = 3
     n = rng.choice([1, 2, 3, 5])
     if cin * h * w_ * n > 3e6:
@@ -147,6 +158,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=300)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--large', action='store_true', help='128 / 256-pixel images')
     args = ap.parse_args()
     rng = random.Random(args.seed)
     dev = torch.device('cuda:0')
@@ -154,7 +166,7 @@ def main():
     modes = {}
     for i in range(args.cases):
         try:
-            cfg, msg = one_case(rng, dev, i + 7919 * args.seed)
+            cfg, msg = one_case(rng, dev, i + 7919 * args.seed, large=args.large)
         except Exception as e:  # noqa: BLE001
             cfg, msg = {'case': i}, f'EXCEPTION {type(e).__name__}: {e}'
         modes[cfg.get('mode')] = modes.get(cfg.get('mode'), 0) + 1

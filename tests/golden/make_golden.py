@@ -201,7 +201,22 @@ def main():
     inner = rscore.VPSDE(net2, shape=())
     gs = rscore.GaussianScore(y_obs, A=A, std=0.5, sde=inner, gamma=1e-2)
     t3 = torch.tensor(0.8)
-    guided = gs(x2, t3)
+    # the reference's own d log p / d x (the `s` of score.py:394) is captured from its torch.autograd.grad call
+    captured = []
+    real_grad = torch.autograd.grad
+
+    def capturing_grad(*a, **kw):
+        out = real_grad(*a, **kw)
+        captured.append(out[0].detach().clone())
+        return out
+
+    torch.autograd.grad = capturing_grad
+    try:
+        guided = gs(x2, t3)
+    finally:
+        torch.autograd.grad = real_grad
+    assert len(captured) == 1
+    grad_logp_ref = captured[0]
     with torch.no_grad():
         plain = net2(x2, t3)
     mu, sigma = inner.mu(t3), inner.sigma(t3)
@@ -221,7 +236,8 @@ def main():
     x_final = sde_g.sample((2,), steps=steps, corrections=corr, tau=tau)
 
     _save('mcscore2d_tiny', sd=_np(net2.state_dict()), x=x2, t=t2, out=out2, taps={k: v for k, v in taps.items()},
-          y_obs=y_obs, t_guided=t3, guided=guided, plain=plain, grad_logp=grad_logp, dps=dps_out,
+          y_obs=y_obs, t_guided=t3, guided=guided, plain=plain, grad_logp=grad_logp, grad_logp_ref=grad_logp_ref,
+          dps=dps_out,
           pc_x_init=x_init, pc_noise=torch.stack(zs), pc_x_final=x_final,
           pc_args=np.array([steps, corr, tau]))
 
@@ -243,6 +259,45 @@ def main():
     torch.random.set_rng_state(state)
     xf = sde_u.sample((3,), steps=8, corrections=2, tau=0.25)
     _save('sample_unguided_lorenz', x_init=xi, noise=torch.stack(zs), x_final=xf, args=np.array([8, 2, 0.25]))
+
+    # ---------------------------------------------------------------- observation operators of the notebooks
+    # KolmogorovFlow.coarsen / .vorticity (sda/mcs.py:340-347, 361-375) are pure-torch static methods, but sda/mcs.py imports
+    # jax at module level and cannot be executed here: the two function definitions are extracted from the file's AST and
+    # compiled on their own (the reference's text runs; nothing of it is stored).
+    import ast
+    src = open(os.path.join(REF, 'sda', 'mcs.py')).read()
+    tree = ast.parse(src)
+    fns = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == 'KolmogorovFlow':
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name in ('coarsen', 'vorticity'):
+                    item.decorator_list = []
+                    mod = ast.Module(body=[item], type_ignores=[])
+                    ns = {'torch': torch, 'Tensor': torch.Tensor}
+                    exec(compile(ast.fix_missing_locations(mod), 'sda/mcs.py', 'exec'), ns)
+                    fns[item.name] = ns[item.name]
+    assert set(fns) == {'coarsen', 'vorticity'}
+    torch.manual_seed(7)
+    xo = torch.randn(2, 3, 2, 16, 24)
+    obs = dict(x=xo)
+    for r in (2, 4):
+        xr = xo.clone().requires_grad_(True)
+        out = fns['coarsen'](xr, r)
+        cot = torch.randn(out.shape)
+        g, = torch.autograd.grad(out, xr, cot)
+        obs.update({f'coarsen{r}': out.detach(), f'coarsen{r}_cot': cot, f'coarsen{r}_vjp': g})
+    xr = xo.clone().requires_grad_(True)
+    out = fns['vorticity'](xr)
+    cot = torch.randn(out.shape)
+    g, = torch.autograd.grad(out, xr, cot)
+    obs.update(vorticity=out.detach(), vorticity_cot=cot, vorticity_vjp=g)
+    xr = xo.clone().requires_grad_(True)
+    out = fns['vorticity'](fns['coarsen'](xr, 2))           # composition used in figures.ipynb
+    cot = torch.randn(out.shape)
+    g, = torch.autograd.grad(out, xr, cot)
+    obs.update(vort_of_coarsen2=out.detach(), vort_of_coarsen2_cot=cot, vort_of_coarsen2_vjp=g)
+    _save('observe_ops', **obs)
 
     # ---------------------------------------------------------------- key inventory of the real K64 Kolmogorov net
     k64 = rscore.MCScoreNet(2, order=2)

@@ -1,0 +1,207 @@
+"""GPU parity on the BASELINE.json workloads themselves (configs[1], [3], [4]; configs[0] and [2] are covered in
+test_gpu_net.py): the HIP path through the reference-mirroring API against the CPU oracle on seeded inputs, at the real
+network sizes and resolutions but with as few trajectory windows as the oracle finishes in seconds, plus -- at the full
+configs[3] shard -- the size-independent properties (finite, deterministic, group-streaming == one pass, VJP linear).
+
+Shapes: experiments/kolmogorov/train.py:15-22 (K64 net), SURVEY.md section 8(d).  fp32, rtol 1e-4 (north_star)."""
+import pytest
+import torch
+
+from oracle import sda_oracle as O
+from tests.util import assert_close, oracle_eps_from_module, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+K64 = dict(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from sda_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _subsample4(x):
+    return x[..., ::4, ::4]
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]
+@pytest.fixture(scope='module')
+def k64_256(dev):
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(30)
+    net = make_score(size=256, **K64)
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    return net.to(dev), eps_o
+
+
+def test_config3_k64_at_256_plain_and_guided(dev, k64_256):
+    """K64 net at 256 x 256, one trajectory of L = 6 (two windows): the score and the Gaussian-guided score
+    (A = every 4th pixel, as bench.py) vs the fp32 oracle; the fused-adjoint observation path gives the same numbers."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    net, eps_o = k64_256
+    torch.manual_seed(31)
+    x = torch.randn(1, 6, 2, 256, 256)
+    t = torch.tensor(0.37)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev))
+        ref = eps_o(x, t)
+    assert_close(out.cpu(), ref, TOL, what='eps 256^2')
+    y = torch.randn(_subsample4(x).shape)
+    ref_g = O.gaussian_score(eps_o, O.Schedule(), y, _subsample4, 0.1, 1e-2, x, t)
+    gs = GaussianScore(y, A=_subsample4, std=0.1, sde=VPSDE(net, shape=())).to(dev)
+    got = gs(x.to(dev), t.to(dev))
+    assert_close(got.cpu(), ref_g, TOL, what='guided 256^2 (autograd through A)')
+    gs2 = GaussianScore(y, A=Ob.Subsample.space(4), std=0.1, sde=VPSDE(net, shape=())).to(dev)
+    got2 = gs2(x.to(dev), t.to(dev))
+    assert_close(got2.cpu(), ref_g, TOL, what='guided 256^2 (fused adjoint)')
+
+
+def test_config3_k64_at_256_vjp_vs_fp64_autograd(dev, k64_256):
+    """J^T g through one 10 x 256 x 256 window vs torch autograd through the float64 oracle."""
+    net, eps_o = k64_256
+    torch.manual_seed(32)
+    x = torch.randn(1, 5, 2, 256, 256)
+    t = torch.tensor(0.61)
+    g = torch.randn_like(x)
+    xo = x.double().requires_grad_(True)
+    eo = eps_o(xo, t.double(), torch.float64)
+    ref, = torch.autograd.grad(eo, xo, g.double())
+    xd = x.to(dev).requires_grad_(True)
+    out = net(xd, t.to(dev))
+    vjp, = torch.autograd.grad(out, xd, g.to(dev))
+    assert_close(out.detach().cpu(), eo.detach(), TOL, what='eps (fp64 oracle)')
+    assert_close(vjp.cpu(), ref, TOL, what='vjp (fp64 oracle)')
+
+
+def test_config3_full_shard_properties(dev, k64_256):
+    """The whole configs[3] per-GPU shard -- 16 trajectories x 64 x 2 x 256 x 256, 960 windows, guided -- goes through the
+    group-streamed path (its activations exceed HBM).  Size-independent checks: finite; deterministic; the first
+    trajectory equals the same trajectory evaluated alone (groups do not couple samples); the guidance VJP is linear in
+    the observation residual (out(y1) + out(y2) - out(y0) relation of an affine map)."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    net, _ = k64_256
+    torch.manual_seed(33)
+    B = 16
+    x = torch.randn(B, 64, 2, 256, 256, device=dev)
+    t = torch.tensor(0.5, device=dev)
+    A = Ob.Subsample.space(4)
+    ys = [torch.randn(B, 64, 2, 64, 64) for _ in range(2)]
+    outs = []
+    for y in ys:
+        gs = GaussianScore(y, A=A, std=0.1, sde=VPSDE(net, shape=())).to(dev)
+        outs.append(gs(x, t))
+    assert torch.isfinite(outs[0]).all()
+    gs = GaussianScore(ys[0], A=A, std=0.1, sde=VPSDE(net, shape=())).to(dev)
+    again = gs(x, t)
+    assert torch.equal(again, outs[0]), 'guided evaluation is not deterministic'
+    solo = GaussianScore(ys[0][:1], A=A, std=0.1, sde=VPSDE(net, shape=())).to(dev)(x[:1], t)
+    assert_close(outs[0][:1].cpu(), solo.cpu(), 1e-6, what='trajectory 0: streamed in a group vs alone')
+    # out is affine in y: out(y) = a + M y  =>  out((y0 + y1)/2) = (out(y0) + out(y1))/2
+    mid = GaussianScore((ys[0] + ys[1]) / 2, A=A, std=0.1, sde=VPSDE(net, shape=())).to(dev)(x, t)
+    assert rel_err(mid, (outs[0] + outs[1]) / 2) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_config4_qg_shaped_128_guided(dev):
+    """QG-shaped workload: 4 state channels => Cin = 21 (20 + forcing), Cout = 20, K64-style net at
+    128 x 128, guided with A = every 4th pixel, std 0.1.  One trajectory of L = 6 vs the oracle; VJP vs fp64 autograd."""
+    from sda_amd.experiments.kolmogorov import LocalScoreUNet
+    from sda_amd.score import GaussianScore, MCScoreNet, VPSDE
+    from sda_amd.utils import ACTIVATIONS
+    torch.manual_seed(40)
+    net = MCScoreNet(4, order=2)
+    net.kernel = LocalScoreUNet(channels=20, size=128, embedding=64, hidden_channels=(96, 192, 384),
+                                hidden_blocks=(3, 3, 3), kernel_size=3, activation=ACTIVATIONS['SiLU'], spatial=2,
+                                padding_mode='circular')
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    net.to(dev)
+    x = torch.randn(1, 6, 4, 128, 128)
+    t = torch.tensor(0.45)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev))
+    assert_close(out.cpu(), eps_o(x, t), TOL, what='eps qg')
+    y = torch.randn(_subsample4(x).shape)
+    ref = O.gaussian_score(eps_o, O.Schedule(), y, _subsample4, 0.1, 1e-2, x, t)
+    gs = GaussianScore(y, A=_subsample4, std=0.1, sde=VPSDE(net, shape=())).to(dev)
+    assert_close(gs(x.to(dev), t.to(dev)).cpu(), ref, TOL, what='guided qg')
+    # VJP of one window in float64
+    x1 = torch.randn(1, 5, 4, 128, 128)
+    g = torch.randn_like(x1)
+    xo = x1.double().requires_grad_(True)
+    ref_v, = torch.autograd.grad(eps_o(xo, t.double(), torch.float64), xo, g.double())
+    xd = x1.to(dev).requires_grad_(True)
+    got_v, = torch.autograd.grad(net(xd, t.to(dev)), xd, g.to(dev))
+    assert_close(got_v.cpu(), ref_v, TOL, what='vjp qg')
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]
+def test_config1_lorenz96_guided_eager_and_graph(dev):
+    """Lorenz-96: 40 states, L = 128, batch 64, 1-D ScoreUNet (64,)/(3,), guided with the
+    experiment's strided observation (experiments/lorenz/eval.py:75).  Score, guided score and teacher-forced PC steps
+    with injected noise vs the oracle; the hipGraph-replayed step reproduces the eager one."""
+    from sda_amd.experiments.lorenz import make_global_score
+    from sda_amd.score import GaussianScore, VPSDE
+    torch.manual_seed(10)
+    net = make_global_score(channels=40)
+    eps_o = oracle_eps_from_module(net, 'wrap1d')
+    net.to(dev)
+    B, L, S = 64, 128, 40
+    x = torch.randn(B, L, S)
+    t = torch.tensor(0.8)
+    with torch.no_grad():
+        out = net(x.to(dev), t.to(dev))
+    assert_close(out.cpu(), eps_o(x, t), TOL, what='eps lorenz96')
+    A = lambda v: v[..., ::8, :1]
+    y = torch.randn(A(x).shape)
+    gs = GaussianScore(y, A=A, std=0.5, sde=VPSDE(net, shape=()), gamma=3e-2).to(dev)
+    ref = O.gaussian_score(eps_o, O.Schedule(), y, A, 0.5, 3e-2, x, t)
+    assert_close(gs(x.to(dev), t.to(dev)).cpu(), ref, TOL, what='guided lorenz96')
+    # three guided predictor-corrector steps with injected noise (teacher-forced: same z on both sides)
+    steps, corr, tau = 3, 1, 0.25
+    zs = torch.randn(steps * corr, B, L, S)
+    sde = VPSDE(gs, shape=(L, S)).to(dev)
+    sde.initial_noise = x
+    sde.noise_source = lambda i, j: zs[i * corr + j]
+    got = sde.sample((B,), steps=steps, corrections=corr, tau=tau)
+    score_o = lambda xx, tt: O.gaussian_score(eps_o, O.Schedule(), y, A, 0.5, 3e-2, xx, tt)
+    ref_x = O.sample(score_o, O.Schedule(), x, 2, steps, corr, tau, noise=lambda i, j: zs[i * corr + j])
+    assert_close(got.cpu(), ref_x, 5e-4, what='3 guided PC steps (6 evals deep)')
+    sde.noise_source = None
+    # graph replay == eager on the device RNG stream
+    outs = []
+    for use_graph in (False, True):
+        sde.initial_noise = x
+        torch.manual_seed(11)
+        sampler = sde.sampler((B,), steps=8, corrections=1, tau=0.25)
+        if use_graph:
+            sampler.capture()
+        for _ in range(8):
+            sampler.step()
+        outs.append(sampler.result().clone())
+    sde.initial_noise = None
+    assert torch.isfinite(outs[0]).all()
+    assert_close(outs[1].cpu(), outs[0].cpu(), 1e-5, what='graph vs eager')
+
+
+def test_conv_sweep_large_images():
+    """A bounded sample of tests/fuzz/conv_fuzz.py restricted to 128- and 256-pixel images (the configs[3]/[4] levels)."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location(
+        'conv_fuzz', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz', 'conv_fuzz.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    from sda_amd import _lib
+    _lib.load()
+    rng = random.Random(256)
+    failures = []
+    for i in range(24):
+        cfg, msg = fuzz.one_case(rng, torch.device('cuda:0'), 9000 + i, large=True)
+        if msg:
+            failures.append((cfg, msg))
+    assert not failures, failures[:3]

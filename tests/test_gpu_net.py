@@ -94,6 +94,11 @@ def test_golden_guided_score_grad_and_dps(dev):
     gs.group_size = None
     sigma = inner.sigma(g['t_guided'])
     assert_close(((plain - guided) / sigma.to(dev)).cpu(), g['grad_logp'], 2e-3)   # cancellation-limited fixture
+    # d log p / d x itself, against the reference's own autograd.grad output (no cancellation): 1e-4
+    assert_close(gs.log_p_grad(x, t).cpu(), g['grad_logp_ref'], TOL)
+    gs.group_size = 1
+    assert_close(gs.log_p_grad(x, t).cpu(), g['grad_logp_ref'], TOL)
+    gs.group_size = None
     dps = DPSGaussianScore(g['y_obs'], A=_A, sde=inner, zeta=1.0).to(dev)
     assert_close(dps(x, t).cpu(), g['dps'], TOL)
 
@@ -333,6 +338,40 @@ def test_mcscore_short_and_long_trajectories(dev):
         net(torch.randn(1, 4, 2, 16, 16, device=dev), torch.tensor(0.2, device=dev))
 
 
+def test_weight_updates_reach_the_packed_caches(dev):
+    """Packed (forward / VJP / Winograd) weights follow optimiser-style in-place updates and load_state_dict on their own;
+    writes through ``.data`` (EMA swaps) need UNet.invalidate_engine()."""
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    net.to(dev)
+    x, t = g['x'].to(dev), g['t'].to(dev)
+    with torch.no_grad():
+        base = net(x, t)
+        for p in net.parameters():
+            p.mul_(1.5)                              # bumps _version: caches re-key themselves
+        scaled = net(x, t)
+        assert not torch.allclose(scaled, base)
+        net.load_state_dict({k: v.to(dev) for k, v in grp['sd'].items()})
+        assert torch.equal(net(x, t), base)
+        for p in net.parameters():
+            p.data.mul_(1.5)                         # invisible to (data_ptr, _version)
+        net.kernel.network.invalidate_engine()
+        assert torch.equal(net(x, t), scaled)
+
+
+def test_overridden_alpha_is_used_consistently(dev):
+    """A reassigned ``sde.alpha`` must reach the guidance (mu_sigma) as well as the PC loop (mu / sigma)."""
+    from sda_amd.score import VPSDE
+    sde = VPSDE(nn.Identity(), shape=()).to(dev)
+    t = torch.tensor(0.3, device=dev)
+    mu0, sg0 = sde.mu_sigma(t)
+    assert_close(mu0.cpu(), sde.mu(t).cpu(), 1e-6)
+    sde.alpha = lambda tt: 1 - 0.5 * tt
+    mu1, sg1 = sde.mu_sigma(t)
+    assert abs(mu1.item() - 0.85) < 1e-6 and abs(sg1.item() - sde.sigma(t).item()) < 1e-7
+
+
 def test_subvp_schedules_sample(dev):
     from sda_amd.score import SubSubVPSDE, SubVPSDE
     g, grp = load_golden('unet1d_tiny')
@@ -377,6 +416,13 @@ def test_fused_observation_operators_match_autograd(dev):
         r = torch.randn_like(ref)
         gref, = torch.autograd.grad(ref, xo, r)
         assert_close(op.adjoint(r.to(dev), x.shape).cpu(), gref, 1e-5)
+    # the same operators against fixtures produced by the reference's own function bodies (sda/mcs.py:340-375)
+    gold, _ = load_golden('observe_ops')
+    xg_ = gold['x']
+    for name, op in (('coarsen2', Ob.Coarsen(2)), ('coarsen4', Ob.Coarsen(4)), ('vorticity', Ob.Vorticity()),
+                     ('vort_of_coarsen2', Ob.Compose(Ob.Coarsen(2), Ob.Vorticity()))):
+        assert_close(op(xg_.to(dev)).cpu(), gold[name], 1e-5, what=name)
+        assert_close(op.adjoint(gold[name + '_cot'].to(dev), xg_.shape).cpu(), gold[name + '_vjp'], 1e-5, what=name + ' vjp')
     xl = torch.randn(3, 65, 3)
     op = Ob.Subsample((slice(None, None, 8), slice(0, 1)))
     xo = xl.clone().requires_grad_(True)

@@ -68,6 +68,7 @@ def test_guided_and_dps_golden():
     inner = VPSDE(net, shape=())
     gs = GaussianScore(g['y_obs'], A=_A, std=0.5, sde=inner, gamma=1e-2)
     assert_close(gs(g['x'], g['t_guided']), g['guided'], 5e-5)
+    assert_close(gs.log_p_grad(g['x'], g['t_guided']), g['grad_logp_ref'], 1e-4)    # the reference's autograd.grad output
     # streamed in groups of whole trajectories (what a batch too large for HBM gets): same result, shared or per-row y
     gs.group_size = 1
     assert_close(gs(g['x'], g['t_guided']), g['guided'], 5e-5)

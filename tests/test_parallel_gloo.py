@@ -29,9 +29,22 @@ def test_sharded_initial_noise_is_a_slice_of_the_single_process_draw():
     assert not torch.equal(full, P.sharded_initial_noise(7, (4, 3), 6, 0, 1))
 
 
+def _tiny_guided_sde():
+    from sda_amd.score import GaussianScore, VPSDE
+    from tests.util import build_mcscore2d_tiny, load_golden
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    A = lambda x: x[..., ::2, :, ::2, ::2]
+    gs = GaussianScore(g['y_obs'][:1], A=A, std=0.5, sde=VPSDE(net, shape=()), gamma=1e-2)     # one shared observation
+    return VPSDE(gs, shape=(5, 2, 8, 8))
+
+
 def _worker(rank, ws, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
     dist.init_process_group('gloo', rank=rank, world_size=ws)
+    mpatch = pytest.MonkeyPatch()
     try:
         batch, event = 5, (3, 2)
         lo, hi = P.shard_range(batch, rank, ws)
@@ -39,18 +52,42 @@ def _worker(rank, ws, port, ret):
         full = torch.arange(batch * 6, dtype=torch.float32).reshape(batch, *event)
         gathered = P.all_gather_samples(full[lo:hi].clone(), batch)
         assert torch.equal(gathered, full)
-        noise = P.ShardedNoise(batch, event, 11, rank, ws, 'cpu')
-        z0, z1 = noise(0, 0), noise(0, 1)
-        ref = torch.Generator().manual_seed(11)
-        f0, f1 = torch.randn((batch,) + event, generator=ref), torch.randn((batch,) + event, generator=ref)
-        assert torch.equal(z0, f0[lo:hi]) and torch.equal(z1, f1[lo:hi])
         assert P.world() == (rank, ws)
+        # the whole sharded sampler (Python orchestration on the test-only CPU shim; kernels are covered by -m gpu):
+        # guided, one Langevin correction per step; the gathered result equals the single-process run of the same job
+        from tests import cpu_shim
+        cpu_shim.install(mpatch)
+        sde = _tiny_guided_sde()
+        got = P.sample_sharded(sde, 3, steps=2, corrections=1, tau=0.5, seed=4)
+        assert got.shape == (3, 5, 2, 8, 8)
+        alone = P.sample_sharded(sde, 3, steps=2, corrections=1, tau=0.5, seed=4, rank=0, world_size=1)
+        assert torch.equal(got, alone), (got - alone).abs().max()
+        mine = P.sample_sharded(sde, 3, steps=2, corrections=1, tau=0.5, seed=4, gather=False)
+        assert torch.equal(mine, alone[P.shard_range(3, rank, ws)[0]:P.shard_range(3, rank, ws)[1]])
         ret[rank] = True
     finally:
+        mpatch.undo()
         dist.destroy_process_group()
 
 
-def test_gloo_world2_gather_and_noise():
+def test_keyed_noise_rows_do_not_depend_on_the_partition(monkeypatch):
+    from tests import cpu_shim
+    cpu_shim.install(monkeypatch)
+    event = (4, 3)
+    whole = P.KeyedNoise((0, 7), event, 9, 2, 'cpu')
+    for ws in (2, 3):
+        for step, corr in ((0, 0), (3, 1)):
+            parts = [P.KeyedNoise(P.shard_range(7, r, ws), event, 9, 2, 'cpu')(step, corr) for r in range(ws)]
+            assert torch.equal(torch.cat(parts), whole(step, corr))
+    assert not torch.equal(whole(0, 0), whole(0, 1))
+    assert not torch.equal(whole(0, 1), whole(1, 0))
+    # device-side draw index (what a replayed hipGraph reads) == host-side draw index
+    assert torch.equal(whole.draw_dev(torch.tensor([3]), 1), whole(3, 1))
+    z = P.KeyedNoise((0, 64), (1000,), 1, 1, 'cpu')(0, 0)
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
+
+
+def test_gloo_world2_sample_sharded_equals_single_process():
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
     port = 29500 + os.getpid() % 2000
@@ -58,6 +95,6 @@ def test_gloo_world2_gather_and_noise():
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)

@@ -34,8 +34,19 @@ def assert_close(a, b, rtol=1e-4, atol=None, what=''):
     assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
     scale = b.abs().max().item()
     tol = rtol * scale + (atol or 0.0)
-    err = (a - b).abs().max().item()
+    diff = (a - b).abs()
+    err = diff.max().item() if diff.numel() else 0.0
     assert err <= tol, f'{what}: max abs err {err:.3e} > {tol:.3e} (scale {scale:.3e})'
+    # and elementwise: |a - b| <= rtol |b| + atol_e with atol_e = rtol/10 x the tensor scale (not below fp32 round-off of
+    # that scale), i.e. torch.allclose(a, b, rtol, atol_e)
+    atol_e = max(0.1 * rtol, 2e-6) * scale + (atol or 0.0)
+    bound = rtol * b.abs() + atol_e
+    bad = diff > bound
+    if bad.any():
+        worst = (diff - bound).argmax().item()
+        raise AssertionError(f'{what}: {int(bad.sum())} of {bad.numel()} elements outside rtol={rtol:g}, '
+                             f'atol={atol_e:.3e}; worst |a-b|={diff.reshape(-1)[worst]:.3e} '
+                             f'at |b|={b.abs().reshape(-1)[worst]:.3e}')
 
 
 # ---------------------------------------------------------------------------- model builders shared by GPU tests
