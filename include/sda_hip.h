@@ -111,9 +111,17 @@ typedef struct sda_conv_desc {
      *   interleaved quarter of the gradient, instead of convolving a zero-inserted tensor (4x the multiplies). */
     int32_t explicit_pad, pad_h, pad_w;
     int64_t out_sn, out_sc, out_sy, out_sx;
+    /* optional Winograd weights for the one-wave-per-SIMD kernel (sda_pack_conv_weight_wino4: [stage][16][cout/16][64][4],
+     * contraction channels padded to 16).  Taken when the layer is Winograd-eligible as above AND its output height and
+     * width are multiples of 16 (workgroup tile = 96 couts x 16 x 16 pixels of one image); otherwise w_wino / the direct
+     * kernel serve the launch. */
+    const float* w_wino4;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
+/* which kernel family would serve the launch (pure planning, nothing is launched): 2 = one-wave-per-SIMD Winograd
+ * (w_wino4), 1 = Winograd (w_wino), 0 = direct implicit GEMM; <0 error */
+int sda_conv_igemm_path(const sda_conv_desc* d);
 /* bytes of dynamic LDS the launch would use (or <0 error), for planning / tests */
 int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);
 
@@ -129,6 +137,10 @@ int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int 
 /* Winograd-domain weights U[4*xi+nu][k][m] = (G g G^T)[xi][nu] for 3x3 filters; transpose / cin_keep as above. */
 int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                               int m_pad, void* stream);
+
+/* U for the one-wave-per-SIMD Winograd kernel: dst[k_pad/16][16][m_pad/16][64][4], k_pad % 16 == 0, m_pad % 96 == 0. */
+int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
+                               int m_pad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * zuko.nn.LayerNorm(dim=-(spatial+1)) statistics: per pixel, over channels, of (x + mod).

@@ -51,6 +51,7 @@ class ConvDesc(Structure):
         ('w_wino', c_fp),
         ('explicit_pad', c_int32), ('pad_h', c_int32), ('pad_w', c_int32),
         ('out_sn', c_int64), ('out_sc', c_int64), ('out_sy', c_int64), ('out_sx', c_int64),
+        ('w_wino4', c_fp),
     ]
 
 
@@ -58,9 +59,11 @@ class ConvDesc(Structure):
 SIGNATURES = {
     'sda_abi_version': (c_int, []),
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
+    'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_pack_conv_weight_wino': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
+    'sda_pack_conv_weight_wino4': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_ln_stats': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_float, c_int, c_fp, c_fp, c_void_p]),
     'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
     'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,

@@ -15,8 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 ARCH = 'gfx950'
-SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip', 'noise.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'conv_wino4.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip', 'noise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# extra compile flags (e.g. SDA_EXTRA_HIPCC_FLAGS=-DSDA_W4_VARIANTS builds the tuning variants tools/wino4_check.py compares)
+EXTRA_FLAGS = os.environ.get('SDA_EXTRA_HIPCC_FLAGS', '').split()
 CONV_PARTS = 4                                       # see SDA_CONV_PART in csrc/conv_igemm.hip
 
 
@@ -51,7 +53,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(LIBDIR, src.replace('.hip', suffix + '.o'))
         objs.append(obj)
         if force or _newer(obj, [sp] + hdrs):
-            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off'] + flags + ['-c', sp, '-o', obj]
+            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off'] + flags + EXTRA_FLAGS + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src + suffix, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -788,9 +788,14 @@ static int conv_launch_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t 
 // Winograd F(2x2,3x3) path (conv_wino.hip)
 struct WinoGeom;
 int sda_wino_try(const sda_conv_desc* d, hipStream_t stream);   // SDA_E_UNSUPPORTED -> use the direct kernel
+int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream);  // one-wave-per-SIMD Winograd (conv_wino4.hip)
 
 extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (d && d->w_wino4) {
+        const int rc4 = sda_wino4_try(d, s);
+        if (rc4 != SDA_E_UNSUPPORTED) return rc4;
+    }
     if (d && d->w_wino) {
         const int rcw = sda_wino_try(d, s);
         if (rcw != SDA_E_UNSUPPORTED) return rcw;
@@ -830,6 +835,17 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         case 3: return conv_launch_m<3>(d, g, s);
         default: return conv_launch_m<4>(d, g, s);
     }
+}
+
+// which kernel family sda_conv_igemm would serve this launch with: 2 one-wave-per-SIMD Winograd, 1 Winograd, 0 direct
+struct Wino4Geom;
+int sda_wino4_path(const sda_conv_desc* d);
+int sda_wino_path(const sda_conv_desc* d);
+extern "C" int sda_conv_igemm_path(const sda_conv_desc* d) {
+    if (!d) return SDA_E_BADARG;
+    if (d->w_wino4 && sda_wino4_path(d)) return 2;
+    if (d->w_wino && sda_wino_path(d)) return 1;
+    return 0;
 }
 
 extern "C" int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d) {

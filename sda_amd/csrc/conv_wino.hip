@@ -448,9 +448,18 @@ int sda_wino_launch(const sda_conv_desc* d, const WinoGeom& g, hipStream_t strea
     return 2 * g.sh <= 6 * 64 ? wino_launch_nh<6>(d, g, grid, stream) : wino_launch_nh<9>(d, g, grid, stream);
 }
 
-int sda_wino_try(const sda_conv_desc* d, hipStream_t stream) {
+static bool wino_disabled() {
     static const bool off = getenv("SDA_CONV_WINO") && atoi(getenv("SDA_CONV_WINO")) == 0;
-    if (off) return SDA_E_UNSUPPORTED;
+    return off;
+}
+
+int sda_wino_path(const sda_conv_desc* d) {
+    WinoGeom g;
+    return !wino_disabled() && sda_wino_plan(d, &g) == SDA_OK;
+}
+
+int sda_wino_try(const sda_conv_desc* d, hipStream_t stream) {
+    if (wino_disabled()) return SDA_E_UNSUPPORTED;
     WinoGeom g;
     const int rc = sda_wino_plan(d, &g);
     if (rc != SDA_OK) return rc;

@@ -46,10 +46,11 @@ static inline int sda_raise_dyn_lds(const void* kern, int lds, bool (&done)[SDA_
 // ---- activations (sda/utils.py:19-25) and their derivatives w.r.t. the pre-activation ----
 // sigmoid: on the device exp and the reciprocal are the hardware v_exp_f32 / v_rcp_f32 (1 ulp each; measured
 // end-to-end error of SiLU ~1e-7 relative) -- the accurate libm sequences cost ~30 VALU per element, which made the
-// conv loaders VALU-bound.  The host build (emulator) keeps libm.
+// conv loaders VALU-bound (and __frcp_rn is a correctly rounded division: a 10-instruction v_div_scale / fmas / fixup
+// sequence, not v_rcp_f32).  The host build (emulator) keeps libm.
 __host__ __device__ __forceinline__ float sda_sigmoid(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __frcp_rn(1.0f + __expf(-v));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 #else
     return 1.0f / (1.0f + expf(-v));
 #endif

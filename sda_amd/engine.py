@@ -167,8 +167,10 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        dact_z_ptr=None if dact_z is None else dact_z.data_ptr(), act_d=act_d,
                        res_ptr=None if res is None else res.data_ptr(),
                        w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr(),
+                       w_wino4_ptr=None if getattr(pk, 'wino4', None) is None else pk.wino4.data_ptr(),
                        pad=pad, out_strides=out_strides)
     ops.conv_igemm(d)
+    return d
 
 
 class _Block:

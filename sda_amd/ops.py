@@ -15,6 +15,7 @@ from ._lib import ACT_IDS, ConvDesc
 CONV_CK = 8          # K-stage depth of conv_igemm (SDA_CONV_CK)
 import os as _os
 WINOGRAD = _os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3) for eligible 3x3 layers
+WINOGRAD4 = _os.environ.get('SDA_CONV_WINO4', '1') != '0'    # ... its one-wave-per-SIMD kernel where images are multiples of 16
 
 
 def _dev(*tensors):
@@ -58,7 +59,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
                    stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
                    ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
                    act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None,
-                   pad=None, out_strides=(0, 0, 0, 0)) -> ConvDesc:
+                   w_wino4_ptr=None, pad=None, out_strides=(0, 0, 0, 0)) -> ConvDesc:
     d = ConvDesc()
     d.x = x_ptr
     d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
@@ -78,6 +79,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     d.res = res_ptr
     d.mt = mt
     d.w_wino = w_wino_ptr
+    d.w_wino4 = w_wino4_ptr
     d.explicit_pad = 0 if pad is None else 1
     d.pad_h, d.pad_w = (0, 0) if pad is None else pad
     d.out_sn, d.out_sc, d.out_sy, d.out_sx = out_strides
@@ -90,7 +92,7 @@ class ConvProfile:
     (2 * n * out-pixels * cout * cin * taps over the real channels; zero-inserted taps are not counted)."""
 
     def __init__(self):
-        self.records = []          # (start_event, stop_event, flops)
+        self.records = []          # (start_event, stop_event, flops, family)
 
     def flops(self, d: ConvDesc) -> float:
         pixels = d.ho * d.wo / (d.zins_h * d.zins_w)
@@ -98,9 +100,16 @@ class ConvProfile:
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        return dict(launches=len(self.records), total_ms=ms, total_flops=fl)
+        out = dict(launches=len(self.records), total_ms=0.0, total_flops=0.0, families={})
+        for a, b, f, fam in self.records:
+            ms = a.elapsed_time(b)
+            out['total_ms'] += ms
+            out['total_flops'] += f
+            r = out['families'].setdefault(fam, dict(launches=0, ms=0.0, flops=0.0))
+            r['launches'] += 1
+            r['ms'] += ms
+            r['flops'] += f
+        return out
 
 
 conv_profile: Optional[ConvProfile] = None
@@ -114,9 +123,14 @@ def conv_igemm(desc: ConvDesc):
         e0.record()
         _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
         e1.record()
-        prof.records.append((e0, e1, prof.flops(desc)))
+        prof.records.append((e0, e1, prof.flops(desc), ('direct', 'wino', 'wino4')[max(0, conv_path(desc))]))
         return
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
+
+
+def conv_path(desc: ConvDesc) -> int:
+    """Kernel family that would serve the launch: 2 one-wave-per-SIMD Winograd, 1 Winograd, 0 direct implicit GEMM."""
+    return _lib.load().sda_conv_igemm_path(ctypes.byref(desc))
 
 
 def pack_conv_weight(w: Tensor, cout: int, cin: int, kh: int, kw: int, transpose: bool, keep: int, dst: Tensor,
@@ -153,6 +167,14 @@ class PackedConv:
             _lib.check(_lib.load().sda_pack_conv_weight_wino(w.data_ptr(), cout, cin, int(transpose), keep,
                                                              self.wino.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino')
+        # ... and the packing of the one-wave-per-SIMD Winograd kernel (contraction channels padded to 16)
+        self.wino4 = None
+        if WINOGRAD4 and self.wino is not None:
+            k16 = round_up(self.k_real, 16)
+            self.wino4 = torch.empty(16 * k16 * self.m_pad, device=w.device, dtype=torch.float32)
+            _lib.check(_lib.load().sda_pack_conv_weight_wino4(w.data_ptr(), cout, cin, int(transpose), keep,
+                                                              self.wino4.data_ptr(), k16, self.m_pad, _stream()),
+                       'sda_pack_conv_weight_wino4')
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm pieces

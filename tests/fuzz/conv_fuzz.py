@@ -29,9 +29,9 @@ def ref_conv(x, w, b, stride, circular, kh, kw):
 
 def one_case(rng, dev, idx, large=False):
     """large=True: images of 128 / 256 pixels per side (the configs[3] / [4] U-Net levels), one image, fewer channels."""
-    mode = rng.choice(['plain', 'plain', 'wino', 'wino', 'stride2', 'up', 'zins', 'oned'])
+    mode = rng.choice(['plain', 'plain', 'wino', 'wino', 'wino4', 'wino4', 'stride2', 'up', 'zins', 'oned'])
     if large and mode == 'oned':
-        mode = 'wino'
+        mode = 'wino4'
     circular = rng.random() < 0.6
     cfg = dict(mode=mode, circular=circular)
     if mode == 'wino':
@@ -40,6 +40,16 @@ def one_case(rng, dev, idx, large=False):
         h, w_ = rng.choice([2, 4, 6, 8, 16, 18, 32, 64]), rng.choice([2, 4, 8, 10, 16, 32, 64])
         if large:
             cin, cout = rng.choice([8, 24, 96]), 96
+            h, w_ = rng.choice([128, 256]), rng.choice([128, 256])
+        kh = kw = 3
+    elif mode == 'wino4':
+        # shapes the one-wave-per-SIMD Winograd kernel tiles (height % 8 == 0, width % 16 == 0, cout % 96 == 0), incl. partial
+        # last K-stages (cin % 16 != 0), the upsampling tails and both paddings
+        cin = rng.choice([3, 8, 16, 24, 40, 96, 100, 192])
+        cout = rng.choice([96, 96, 192])
+        h, w_ = rng.choice([8, 16, 24, 32, 64]), rng.choice([16, 32, 48, 64])
+        if large:
+            cin, cout = rng.choice([16, 24, 96]), 96
             h, w_ = rng.choice([128, 256]), rng.choice([128, 256])
         kh = kw = 3
     elif mode == 'oned':
@@ -69,6 +79,9 @@ def one_case(rng, dev, idx, large=False):
     use_ln = rng.random() < 0.5 and cin > 1
     per_image = rng.random() < 0.5
     act = rng.choice([None, None, 'SiLU', 'GELU', 'ELU', 'ReLU', 'SELU'])
+    if mode == 'wino4':
+        act = rng.choice([None, 'SiLU', 'SiLU', 'GELU'])          # (GELU: falls back to the first-generation kernel)
+        per_image = False                                         # (per-image modulation: direct kernel)
     cfg.update(mod=use_mod, ln=use_ln, per_image=per_image, act=act, bias=bias is not None)
     if use_mod:
         mod = torch.randn(n if per_image else 1, cin, generator=g)
@@ -91,6 +104,16 @@ def one_case(rng, dev, idx, large=False):
             circular = cfg['circular'] = False
         opts['stride'] = stride
         ref = ref_conv(xin, wgt.double(), None if bias is None else bias.double(), 2, circular, kh, kw)
+    elif mode == 'wino4' and rng.random() < 0.3:
+        cfg['up'] = True
+        opts['up'] = (2, 2)
+        h2, w2 = h // 2, w_ // 2
+        x = x[:, :, :h2, :w2].contiguous()
+        xin = xin[:, :, :h2, :w2]
+        if use_ln:
+            opts['ln'] = tuple(t.reshape(n, h, w_)[:, :h2, :w2].reshape(n, -1).contiguous() for t in opts['ln'])
+        xin = xin.repeat_interleave(2, -1).repeat_interleave(2, -2)
+        ref = ref_conv(xin, wgt.double(), None if bias is None else bias.double(), 1, circular, kh, kw)
     elif mode == 'up':
         uh = 1 if h == 1 else 2
         opts['up'] = (uh, 2)
@@ -140,9 +163,12 @@ def one_case(rng, dev, idx, large=False):
         else:
             dopts[k] = v
     try:
-        launch_conv(pk, planar_source(xd), out, ho, wo, circular=circular, bias=pk.bias, **dopts)
+        desc = launch_conv(pk, planar_source(xd), out, ho, wo, circular=circular, bias=pk.bias, **dopts)
     except Exception as e:  # noqa: BLE001
         return cfg, f'EXCEPTION {type(e).__name__}: {e}'
+    cfg['path'] = ops.conv_path(desc)
+    if mode == 'wino4' and act in (None, 'SiLU') and ops.WINOGRAD4 and ops.WINOGRAD and cfg['path'] != 2:
+        return cfg, f'expected the one-wave-per-SIMD Winograd kernel, got path {cfg["path"]}'
     torch.cuda.synchronize()
     got = out.cpu().double()
     if torch.isnan(got).any():

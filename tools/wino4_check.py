@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Correctness + speed of the one-wave-per-SIMD Winograd kernel (conv_wino4.hip) on the GPU box.
+
+    python tools/wino4_check.py [--cases 120] [--bench]
+
+1. structured cases (every loader / epilogue fusion, both paddings, upsampling, partial K-stages, several cout tiles,
+   batches that leave workgroups with 0 / 1 / many tiles) + a randomised sweep, each against torch float64;
+2. --bench: the K64 layer shapes at 64^2 and 256^2 with both Winograd kernels (SDA_CONV_WINO4 toggled per process is not
+   possible, so the old kernel is timed by passing descriptors without w_wino4)."""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from sda_amd import ops  # noqa: E402
+from sda_amd.engine import launch_conv, planar_source  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def ref_conv(x, w, b, circular):
+    xp = F.pad(x, (1, 1, 1, 1), mode='circular' if circular else 'constant')
+    return F.conv2d(xp, w, b)
+
+
+def run_case(n, cin, cout, h, w_, circular, mod, ln, silu, up, dact, res, bias, seed, transpose=False):
+    g = torch.Generator().manual_seed(seed)
+    hs, ws = (h // 2, w_ // 2) if up else (h, w_)
+    x = torch.randn(n, cin, hs, ws, generator=g) * 1.3 + 0.1
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xin, opts = x.double(), {}
+    if mod:
+        m = torch.randn(1, cin, generator=g)
+        opts['mod'] = m
+        xin = xin + m.double()[:, :, None, None]
+    if ln:
+        var, mean = torch.var_mean(xin, dim=1, unbiased=True, keepdim=True)
+        rstd = 1 / torch.sqrt(var + 1e-5)
+        opts['ln'] = (mean.float().reshape(n, -1), rstd.float().reshape(n, -1))
+        xin = (xin - mean) * rstd
+    if silu:
+        opts['act_in'] = 1
+        xin = F.silu(xin)
+    if up:
+        opts['up'] = (2, 2)
+        xin = xin.repeat_interleave(2, -1).repeat_interleave(2, -2)
+    ref = ref_conv(xin, wgt.double(), None if b is None else b.double(), circular)
+    if dact:
+        z = torch.randn(ref.shape, generator=g)
+        zz = z.double().requires_grad_(True)
+        dz, = torch.autograd.grad(F.silu(zz).sum(), zz)
+        ref = ref * dz
+        opts['dact_z'], opts['act_d'] = z, 1
+    if res:
+        r = torch.randn(ref.shape, generator=g)
+        ref = ref + r.double()
+        opts['res'] = r
+    pk = ops.PackedConv(wgt.to(dev), None if b is None else b.to(dev))
+    out = torch.full((n, cout, h, w_), float('nan'), device=dev)
+    dopts = {}
+    for k, v in opts.items():
+        dopts[k] = tuple(t.to(dev).contiguous() for t in v) if k == 'ln' else (v.to(dev).contiguous() if torch.is_tensor(v) else v)
+    desc = launch_conv(pk, planar_source(x.to(dev)), out, h, w_, circular=circular, bias=pk.bias, **dopts)
+    torch.cuda.synchronize()
+    path = ops.conv_path(desc)
+    got = out.cpu().double()
+    nan = int(torch.isnan(got).sum())
+    scale = ref.abs().max().item() + 1e-30
+    diff = (got - ref).abs()
+    diff[torch.isnan(diff)] = float('inf')
+    err = diff.max().item() / scale
+    info = ''
+    if err > 1e-4:
+        bad = (diff > 1e-4 * scale)
+        idx = bad.nonzero()
+        info = (f' bad={int(bad.sum())}/{bad.numel()} nan={nan} first={idx[0].tolist()} last={idx[-1].tolist()} '
+                f'bad per image={bad.flatten(1).sum(1).tolist()[:6]} per cout(first 12)={bad.sum((0, 2, 3)).tolist()[:12]} '
+                f'rows={bad.sum((0, 1, 3)).tolist()[:20]} cols={bad.sum((0, 1, 2)).tolist()[:20]}')
+    return path, err, info
+
+
+def structured():
+    cases = []
+    base = dict(n=2, cin=16, cout=96, h=8, w_=16, circular=True, mod=False, ln=False, silu=False, up=False, dact=False,
+                res=False, bias=False)
+    def add(**kw):
+        c = dict(base); c.update(kw); cases.append(c)
+    add()
+    add(circular=False)
+    add(bias=True)
+    add(cin=32)
+    add(cin=96, h=16, w_=32)
+    add(cin=24)                      # partial last stage
+    add(cin=3)
+    add(cout=192)
+    add(cout=384, cin=48)
+    add(n=1, h=64, w_=64, cin=96)
+    add(n=7, h=16, w_=16, cin=40, circular=False)
+    add(mod=True)
+    add(ln=True)
+    add(mod=True, ln=True, cin=96, h=16, w_=32)
+    add(silu=True, res=True, cin=96, h=16, w_=32)
+    add(dact=True, bias=True)
+    add(res=True, dact=True, bias=True, cin=32, circular=False)
+    add(up=True, ln=True, cin=32, h=16, w_=32)
+    add(up=True, ln=True, cin=192, cout=96, h=32, w_=32, circular=False)
+    add(n=300, cin=16, h=8, w_=16)   # more tiles than workgroups, uneven split
+    add(n=33, cin=96, cout=192, h=16, w_=16, mod=True, ln=True)
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=120)
+    ap.add_argument('--bench', action='store_true')
+    ap.add_argument('--variants', default='', help='comma list of SDA_W4_VAR values to time on the plain layers (needs a -DSDA_W4_VARIANTS build)')
+    ap.add_argument('--skip-check', action='store_true')
+    args = ap.parse_args()
+    if args.variants:
+        variants([int(v) for v in args.variants.split(',')])
+    if args.skip_check:
+        if args.bench:
+            bench()
+        return
+    bad = 0
+    for i, c in enumerate(structured()):
+        path, err, info = run_case(seed=100 + i, **c)
+        ok = err <= 1e-4 and path == 2
+        bad += not ok
+        print(f'{"ok  " if ok else "FAIL"} struct {i:2d} path={path} err={err:.2e} {c if not ok else ""}{info}', flush=True)
+    rng = random.Random(0)
+    worst = 0.0
+    for i in range(args.cases):
+        c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 16, 24, 40, 96, 100, 192, 384]),
+                 cout=rng.choice([96, 96, 192, 384]), h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]),
+                 circular=rng.random() < 0.6, mod=rng.random() < 0.4, ln=rng.random() < 0.4, silu=rng.random() < 0.4,
+                 up=rng.random() < 0.25, dact=rng.random() < 0.3, res=rng.random() < 0.4, bias=rng.random() < 0.6)
+        if c['cin'] * c['h'] * c['w_'] * c['n'] > 4e6:
+            c['n'] = 1
+        path, err, info = run_case(seed=1000 + i, **c)
+        ok = err <= 1e-4 and path == 2
+        worst = max(worst, err if err == err else 1.0)
+        if not ok:
+            bad += 1
+            print(f'FAIL rand {i} path={path} err={err:.2e} {c}{info}', flush=True)
+    print(f'random sweep: {args.cases} cases, worst rel err {worst:.2e}; total failures {bad}', flush=True)
+    if args.bench:
+        bench()
+    sys.exit(1 if bad else 0)
+
+
+def variants(vs):
+    print('--- variants on plain layers (algorithmic TFLOP/s | mfma util)')
+    for name, cin, cout, h, n in (('96->96 @64', 96, 96, 64, 896), ('192->192 @32', 192, 192, 32, 896),
+                                  ('384->384 @16', 384, 384, 16, 896), ('384->384 @64', 384, 384, 64, 60)):
+        x = torch.randn(n, cin, h, h, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        pk = ops.PackedConv(w, None)
+        out = torch.empty(n, cout, h, h, device=dev)
+        row = []
+        for v in vs:
+            os.environ['SDA_W4_VAR'] = str(v)
+            launch_conv(pk, planar_source(x), out, h, h, circular=True)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    launch_conv(pk, planar_source(x), out, h, h, circular=True)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 4)
+            tf = 2.0 * n * h * h * cout * cin * 9 / best / 1e9
+            row.append(f'v{v}: {tf:6.1f}|{tf / 2.25 / 157.3:.2f}')
+        os.environ['SDA_W4_VAR'] = '0'
+        print(f'{name:16s} ' + '  '.join(row), flush=True)
+
+
+def bench():
+    print('--- layer bench (algorithmic TFLOP/s; issued = /2.25)')
+    for S, n in ((64, 896), (256, 60)):
+        layers = [('blk0 96->96 plain', 96, 96, S, {}), ('blk0 96->96 mod+LN', 96, 96, S, dict(ln=True, mod=True)),
+                  ('blk0 96->96 silu+res', 96, 96, S, dict(silu=True, res=True)), ('blk0^T 96->96 dact', 96, 96, S, dict(dact=True)),
+                  ('blk1 192->192 mod+LN', 192, 192, S // 2, dict(ln=True, mod=True)),
+                  ('blk2 384->384 mod+LN', 384, 384, S // 4, dict(ln=True, mod=True)),
+                  ('tail1 192->96 up+LN', 192, 96, S, dict(ln=True, up=True)), ('tail2 384->192 up+LN', 384, 192, S // 2, dict(ln=True, up=True))]
+        for name, cin, cout, h, fz in layers:
+            hs = h // 2 if fz.get('up') else h
+            x = torch.randn(n, cin, hs, hs, device=dev)
+            w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+            b = torch.randn(cout, device=dev)
+            pk = ops.PackedConv(w, b)
+            out = torch.empty(n, cout, h, h, device=dev)
+            kw = dict(circular=True, bias=pk.bias)
+            if fz.get('up'):
+                kw['up'] = (2, 2)
+            if fz.get('ln'):
+                kw['ln'] = (torch.zeros(n * hs * hs, device=dev), torch.ones(n * hs * hs, device=dev))
+            if fz.get('mod'):
+                kw['mod'] = torch.randn(1, cin, device=dev)
+            if fz.get('silu'):
+                kw['act_in'] = 1
+            if fz.get('res'):
+                kw['res'] = torch.randn_like(out)
+            if fz.get('dact'):
+                kw.update(dact_z=torch.randn_like(out), act_d=1)
+            res = []
+            for use4 in (True, False):
+                keep = pk.wino4
+                if not use4:
+                    pk.wino4 = None
+                d = launch_conv(pk, planar_source(x), out, h, h, **kw)
+                path = ops.conv_path(d)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    launch_conv(pk, planar_source(x), out, h, h, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 5
+                pk.wino4 = keep
+                flops = 2.0 * n * h * h * cout * cin * 9
+                res.append((path, ms, flops / ms / 1e9))
+            print(f'S={S:3d} {name:24s} ' + '   '.join(f'path{p}: {ms:7.3f} ms {tf:6.1f} TF (mfma util {tf / 2.25 / 157.3:.2f})' for p, ms, tf in res), flush=True)
+
+
+if __name__ == '__main__':
+    main()
