@@ -111,10 +111,10 @@ typedef struct sda_conv_desc {
      *   interleaved quarter of the gradient, instead of convolving a zero-inserted tensor (4x the multiplies). */
     int32_t explicit_pad, pad_h, pad_w;
     int64_t out_sn, out_sc, out_sy, out_sx;
-    /* optional Winograd weights for the one-wave-per-SIMD kernel (sda_pack_conv_weight_wino4: [stage][16][cout/16][64][4],
-     * contraction channels padded to 16).  Taken when the layer is Winograd-eligible as above AND its output height and
-     * width are multiples of 16 (workgroup tile = 96 couts x 16 x 16 pixels of one image); otherwise w_wino / the direct
-     * kernel serve the launch. */
+    /* optional Winograd weights for the second-generation kernel (sda_pack_conv_weight_wino4: [cin_pad/8][16][cout/16][64][2],
+     * U fragments in MFMA lane order).  Taken when the layer is Winograd-eligible as above, its output height is a multiple
+     * of 8 and its width of 16 (workgroup tile = 96 couts x 16 x 8 pixels of one image), and the loader fusions are one of
+     * none / SiLU / LayerNorm / modulation + LayerNorm; otherwise w_wino / the direct kernel serve the launch. */
     const float* w_wino4;
 } sda_conv_desc;
 
@@ -138,7 +138,7 @@ int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int 
 int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                               int m_pad, void* stream);
 
-/* U for the one-wave-per-SIMD Winograd kernel: dst[k_pad/16][16][m_pad/16][64][4], k_pad % 16 == 0, m_pad % 96 == 0. */
+/* U for the second-generation Winograd kernel: dst[k_pad/8][16][m_pad/16][64][2], k_pad % 8 == 0, m_pad % 96 == 0. */
 int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                                int m_pad, void* stream);
 

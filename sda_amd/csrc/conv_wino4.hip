@@ -1,36 +1,35 @@
-// Winograd F(2x2, 3x3) convolution, second generation: ONE wavefront per SIMD (4 waves x 512 registers per workgroup), every
-// wave stages + transforms + multiplies in one software-pipelined instruction stream, and every wave owns ALL 16
-// transform-domain positions of its output fragment, so the inverse transform is lane-local (no LDS exchange, no epilogue
-// barriers).  Same arithmetic as conv_wino.hip (which stays as the fallback for shapes this kernel does not tile):
+// Winograd F(2x2, 3x3) convolution, second generation.  Same arithmetic as conv_wino.hip (which stays as the fallback
+// for shapes this kernel does not tile):
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A         d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //   U[p][ci][co] = (G g G^T)[xi][nu],  p = 4 xi + nu        (sda_pack_conv_weight_wino4, once per layer)
 //   V[p][ci][t]  = (B^T d B)[xi][nu]   of tile t            (computed here, into LDS)
 //   M[p][co][t]  = sum_ci U[p][ci][co] V[p][ci][t]          (16 GEMMs on v_mfma_f32_16x16x4_f32: exact fp32)
 //
-// Workgroup tile = 96 couts x (8 x 4 Winograd tiles = 16 x 8 output pixels of one image); K-stage = 16 input channels.
-//   * wave (wm, wn) owns couts 48 wm .. +48 (three 16-row MFMA fragments) x Winograd tiles 16 wn .. +16 for all 16
-//     positions: 16 x 3 accumulator fragments = 192 registers (the AGPR half of the file; the VGPR half is free for the
-//     operand streams and the producer work).  Per (position, 4-channel k-step): 3 A + 1 B operand registers, 3 MFMAs.
-//   * A operand (U) never touches LDS: it is packed [stage][p][cout fragment][lane][k-step] and streamed L2 -> registers,
-//     one fully coalesced dwordx4 per (position, cout fragment) and stage, one position ahead of its MFMAs.
-//   * B operand (V): LDS [p][kq][tile][k4], two 32 KiB stage buffers.  Wave w produces the four channels 4 w .. 4 w + 3 of
-//     a stage (kq = w): it stages their 18 x 10 halo into a wave-private LDS area with row-contiguous loads (each input
-//     pixel fetched once; the loader fusions -- modulation, LayerNorm, activation, nearest upsample, circular / zero
-//     padding -- applied once per pixel), then lane (t, h) transforms the patches of tile t for channels 2 h, 2 h + 1 and
-//     writes V[p][w][t][2 h .. 2 h + 1] (ds_write_b64); consumers read one conflict-free ds_read_b128 per position.
-//   * the stage pipeline runs across tiles: while stage q is multiplied, stage q + 1 (possibly the next tile's first) is
-//     committed and transformed and the global loads of stage q + 2 are issued, all spread over the 16 position steps of
-//     stage q in the shadow of its 192 MFMAs (32 cycles each); one workgroup barrier per stage (the four waves are
-//     symmetric, so they arrive together).  The producer is stateless across tiles: halo addresses, liveness and the
-//     LayerNorm statistics of a stage are derived when its loads are issued and travel with them in registers.
-//   * epilogue: A^T M A in registers, bias / act'(z) / residual fused, float2 row stores.
+// What the design is built around (tools/mfma_shadow_gen.py, profiles/r02_mfma_shadow.txt): the fp32 MFMA runs on the
+// vector datapath, so an instruction of the SAME wave issued between two MFMAs is not hidden -- a VALU costs 4 cycles plus
+// ~10 for the switch, a global load ~18, an LDS read ~0.3-5, scalar instructions nothing -- while the instructions of a
+// SIBLING wave on the same SIMD cost the MFMA wave nothing at all.  Hence:
+//   * waves 0-3 (one per SIMD) are pure multiply streams: MFMA + ds_read + scalar bookkeeping, nothing else in the loop.
+//     BOTH operands come from LDS.  Each owns ALL 16 transform-domain positions of a 48-cout x 16-tile fragment (3 x 1
+//     MFMA fragments x 16 positions = 192 accumulators, the AGPR half of its 256 registers), so the inverse transform
+//     A^T M A is lane-local: no LDS exchange, no epilogue barriers.
+//   * waves 4-7 (their siblings) do everything else for the NEXT K-stage while the current one is multiplied: LDS-DMA of the
+//     stage's U slab (global_load_lds_dwordx4: 48 KiB, no registers), the input halo (row-contiguous loads, every pixel
+//     once, loader fusions -- modulation, LayerNorm, SiLU, nearest upsample, circular / zero padding -- applied once per
+//     pixel), the B^T d B transform and the V writes; and they issue the halo loads of the stage after that.
+//   * workgroup tile = 96 couts x (8 x 4 Winograd tiles = 16 x 8 output pixels of one image); K-stage = 8 input channels;
+//     two (U 48 KiB + V 24 KiB) stage buffers; one workgroup barrier per stage.  The stage pipeline runs across tiles (the
+//     producers are stateless: a stage's halo addresses / liveness / LayerNorm statistics are derived when its loads are
+//     issued and travel with them in registers), so only the epilogue itself is not covered by MFMAs.
+//   * LDS layouts are conflict free: U [p][cout fragment][lane][k4] (lane-linear: what the DMA writes and what ds_read_b64
+//     reads), V [p][kq][tile][k4] with a 32-bank skew between the kq planes.
 // Roofline: fp32 matrix pipe, 157.3 TFLOP/s; issued flops = algorithmic (direct-convolution) flops / 2.25.
 #include "sda_common.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
-#define W4_CK 16
+#define W4_CK 8
 #define W4_BM 96
 #define W4_T 32                        // 8 x 4 Winograd tiles
 #define W4_HC 18                       // halo columns (16 pixels + 2)
@@ -39,14 +38,18 @@
                                        // 32-lane half reads with ds_read_b64 cover the 64 banks exactly once
 #define W4_HPLANE (W4_HRW * W4_HS)     // 240 floats per channel
 #define W4_NSLOT 3                     // ceil(18 * 10 / 64) halo positions per lane and channel
-#define W4_PSTR (4 * W4_T * 4)         // floats per position in a V buffer: [kq 4][t 32][k4 4]
-#define W4_VBUF (16 * W4_PSTR)         // 8192 floats = 32 KiB: V of one stage
-#define W4_LDS_BYTES ((2 * W4_VBUF + 4 * 4 * W4_HPLANE) * 4)
+#define W4_UP (6 * 64 * 2)             // floats per position in a U buffer: [cout fragment 6][lane 64][k4 2]
+#define W4_UBUF (16 * W4_UP)           // 12288 floats = 48 KiB
+#define W4_VKQ 96                      // floats per kq plane of V: [tile 32][k4 2] + 32 floats of skew (ds_read_b64 banks)
+#define W4_VP (4 * W4_VKQ)             // floats per position in a V buffer
+#define W4_VBUF (16 * W4_VP)           // 6144 floats = 24 KiB
+#define W4_LDS_BYTES ((2 * W4_UBUF + 2 * W4_VBUF + 4 * 2 * W4_HPLANE) * 4)
 
 struct Wino4Geom {
     int cin, hv, wv;                   // real input channels, virtual (= output) image size
     int bx_n, by_n;                    // 16 x 8-pixel blocks per image
     int n_ct, grid, nstage, debug, mtiles;
+    long long* trace;                  // (tooling builds only) per-wave phase cycle sums
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -68,7 +71,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
         return SDA_E_UNSUPPORTED;
     if (d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx) return SDA_E_UNSUPPORTED;
-    if (d->cctx > 0 || d->cout % W4_BM || d->cout_pad != d->cout) return SDA_E_UNSUPPORTED;
+    if (d->cctx > 0 || d->cout % W4_BM || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
     if ((d->ho & 7) || (d->wo & 15) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
     if (d->mod && d->mod_sn != 0) return SDA_E_UNSUPPORTED;
@@ -90,9 +93,10 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     const int64_t total = (int64_t)g->bx_n * g->by_n * d->n * g->n_ct;
     if (total > 0x3fffffffLL || total < 1) return SDA_E_UNSUPPORTED;
     g->grid = (int)total;
-    g->nstage = (d->cx + W4_CK - 1) / W4_CK;
+    g->nstage = d->cin_pad / W4_CK;
     if ((int64_t)g->nstage * total > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+    g->trace = nullptr;
     return SDA_OK;
 }
 
@@ -108,22 +112,55 @@ __device__ __forceinline__ W4Tile w4_decode(const Wino4Geom& g, int tile) {
     return t;
 }
 
-// MOD / LN / SILU: the loader fusions of the launch (modulation add, LayerNorm, SiLU), compile-time so that the stage body is
-// ONE basic block: a runtime branch inside it would fence the producer work off from the MFMAs it is meant to hide behind
-// VAR: tuning / ablation variant (0 = the shipped schedule; others exist only for tools/wino4_check.py --variants)
+// stage cursor (all scalar): stage in tile + the decoded tile.  Stepping to the next stage / tile is an increment with
+// carries: consecutive tiles of a workgroup are the cout tiles of one block, then the next block along the row.
+struct W4Cur { int st, ct, bx, by, n; };
+__device__ __forceinline__ void w4_advance(const Wino4Geom& g, W4Cur& c) {
+    const bool t_next = c.st + 1 == g.nstage;
+    c.st = t_next ? 0 : c.st + 1;
+    const bool b_next = t_next && c.ct + 1 == g.n_ct;
+    c.ct = t_next ? (b_next ? 0 : c.ct + 1) : c.ct;
+    const bool y_next = b_next && c.bx + 1 == g.bx_n;
+    c.bx = b_next ? (y_next ? 0 : c.bx + 1) : c.bx;
+    const bool n_next = y_next && c.by + 1 == g.by_n;
+    c.by = y_next ? (n_next ? 0 : c.by + 1) : c.by;
+    c.n += n_next ? 1 : 0;
+}
+
+// phase stamps of the tracing variant (VAR == 11): T(k) adds the cycles since the previous stamp to phase k
+#define W4_TRACE_DECL long long w4tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long w4tl_ = 0; (void)w4tr_; (void)w4tl_
+#define W4_T0() do { if constexpr (VAR == 11) w4tl_ = __builtin_readcyclecounter(); } while (0)
+#define W4_T(k) do { if constexpr (VAR == 11) { const long long n_ = __builtin_readcyclecounter(); w4tr_[k] += n_ - w4tl_; w4tl_ = n_; } } while (0)
+#define W4_TRACE_OUT() do { if constexpr (VAR == 11) { if (g.trace && lane == 0) for (int k_ = 0; k_ < 8; ++k_) g.trace[(blockIdx.x * 8 + wave) * 8 + k_] = w4tr_[k_]; } } while (0)
+
+// Helper-wave global loads, hidden from the compiler's s_waitcnt bookkeeping.  The helpers keep loads in flight for several
+// loop iterations (the halo comes from HBM: ~2.5 us under load); hipcc's waitcnt insertion loses count across the loop's
+// control flow and falls back to vmcnt(0) before every use, which serialises every load with its consumer.  Issued from
+// inline asm the loads are invisible to it, and the waits are written by hand with exact counts (vmcnt retires in order).
+// `s_nop 4`: an SGPR base written by a scalar instruction needs 5 wait states before a vector memory instruction reads it,
+// and the compiler does not know this statement is one.
+__device__ __forceinline__ void w4_ld1(float& dst, const char* base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ float* ubuf_of(float* ub, int p) { return ub + p * W4_UP; }
+
+// MOD / LN / SILU: the loader fusions of the launch (modulation add, LayerNorm, SiLU) as compile-time switches
+// VAR: ablation variant (0 = shipped; others exist only under -DSDA_W4_VARIANTS for tools/wino4_check.py --variants)
 template <bool MOD, bool LN, bool SILU, int VAR = 0>
-__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
+__global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, kq = lane >> 4;
-    float* const priv = smem + 2 * W4_VBUF + wave * (4 * W4_HPLANE);       // this wave's 4-channel halo
+    float* const ubuf = smem;                              // [2][W4_UBUF]
+    float* const vbuf = smem + 2 * W4_UBUF;                // [2][W4_VBUF]
 
     // persistent, XCD-aware tile walk: XCD (blockIdx & 7) owns a contiguous range of the tile list, and each of its
-    // workgroups a contiguous sub-range -- consecutive tiles are the cout tiles of one block, then the next block along
-    // the row, so a tile's input halo was (mostly) just read into this XCD's L2, and stepping to the next tile is an
-    // increment with carries (no division in the stage body)
+    // workgroups a contiguous sub-range (a tile's input halo was mostly just read into this XCD's L2 by its neighbour)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int tq = g.grid >> 3, tr_ = g.grid & 7;
     const int t_begin = xcd * tq + (xcd < tr_ ? xcd : tr_);
@@ -133,247 +170,328 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const sda_conv_desc 
     const int my_tiles = sq + (slot < sr ? 1 : 0);
     if (my_tiles <= 0) return;
     const int Q = my_tiles * g.nstage;                     // stages this workgroup runs, across all of its tiles
-
-    // halo slot i of this lane: position lane + 64 i of the 10 x 18 halo -> (row, column); tile independent
-    int hy[W4_NSLOT], hx[W4_NSLOT], lidx[W4_NSLOT];
-#pragma unroll
-    for (int i = 0; i < W4_NSLOT; ++i) {
-        const int pos = lane + 64 * i;
-        const bool valid = pos < W4_HRW * W4_HC;
-        hy[i] = valid ? pos / W4_HC : -1000;               // (never live)
-        hx[i] = valid ? pos - W4_HC * (pos / W4_HC) : 0;
-        lidx[i] = valid ? (pos / W4_HC) * W4_HS + hx[i] : W4_HS - 1;       // (column 23 of row 0 is padding)
-    }
-    const int up_sh_h = d.up_h == 2 ? 1 : 0, up_sh_w = d.up_w == 2 ? 1 : 0;
-    const bool circ = d.circular != 0;
-    // producer lane (t, h): tile t = lane & 31 = (ty, tx) = (t >> 3, t & 7), channels 2 h and 2 h + 1 of the wave's four
-    const int ph = lane >> 5;
-    const int pbase = (2 * ((lane & 31) >> 3)) * W4_HS + 2 * (lane & 7) + 2 * ph * W4_HPLANE;
-    const int vwr = (wave * W4_T + (lane & 31)) * 4 + 2 * ph;
-    // consumer: B fragment of position p = V[p][kq][16 wn + li][0..3]
-    const int vrd = (kq * W4_T + 16 * wn + li) * 4;
-
-    // ---- producer state that travels from the issue of a stage's loads to their commit
-    float hv_[4][W4_NSLOT];
-    float hmean[W4_NSLOT], hrstd[W4_NSLOT];
-    unsigned hlive = 0;                                    // bit i: slot i carries data
-    unsigned hoff[W4_NSLOT];                               // BYTE offsets inside a channel plane (scalar base + 32-bit lane offset)
-    const float* ximg = d.x;
-    float u[2][4][4];                                      // [channel of the pair][row a][column]: row-transformed patches
-
-    // stage cursor (all scalar): stage in tile + the decoded tile; kept incrementally for q (consume), q + 1 (commit /
-    // transform) and q + 2 (issue)
-    struct Cur { int st, ct, bx, by, n; };
-    auto advance = [&](Cur& c) {
-        const bool t_next = c.st + 1 == g.nstage;
-        c.st = t_next ? 0 : c.st + 1;
-        const bool b_next = t_next && c.ct + 1 == g.n_ct;
-        c.ct = t_next ? (b_next ? 0 : c.ct + 1) : c.ct;
-        const bool y_next = b_next && c.bx + 1 == g.bx_n;
-        c.bx = b_next ? (y_next ? 0 : c.bx + 1) : c.bx;
-        const bool n_next = y_next && c.by + 1 == g.by_n;
-        c.by = y_next ? (n_next ? 0 : c.by + 1) : c.by;
-        c.n += n_next ? 1 : 0;
-    };
-
-    // geometry of a stage's halo (once per stage, at issue time): addresses, liveness, LayerNorm statistics
-    auto halo_geometry = [&](const Cur& t, auto I0, auto I1) {
-        constexpr int i0 = decltype(I0)::value, i1 = decltype(I1)::value;
-        if constexpr (i0 == 0) {
-            ximg = d.x + (int64_t)(t.n + d.x_n_off) * d.x_sn_outer;
-            hlive = 0;
-        }
-#pragma unroll
-        for (int i = i0; i < i1; ++i) {
-            // (selects only: no branch may split the stage body)
-            const int vy0 = 8 * t.by - 1 + hy[i], vx0 = 16 * t.bx - 1 + hx[i];
-            const bool inside = vy0 >= 0 && vy0 < g.hv && vx0 >= 0 && vx0 < g.wv;
-            const int vyw = vy0 < 0 ? vy0 + g.hv : (vy0 >= g.hv ? vy0 - g.hv : vy0);
-            const int vxw = vx0 < 0 ? vx0 + g.wv : (vx0 >= g.wv ? vx0 - g.wv : vx0);
-            const bool ok = (hy[i] >= 0) && (circ || inside);
-            const int vy = ok ? vyw : 0, vx = ok ? vxw : 0;
-            const int sy = vy >> up_sh_h, sx = vx >> up_sh_w;
-            hoff[i] = (unsigned)(sy * (int)d.x_sy + sx * (int)d.x_sx) * 4u;
-            hlive |= ok ? (1u << i) : 0u;
-            if constexpr (LN) {
-                const int st = (t.n * d.hs + sy) * d.ws + sx;
-                hmean[i] = d.ln_mean[st];
-                hrstd[i] = d.ln_rstd[st];
-            }
-        }
-    };
-    auto halo_issue = [&](const Cur& c, auto CH) {
-        constexpr int ch = decltype(CH)::value;
-        const int cc = W4_CK * c.st + 4 * wave + ch;
-        const int cce = cc < g.cin ? cc : 0;               // (padded channels read channel 0 and are zeroed at commit)
-        const char* xc = reinterpret_cast<const char*>(ximg + (int64_t)cce * d.x_sc);
-#pragma unroll
-        for (int i = 0; i < W4_NSLOT; ++i) hv_[ch][i] = *reinterpret_cast<const float*>(xc + hoff[i]);
-    };
-    auto halo_commit = [&](const Cur& c, auto CH) {
-        constexpr int ch = decltype(CH)::value;
-        const int cc = W4_CK * c.st + 4 * wave + ch;
-        const bool real = cc < g.cin;                      // wave uniform (false only in a partial last stage)
-        float* dst = priv + ch * W4_HPLANE;
-        float mv = 0.f;
-        if constexpr (MOD) mv = d.mod[real ? cc : 0];
-        const unsigned keep = real ? hlive : 0u;
-#pragma unroll
-        for (int i = 0; i < W4_NSLOT; ++i) {
-            float v = hv_[ch][i];
-            if constexpr (MOD) v += mv;
-            if constexpr (LN) v = (v - hmean[i]) * hrstd[i];
-            if constexpr (SILU) v = sda_act(SDA_ACT_SILU, v);
-            // padding / out-of-range positions and padded channels stage zeros
-            dst[lidx[i]] = ((keep >> i) & 1u) ? v : 0.f;
-        }
-    };
-    // patch of this lane's channel `e` of its pair -> rows transformed: u0 = d0 - d2, u1 = d1 + d2, u2 = d2 - d1, u3 = d1 - d3
-    auto patch_rows = [&](auto E) {
-        constexpr int e = decltype(E)::value;
-        const float* src = priv + pbase + e * W4_HPLANE;
-        f32x2 lo[4], hi[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            lo[a] = *reinterpret_cast<const f32x2*>(src + a * W4_HS);
-            hi[a] = *reinterpret_cast<const f32x2*>(src + a * W4_HS + 2);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float d0 = c < 2 ? lo[0][c & 1] : hi[0][c & 1], d1 = c < 2 ? lo[1][c & 1] : hi[1][c & 1];
-            const float d2 = c < 2 ? lo[2][c & 1] : hi[2][c & 1], d3 = c < 2 ? lo[3][c & 1] : hi[3][c & 1];
-            u[e][0][c] = d0 - d2;
-            u[e][1][c] = d1 + d2;
-            u[e][2][c] = d2 - d1;
-            u[e][3][c] = d1 - d3;
-        }
-    };
-    // row a of both patches -> columns transformed -> V[4 a + b][wave][t][2 h .. 2 h + 1], b = 0..3
-    auto patch_cols_store = [&](float* vb, auto A) {
-        constexpr int a = decltype(A)::value;
-        f32x2 w0, w1, w2, w3;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            w0[e] = u[e][a][0] - u[e][a][2];
-            w1[e] = u[e][a][1] + u[e][a][2];
-            w2[e] = u[e][a][2] - u[e][a][1];
-            w3[e] = u[e][a][1] - u[e][a][3];
-        }
-        float* dst = vb + vwr + (4 * a) * W4_PSTR;
-        *reinterpret_cast<f32x2*>(dst) = w0;
-        *reinterpret_cast<f32x2*>(dst + 1 * W4_PSTR) = w1;
-        *reinterpret_cast<f32x2*>(dst + 2 * W4_PSTR) = w2;
-        *reinterpret_cast<f32x2*>(dst + 3 * W4_PSTR) = w3;
-    };
-
-    // ---- consumer operand streams.  A: U packed [stage][p][cout fragment][lane][k4]
-    const int64_t u_pstride = (int64_t)g.mtiles * 256, u_sstride = 16 * u_pstride;
-    constexpr int UD = VAR == 3 ? 7 : 3, UB = UD + 1;                     // U fragments are fetched UD position steps ahead (ring of UB)
-    static_assert(16 % UB == 0, "the ring index must be static across stages");
-    f32x4 av[UB][3], bv[2];
-    const unsigned lane16 = lane * 16u;
-    const char* up_cur = nullptr;                          // (scalar) U of the position whose fragments are fetched next
-    auto u_stage = [&](const Cur& c) {
-        return reinterpret_cast<const char*>(d.w_wino4 + (int64_t)(c.ct * 6 + 3 * wm) * 256 + c.st * u_sstride);
-    };
-    auto fetch_a = [&](int s_) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m) av[s_][m] = *reinterpret_cast<const f32x4*>((up_cur + m * 1024) + lane16);   // scalar base + lane offset
-        up_cur += u_pstride * 4;
-    };
-    auto fetch_b = [&](const float* vb, int p, int s_) {
-        bv[s_] = *reinterpret_cast<const f32x4*>(vb + vrd + p * W4_PSTR);
-    };
-
-    f32x4 acc[16][3];
-
-    // ---- prologue: produce stage 0 into V buffer 0, issue the loads of stage 1
-    Cur c0;
+    W4Cur c0;
     {
         const W4Tile t0 = w4_decode(g, first);
         c0.st = 0; c0.ct = t0.ct; c0.bx = t0.bx; c0.by = t0.by; c0.n = t0.n;
     }
-    Cur c1 = c0, c2 = c0;                                  // c1 / c2: stages q + 1 / q + 2, clamped to the last one
-    if (Q > 1) { advance(c1); advance(c2); }
-    if (Q > 2) advance(c2);
-    halo_geometry(c0, std::integral_constant<int, 0>{}, std::integral_constant<int, W4_NSLOT>{});
-    w4_static_for<0, 4>([&](auto CH) { halo_issue(c0, CH); });
-    w4_static_for<0, 4>([&](auto CH) { halo_commit(c0, CH); });
-    w4_static_for<0, 2>([&](auto E) { patch_rows(E); });
-    w4_static_for<0, 4>([&](auto A) { patch_cols_store(smem, A); });
-    halo_geometry(c1, std::integral_constant<int, 0>{}, std::integral_constant<int, W4_NSLOT>{});
-    w4_static_for<0, 4>([&](auto CH) { halo_issue(c1, CH); });
-    up_cur = u_stage(c0);
-#pragma unroll
-    for (int i = 0; i < UD; ++i) fetch_a(i);
-    __syncthreads();
 
-    // one stage: 16 position steps of 12 MFMAs, each carrying its slice of the production of stage q + 1 and of the loads of
-    // stage q + 2.  The body is ONE basic block, the same for every stage: at the very end of the workgroup's run the
-    // producer cursors are clamped to the last stage, whose (valid) data is produced once more into a buffer nobody reads --
-    // two redundant slices per launch instead of a peeled loop whose copies of the accumulators would have to be merged.
-    // sched_barrier fences keep every slice (and the operand prefetch, which the scheduler would otherwise hoist to the top
-    // and hold 190 registers with) inside its step; inside a step the group barriers ask for MFMA / others / MFMA / ...
-    // so the slice issues in the 32-cycle shadows of the step's MFMAs.
+    if (wave >= 4) {
+        // ================================================================== helpers (waves 4-7, the consumers' siblings)
+        // A sibling of an MFMA-saturated wave issues roughly one instruction per 10-20 cycles (and an LDS-DMA instruction costs
+        // it ~150), so a helper has room for ~200 instructions per 3072-cycle stage: the work is split evenly over the four of
+        // them and kept lean.  Helper j, while stage q is multiplied:
+        //   * V of stage q + 1 for the channels with kq = j (channel of a stage = 2 kq + k4): commits their 18 x 10 halo --
+        //     loaded THREE iterations ago (HBM round trips take ~2.5 us under load) into a ring of four register sets, with the
+        //     loader fusions applied once per pixel -- to its private LDS area, then lane (t, e) transforms the patch of tile
+        //     t, channel k4 = e and writes V[p][j][t][e];
+        //   * U of stage q + 1, positions 4 j .. 4 j + 3 (12 KiB): registers (loaded one iteration ago from L2, 12 coalesced
+        //     dwordx4) -> LDS, lane-linear; then the loads of stage q + 2 into the same registers;
+        //   * the halo loads of stage q + 4 last: vmcnt retires in order, so waiting for the U registers of the next iteration
+        //     completes only halo loads that are at least two iterations old.
+        // Halo addresses / liveness / LayerNorm statistics depend on the tile only: they are recomputed when the issue cursor
+        // enters a new tile and travel with each register set.
+        const int pw = wave - 4;
+        float* const priv = smem + 2 * W4_UBUF + 2 * W4_VBUF + pw * (2 * W4_HPLANE);
+        // halo slot i of this lane: position lane + 64 i of the 10 x 18 halo -> (row, column); tile independent
+        int hy[W4_NSLOT], hx[W4_NSLOT], lidx[W4_NSLOT];
+#pragma unroll
+        for (int i = 0; i < W4_NSLOT; ++i) {
+            const int pos = lane + 64 * i;
+            const bool valid = pos < W4_HRW * W4_HC;
+            hy[i] = valid ? pos / W4_HC : -1000;           // (never live)
+            hx[i] = valid ? pos - W4_HC * (pos / W4_HC) : 0;
+            lidx[i] = valid ? (pos / W4_HC) * W4_HS + hx[i] : W4_HS - 1;   // (column 23 of row 0 is padding)
+        }
+        const int up_sh_h = d.up_h == 2 ? 1 : 0, up_sh_w = d.up_w == 2 ? 1 : 0;
+        const bool circ = d.circular != 0;
+        // lane (t, e): tile t = lane & 31 = (ty, tx) = (t >> 3, t & 7), channel e = lane >> 5 of the wave's pair
+        const int pe = lane >> 5;
+        const int pbase = pe * W4_HPLANE + (2 * ((lane & 31) >> 3)) * W4_HS + 2 * (lane & 7);
+        const int vwr = pw * W4_VKQ + (lane & 31) * 2 + pe;
+        const unsigned lane16 = lane * 16u;
+
+        // per-tile halo geometry of the issue cursor
+        unsigned goff[W4_NSLOT], glive = 0;
+        float gmean[W4_NSLOT], grstd[W4_NSLOT];
+        const float* gimg = d.x;
+        auto geometry = [&](const W4Cur& t) {
+            gimg = d.x + (int64_t)(t.n + d.x_n_off) * d.x_sn_outer;
+            glive = 0;
+#pragma unroll
+            for (int i = 0; i < W4_NSLOT; ++i) {
+                const int vy0 = 8 * t.by - 1 + hy[i], vx0 = 16 * t.bx - 1 + hx[i];
+                const bool inside = vy0 >= 0 && vy0 < g.hv && vx0 >= 0 && vx0 < g.wv;
+                const int vyw = vy0 < 0 ? vy0 + g.hv : (vy0 >= g.hv ? vy0 - g.hv : vy0);
+                const int vxw = vx0 < 0 ? vx0 + g.wv : (vx0 >= g.wv ? vx0 - g.wv : vx0);
+                const bool ok = (hy[i] >= 0) && (circ || inside);
+                const int vy = ok ? vyw : 0, vx = ok ? vxw : 0;
+                const int sy = vy >> up_sh_h, sx = vx >> up_sh_w;
+                goff[i] = (unsigned)(sy * (int)d.x_sy + sx * (int)d.x_sx) * 4u;
+                glive |= ok ? (1u << i) : 0u;
+                gmean[i] = 0.f; grstd[i] = 1.f;
+                if constexpr (LN) {
+                    const int st = (t.n * d.hs + sy) * d.ws + sx;
+                    gmean[i] = d.ln_mean[st];
+                    grstd[i] = d.ln_rstd[st];
+                }
+            }
+        };
+        // what travels from the issue of a stage's halo loads to their commit
+        struct Halo { float v[2][W4_NSLOT]; float mean[W4_NSLOT], rstd[W4_NSLOT]; unsigned live; };
+        // (vector-memory and scalar instructions only: runs beside the consumers' MFMAs)
+        auto issue = [&](const W4Cur& t, Halo& h) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int cc = W4_CK * t.st + 2 * pw + ch;
+                const int cce = cc < g.cin ? cc : 0;       // (padded channels read channel 0 and are zeroed at commit)
+                const char* xc = reinterpret_cast<const char*>(gimg + (int64_t)cce * d.x_sc);
+#pragma unroll
+                for (int i = 0; i < W4_NSLOT; ++i) w4_ld1(h.v[ch][i], xc, goff[i]);
+            }
+        };
+        // the geometry the set's loads were issued with (VALU copies: part of the pause work)
+        auto tag = [&](Halo& h) {
+            h.live = glive;
+            if constexpr (LN) {
+#pragma unroll
+                for (int i = 0; i < W4_NSLOT; ++i) { h.mean[i] = gmean[i]; h.rstd[i] = grstd[i]; }
+            }
+        };
+        // wait until at most N of this wave's loads are outstanding; the set's registers pass through the statement, so that
+        // nothing that reads them can be scheduled above it
+#define W4_WAIT_HALO(N, h)                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"((h).v[0][0]), "+v"((h).v[0][1]), "+v"((h).v[0][2]), "+v"((h).v[1][0]),             \
+                 "+v"((h).v[1][1]), "+v"((h).v[1][2]) : "n"(N) : "memory")
+        // a launch without loader fusions whose halo positions and channels all carry data (circular padding, cin % 8 == 0 --
+        // every backward-data convolution of the reference nets) commits with plain LDS stores: no VALU, so the commit moves
+        // into the part of the iteration that runs beside the MFMAs
+        const bool raw_commit = !MOD && !LN && !SILU && circ && (g.cin % W4_CK) == 0;
+        auto commit_raw = [&](const Halo& h) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int i = 0; i < W4_NSLOT; ++i) priv[ch * W4_HPLANE + lidx[i]] = h.v[ch][i];
+        };
+        auto commit = [&](const W4Cur& t, const Halo& h) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int cc = W4_CK * t.st + 2 * pw + ch;
+                const bool real = cc < g.cin;              // wave uniform (false only in a partial last stage)
+                float mv = 0.f;
+                if constexpr (MOD) mv = d.mod[real ? cc : 0];
+                const unsigned keep = real ? h.live : 0u;
+#pragma unroll
+                for (int i = 0; i < W4_NSLOT; ++i) {
+                    float v = h.v[ch][i];
+                    if constexpr (MOD) v += mv;
+                    if constexpr (LN) v = (v - h.mean[i]) * h.rstd[i];
+                    if constexpr (SILU) v = sda_act(SDA_ACT_SILU, v);
+                    // padding / out-of-range positions and padded channels stage zeros
+                    priv[ch * W4_HPLANE + lidx[i]] = ((keep >> i) & 1u) ? v : 0.f;
+                }
+            }
+        };
+        // this lane's patch: LDS -> registers (no VALU) ...
+        f32x2 plo[4], phi[4];
+        auto patch_read = [&]() {
+            const float* src = priv + pbase;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                plo[a] = *reinterpret_cast<const f32x2*>(src + a * W4_HS);
+                phi[a] = *reinterpret_cast<const f32x2*>(src + a * W4_HS + 2);
+            }
+        };
+        // ... -> B^T d B -> V[p][pw][t][pe]
+        auto transform = [&](float* vb) {
+            float u[4][4];                                 // rows: u0 = d0 - d2, u1 = d1 + d2, u2 = d2 - d1, u3 = d1 - d3
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = c < 2 ? plo[0][c & 1] : phi[0][c & 1], d1 = c < 2 ? plo[1][c & 1] : phi[1][c & 1];
+                const float d2 = c < 2 ? plo[2][c & 1] : phi[2][c & 1], d3 = c < 2 ? plo[3][c & 1] : phi[3][c & 1];
+                u[0][c] = d0 - d2; u[1][c] = d1 + d2; u[2][c] = d2 - d1; u[3][c] = d1 - d3;
+            }
+            float* dst = vb + vwr;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {                  // columns, same combination
+                dst[(4 * a + 0) * W4_VP] = u[a][0] - u[a][2];
+                dst[(4 * a + 1) * W4_VP] = u[a][1] + u[a][2];
+                dst[(4 * a + 2) * W4_VP] = u[a][2] - u[a][1];
+                dst[(4 * a + 3) * W4_VP] = u[a][1] - u[a][3];
+            }
+        };
+        // U slab, positions 4 pw .. 4 pw + 3 of a stage: 12 KiB = 12 wave-wide dwordx4
+        f32x4 ureg[12];
+        auto u_load = [&](const W4Cur& t) {
+            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 16 + 4 * pw) * g.mtiles + 6 * t.ct) * 128);
+            const int64_t pstride = (int64_t)g.mtiles * 512;          // bytes between positions
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const char* sp = src + pp * pstride;
+                w4_ld4<0>(ureg[pp * 3 + 0], sp, lane16);
+                w4_ld4<1024>(ureg[pp * 3 + 1], sp, lane16);
+                w4_ld4<2048>(ureg[pp * 3 + 2], sp, lane16);
+            }
+        };
+#define W4_WAIT_U(N)                                                                                                           \
+    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
+                 "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]) : "n"(N) : "memory")
+        auto u_store = [&](float* ub) {
+            float* dst = ub + (4 * pw) * W4_UP + lane * 4;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int ck = 0; ck < 3; ++ck) *reinterpret_cast<f32x4*>(dst + pp * W4_UP + ck * 256) = ureg[pp * 3 + ck];
+        };
+        // hand-off: this wave's LDS writes have landed; its global loads stay in flight across the barrier
+        auto handoff = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // cursors: stage q + 2 (U load, halo commit) and stage q + 5 (halo issue), clamped to the last stage (which is then
+        // produced again into buffers nobody reads)
+        W4Cur c2 = c0, ci = c0;
+        int q2 = 0, qi = 0;                                // stage indices of c2, ci
+        auto step2 = [&]() { if (q2 + 1 < Q) { w4_advance(g, c2); ++q2; } };
+        auto step_issue = [&]() {
+            if (qi + 1 < Q) {
+                w4_advance(g, ci); ++qi;
+                if (ci.st == 0) geometry(ci);              // (a new tile; one stage per tile: every time)
+            }
+        };
+        W4_TRACE_DECL;
+        constexpr int NHL = 2 * W4_NSLOT, NUL = 12;        // loads per halo set / per U slab quarter
+        // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
+        // of stages 2, 3, 4 in flight
+        Halo h0, h1, h2, h3;
+        geometry(ci);
+        issue(ci, h0); tag(h0); step_issue();
+        issue(ci, h1); tag(h1); step_issue();
+        issue(ci, h2); tag(h2); step_issue();
+        issue(ci, h3); tag(h3); step_issue();
+        u_load(c2);
+        W4_WAIT_HALO(3 * NHL + NUL, h0);
+        commit(c2, h0);
+        patch_read();
+        transform(vbuf);
+        W4_WAIT_U(0);
+        u_store(ubuf);
+        step2();
+        u_load(c2);
+        W4_WAIT_HALO(NUL, h1);
+        commit(c2, h1);
+        step2();
+        issue(ci, h0); tag(h0); step_issue();
+        handoff();
+        // One helper iteration, while the consumers multiply stage q.  The fp32 MFMA stream owns the SIMD's vector ALU: a
+        // sibling's VALU instruction does not issue at all until the stream pauses (tools/mfma_shadow_gen.py, p_* / x_* rows),
+        // while its LDS, scalar and vector-memory instructions do.  So an iteration has a non-VALU part that runs beside the
+        // MFMAs -- U registers -> LDS, the global loads of the coming stages, the patch reads of stage q + 1 -- and a short
+        // VALU part that runs when the consumers reach the stage barrier: B^T d B of stage q + 1 and the loader fusions of
+        // stage q + 2 (different stages, so no LDS round trip separates them).
+        auto iteration = [&](int q, Halo& hcommit, Halo& hissue) {
+            float* ub = ubuf + ((q + 1) & 1) * W4_UBUF;
+            float* vb = vbuf + ((q + 1) & 1) * W4_VBUF;
+            W4_T0();
+            // the U registers were loaded one iteration ago, before that iteration's halo loads
+            W4_WAIT_U(NHL);
+            if constexpr (VAR != 6) u_store(ub);
+            if constexpr (VAR == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_T(0);                                       // U registers -> LDS (incl. the wait for their loads)
+            __builtin_amdgcn_sched_barrier(0);
+            u_load(c2);                                    // (always: the hand-written wait counts assume both load groups)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(ci, hissue);
+            __builtin_amdgcn_sched_barrier(0);
+            patch_read();                                  // halo of stage q + 1 (committed during the previous iteration)
+            __builtin_amdgcn_sched_barrier(0);
+            // the set committed now (stage q + 2) was issued three iterations ago: 3 x (U + halo) loads came after it
+            W4_WAIT_HALO(3 * (NHL + NUL), hcommit);
+            if (raw_commit) commit_raw(hcommit);
+            W4_T(1);                                       // load issue + patch reads (+ the VALU-free commit)
+            __builtin_amdgcn_sched_barrier(0);
+            transform(vb);
+            if (!raw_commit) commit(c2, hcommit);
+            tag(hissue);
+            step_issue();
+            step2();
+            if constexpr (VAR == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_T(2);                                       // the VALU part
+            handoff();
+            W4_T(3);                                       // barrier wait
+        };
+        for (int q = 0; q < Q; q += 4) {
+            iteration(q, h2, h1);
+            if (q + 1 < Q) iteration(q + 1, h3, h2);
+            if (q + 2 < Q) iteration(q + 2, h0, h3);
+            if (q + 3 < Q) iteration(q + 3, h1, h0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_TRACE_OUT();
+        return;
+    }
+
+    // ====================================================================== consumers (MFMA + LDS reads only in the loop)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    // A fragment of (position p, cout fragment m): U[p][3 wm + m][lane][0..1];  B fragment: V[p][kq][16 wn + li][0..1]
+    const int ard = (3 * wm * 64 + lane) * 2;
+    const int brd = kq * W4_VKQ + (16 * wn + li) * 2;
+    f32x4 acc[16][3];
+    W4_TRACE_DECL;
+    __syncthreads();                                       // stage 0 is in buffer 0
     int q = 0;
+    W4_T0();
     for (int tl = 0; tl < my_tiles; ++tl) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int m = 0; m < 3; ++m) acc[p][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int st = 0; st < g.nstage; ++st, ++q) {
-        const float* vb = smem + (q & 1) * W4_VBUF;
-        float* vnext = smem + ((q + 1) & 1) * W4_VBUF;
-        fetch_b(vb, 0, 0);
-        w4_static_for<0, 16>([&](auto P) {
-            constexpr int p = decltype(P)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            // B of the next position; A of position p + UD (of the next stage's first positions at the end: at a tile
-            // change the U pointer is re-based, inside a tile the next stage simply follows in memory)
-            constexpr bool NO_PROD = VAR == 4 || VAR == 6, NO_A = VAR == 5 || VAR == 6;
-            if constexpr (p + 1 < 16) fetch_b(vb, p + 1, (p + 1) & 1);
-            if constexpr (p + UD == 16) up_cur = u_stage(c1);
-            if constexpr (!NO_A) fetch_a((p + UD) % UB);
-            // the producer slice of this position step
-            // (the geometry of stage q + 2 overwrites what the commits of stage q + 1 read: it starts after them)
-            if constexpr (NO_PROD) { }
-            else if constexpr (p < 4) halo_commit(c1, std::integral_constant<int, p>{});
-            else if constexpr (p == 4) halo_geometry(c2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-            else if constexpr (p == 5 || p == 6) patch_rows(std::integral_constant<int, p - 5>{});
-            else if constexpr (p >= 7 && p < 11) patch_cols_store(vnext, std::integral_constant<int, p - 7>{});
-            else if constexpr (p == 11) halo_geometry(c2, std::integral_constant<int, 2>{}, std::integral_constant<int, W4_NSLOT>{});
-            else if constexpr (p >= 12) halo_issue(c2, std::integral_constant<int, p - 12>{});
+        for (int st = 0; st < g.nstage; ++st, ++q) {
+            const float* ua = ubuf + (q & 1) * W4_UBUF + ard;
+            const float* va = vbuf + (q & 1) * W4_VBUF + brd;
+            // two positions per step: 8 LDS reads, then 12 MFMAs; the operands of step s + 1 are read during step s
+            f32x2 av[2][2][3], bv[2][2];
+            auto fetch = [&](int s, int buf) {
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 2 * s + h;
+                    bv[buf][h] = *reinterpret_cast<const f32x2*>(va + p * W4_VP);
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-                    acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p % UB][m][k4], bv[p & 1][k4], acc[p][m], 0, 0, 0);
-            // fillers per MFMA shadow: the slice of the step spread over its 12 MFMAs
-            constexpr int NF = VAR == 1 ? ((p == 4 || p == 11) ? 6 : 5)
-                                        : ((p == 4 || p == 11) ? 6 : (p < 4 && (SILU || LN)) ? 5 : 3);
-            if constexpr (VAR != 2) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x496, NF, 0);     // a few VALU / SALU / VMEM / DS / TRANS
+                    for (int m = 0; m < 3; ++m) av[buf][h][m] = *reinterpret_cast<const f32x2*>(ua + p * W4_UP + m * 128);
                 }
-            }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        // stage hand-off: every wave's V writes of stage q + 1 have landed and its V reads of stage q have returned
-        // (lgkmcnt only -- a __syncthreads() would also drain the global loads in flight for the coming stages: the U
-        // fragments of the next three positions and the halo of stage q + 2, i.e. expose an HBM round trip per stage)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (st + 1 < g.nstage) advance(c0);                // (c0 stays on the tile for its epilogue)
-        if (q + 2 < Q) advance(c1);
-        if (q + 3 < Q) advance(c2);
-      }
+            };
+            fetch(0, 0);
+            w4_static_for<0, 8>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if constexpr (s + 1 < 8) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+                            acc[2 * s + h][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][h][m][k4], bv[s & 1][h][k4], acc[2 * s + h][m], 0, 0, 0);
+                // pin the software pipeline: the LDS reads of the NEXT step issue first (one group: the first DS instruction
+                // after an MFMA costs ~5 cycles, the following ones ~0.3), then this step's 12 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // stage hand-off: this wave's reads of stage q have returned (lgkmcnt only: the epilogue's stores of the previous
+            // tile may still be draining and need not be waited for)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_T(0);                                       // multiply
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            W4_T(1);                                       // barrier wait
+            if (st + 1 < g.nstage) w4_advance(g, c0);      // (c0 stays on the tile for its epilogue)
+        }
         {
-            // ---- epilogue of tile c0.tile: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
+            // ---- epilogue of tile c0: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
             //      cout = 96 ct + 48 wm + 16 m + 4 kq + r,  tile = 16 wn + li
-            const Cur& tt = c0;
+            const W4Cur& tt = c0;
             const int hw_o = d.ho * d.wo;
             const int t = 16 * wn + li;
             const int oy = 8 * tt.by + 2 * (t >> 3), ox = 16 * tt.bx + 2 * (t & 7);
@@ -418,9 +536,28 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const sda_conv_desc 
                 }
             }
         }
-        advance(c0);
+        w4_advance(g, c0);
+        W4_T(2);                                           // epilogue
     }
+    W4_TRACE_OUT();
 }
+
+#ifdef SDA_W4_VARIANTS
+static long long* w4_trace_buf = nullptr;
+static int w4_trace_grid = 0;
+// tooling: phase cycle sums of the last SDA_W4_VAR=11 launch, averaged over workgroups: out[wave 8][phase 8]
+extern "C" int sda_w4_trace_read(double* out) {
+    if (!w4_trace_buf || !out) return SDA_E_BADARG;
+    static long long host[256 * 64];
+    if (hipMemcpy(host, w4_trace_buf, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return SDA_E_BADARG;
+    for (int i = 0; i < 64; ++i) {
+        double s = 0;
+        for (int b = 0; b < w4_trace_grid; ++b) s += (double)host[b * 64 + i];
+        out[i] = s / w4_trace_grid;
+    }
+    return SDA_OK;
+}
+#endif
 
 template <bool MOD, bool LN, bool SILU, int VAR>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
@@ -428,7 +565,7 @@ static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, 
     static bool attr_set[SDA_MAX_DEVICES];
     const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, VAR>), W4_LDS_BYTES, attr_set);
     if (rc != SDA_OK) return rc;
-    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, VAR>), dim3(grid), dim3(256), (size_t)W4_LDS_BYTES, stream, *d, g);
+    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, VAR>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
     return sda_launch_status();
 }
 
@@ -453,12 +590,20 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
 #ifdef SDA_W4_VARIANTS
             const char* ev = getenv("SDA_W4_VAR");
             switch (ev ? atoi(ev) : 0) {
-                case 1: return wino4_launch_t<false, false, false, 1>(d, g, grid, stream);
-                case 2: return wino4_launch_t<false, false, false, 2>(d, g, grid, stream);
-                case 3: return wino4_launch_t<false, false, false, 3>(d, g, grid, stream);
-                case 4: return wino4_launch_t<false, false, false, 4>(d, g, grid, stream);
-                case 5: return wino4_launch_t<false, false, false, 5>(d, g, grid, stream);
-                case 6: return wino4_launch_t<false, false, false, 6>(d, g, grid, stream);
+                case 4: return wino4_launch_t<false, false, false, 4>(d, g, grid, stream);     // no production (stale operands)
+                case 5: return wino4_launch_t<false, false, false, 5>(d, g, grid, stream);     // U DMA only
+                case 6: return wino4_launch_t<false, false, false, 6>(d, g, grid, stream);     // V production only
+                case 7: return wino4_launch_t<false, false, false, 7>(d, g, grid, stream);     // U DMA + halo commit, no transform
+                case 8: return wino4_launch_t<false, false, false, 8>(d, g, grid, stream);     // helpers at priority 3
+                case 9: return wino4_launch_t<false, false, false, 9>(d, g, grid, stream);     // helpers at priority 1
+                case 10: return wino4_launch_t<false, false, false, 10>(d, g, grid, stream);   // consumers at priority 3
+                case 11: {                                                                      // phase tracing
+                    static long long* tbuf = nullptr;
+                    if (!tbuf && hipMalloc(&tbuf, 256 * 64 * sizeof(long long)) != hipSuccess) return SDA_E_BADARG;
+                    (void)hipMemsetAsync(tbuf, 0, 256 * 64 * sizeof(long long), stream);
+                    Wino4Geom gt = g; gt.trace = tbuf; w4_trace_buf = tbuf; w4_trace_grid = grid;
+                    return wino4_launch_t<false, false, false, 11>(d, gt, grid, stream);
+                }
                 default: break;
             }
 #endif
@@ -491,8 +636,8 @@ int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream) {
 
 // ---------------------------------------------------------------- weight transform for this kernel (one-off per layer)
 // dst[stage][p][m tile][lane = 16 kq + i][k4]  <-  (G g G^T)[xi][nu] of the filter between contraction channel
-// kk = 16 stage + 4 kq + k4 and output channel mm = 16 mtile + i;  forward (transpose = 0): kk = ci, mm = co;
-// backward-data (transpose = 1): kk = co, mm = ci, filter flipped.  k_pad % 16 == 0, m_pad % 96 == 0; padding is zero.
+// kk = 8 stage + 2 kq + k4 and output channel mm = 16 mtile + i;  forward (transpose = 0): kk = ci, mm = co;
+// backward-data (transpose = 1): kk = co, mm = ci, filter flipped.  k_pad % 8 == 0, m_pad % 96 == 0; padding is zero.
 __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin, int transpose, int cin_keep,
                                   float* __restrict__ dst, int k_pad, int m_pad) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -517,20 +662,20 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) tmp[xi][dx] = G[xi][0] * gk[0][dx] + G[xi][1] * gk[1][dx] + G[xi][2] * gk[2][dx];
-        const int st = kk >> 4, kq_ = (kk >> 2) & 3, k4 = kk & 3, mt = mm >> 4, ii = mm & 15;
+        const int st = kk >> 3, kq_ = (kk >> 1) & 3, k4 = kk & 1, mt = mm >> 4, ii = mm & 15;
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 const float uu = tmp[xi][0] * G[nu][0] + tmp[xi][1] * G[nu][1] + tmp[xi][2] * G[nu][2];
-                dst[((((int64_t)st * 16 + (xi * 4 + nu)) * mtiles + mt) * 64 + (kq_ * 16 + ii)) * 4 + k4] = uu;
+                dst[((((int64_t)st * 16 + (xi * 4 + nu)) * mtiles + mt) * 64 + (kq_ * 16 + ii)) * 2 + k4] = uu;
             }
     }
 }
 
 extern "C" int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst,
                                           int k_pad, int m_pad, void* stream) {
-    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 15) || (m_pad % W4_BM)) return SDA_E_BADARG;
+    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
     int64_t total = (int64_t)k_pad * m_pad;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

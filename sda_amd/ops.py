@@ -167,13 +167,12 @@ class PackedConv:
             _lib.check(_lib.load().sda_pack_conv_weight_wino(w.data_ptr(), cout, cin, int(transpose), keep,
                                                              self.wino.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino')
-        # ... and the packing of the one-wave-per-SIMD Winograd kernel (contraction channels padded to 16)
+        # ... and the packing of the second-generation Winograd kernel (conv_wino4.hip: U fragments in MFMA lane order)
         self.wino4 = None
         if WINOGRAD4 and self.wino is not None:
-            k16 = round_up(self.k_real, 16)
-            self.wino4 = torch.empty(16 * k16 * self.m_pad, device=w.device, dtype=torch.float32)
+            self.wino4 = torch.empty(16 * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
             _lib.check(_lib.load().sda_pack_conv_weight_wino4(w.data_ptr(), cout, cin, int(transpose), keep,
-                                                              self.wino4.data_ptr(), k16, self.m_pad, _stream()),
+                                                              self.wino4.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino4')
 
 
