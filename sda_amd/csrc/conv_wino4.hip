@@ -54,6 +54,7 @@ struct Wino4Geom {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w4_u32x2 __attribute__((ext_vector_type(2)));
 
 template <int I, int N, class F>
 __device__ __forceinline__ void w4_static_for(F&& f) {
@@ -79,11 +80,13 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return SDA_E_UNSUPPORTED;
     if (wino4_config(d) < 0) return SDA_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(d->out) & 7) || (d->res && (reinterpret_cast<uintptr_t>(d->res) & 7)) ||
-        (d->dact_z && (reinterpret_cast<uintptr_t>(d->dact_z) & 7)) || (reinterpret_cast<uintptr_t>(d->w_wino4) & 15))
+        (d->dact_z && (reinterpret_cast<uintptr_t>(d->dact_z) & 7)) || (reinterpret_cast<uintptr_t>(d->w_wino4) & 15) ||
+        (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)))
         return SDA_E_UNSUPPORTED;
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 || d->n_inner != 1) return SDA_E_UNSUPPORTED;      // (no window view)
     // 32-bit BYTE offsets inside one image (channel base included)
     if ((int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 30)) return SDA_E_UNSUPPORTED;
+    if ((int64_t)48 * d->ho * d->wo * 4 >= (1LL << 31)) return SDA_E_UNSUPPORTED;            // (epilogue buffer descriptors)
     if ((int64_t)d->cout * d->ho * d->wo >= (1LL << 30) || (int64_t)d->n * d->hs * d->ws >= (1LL << 31)) return SDA_E_UNSUPPORTED;
     g->cin = d->cx;
     g->hv = d->ho; g->wv = d->wo;
@@ -443,97 +446,133 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     __syncthreads();                                       // stage 0 is in buffer 0
     int q = 0;
     W4_T0();
+    // one K-stage: two positions per step -- 8 LDS reads, then 12 MFMAs; the operands of step s + 1 are read during step s.
+    // FIRST: the tile's first stage starts its accumulators from the C operand instead of reading them -- zero, or the bias
+    // for position p = 5 = (xi, nu) = (1, 1): A^T e_11 A is the all-ones 2 x 2 block, so a bias placed there comes out of the
+    // inverse transform added to every output pixel (no zero-fill and no bias adds in the epilogue).
+    auto stage = [&](auto FIRST_, const f32x4 (&binit)[3]) {
+        constexpr bool FIRST = decltype(FIRST_)::value;
+        const float* ua = ubuf + (q & 1) * W4_UBUF + ard;
+        const float* va = vbuf + (q & 1) * W4_VBUF + brd;
+        f32x2 av[2][2][3], bv[2][2];
+        auto fetch = [&](int s, int buf) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 2 * s + h;
+                bv[buf][h] = *reinterpret_cast<const f32x2*>(va + p * W4_VP);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) av[buf][h][m] = *reinterpret_cast<const f32x2*>(ua + p * W4_UP + m * 128);
+            }
+        };
+        fetch(0, 0);
+        w4_static_for<0, 8>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (s + 1 < 8) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int p = 2 * s + h;
+                        f32x4 c;
+                        if (FIRST && k4 == 0) c = (p == 5) ? binit[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        else c = acc[p][m];
+                        acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][h][m][k4], bv[s & 1][h][k4], c, 0, 0, 0);
+                    }
+            // pin the software pipeline: the LDS reads of the NEXT step issue first (one group: the first DS instruction
+            // after an MFMA costs ~5 cycles, the following ones ~0.3), then this step's 12 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // stage hand-off: this wave's reads of stage q have returned (lgkmcnt only: the epilogue's stores of the previous
+        // tile may still be draining and need not be waited for)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_T(0);                                           // multiply
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        W4_T(1);                                           // barrier wait
+        ++q;
+    };
     for (int tl = 0; tl < my_tiles; ++tl) {
+        // bias of this lane's couts: 96 ct + 48 wm + 16 m + 4 kq + (0..3)
+        f32x4 binit[3];
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) acc[p][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int st = 0; st < g.nstage; ++st, ++q) {
-            const float* ua = ubuf + (q & 1) * W4_UBUF + ard;
-            const float* va = vbuf + (q & 1) * W4_VBUF + brd;
-            // two positions per step: 8 LDS reads, then 12 MFMAs; the operands of step s + 1 are read during step s
-            f32x2 av[2][2][3], bv[2][2];
-            auto fetch = [&](int s, int buf) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int p = 2 * s + h;
-                    bv[buf][h] = *reinterpret_cast<const f32x2*>(va + p * W4_VP);
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) av[buf][h][m] = *reinterpret_cast<const f32x2*>(ua + p * W4_UP + m * 128);
-                }
-            };
-            fetch(0, 0);
-            w4_static_for<0, 8>([&](auto S) {
-                constexpr int s = decltype(S)::value;
-                if constexpr (s + 1 < 8) fetch(s + 1, (s + 1) & 1);
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int k4 = 0; k4 < 2; ++k4)
-#pragma unroll
-                        for (int m = 0; m < 3; ++m)
-                            acc[2 * s + h][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][h][m][k4], bv[s & 1][h][k4], acc[2 * s + h][m], 0, 0, 0);
-                // pin the software pipeline: the LDS reads of the NEXT step issue first (one group: the first DS instruction
-                // after an MFMA costs ~5 cycles, the following ones ~0.3), then this step's 12 MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // stage hand-off: this wave's reads of stage q have returned (lgkmcnt only: the epilogue's stores of the previous
-            // tile may still be draining and need not be waited for)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_T(0);                                       // multiply
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            W4_T(1);                                       // barrier wait
-            if (st + 1 < g.nstage) w4_advance(g, c0);      // (c0 stays on the tile for its epilogue)
+        for (int m = 0; m < 3; ++m) {
+            binit[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 48 * wm + 16 * m + 4 * kq);
+        }
+        stage(std::true_type{}, binit);
+        for (int st = 1; st < g.nstage; ++st) {
+            w4_advance(g, c0);                             // (c0 ends on the tile's last stage: the tile of the epilogue)
+            stage(std::false_type{}, binit);
         }
         {
             // ---- epilogue of tile c0: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
-            //      cout = 96 ct + 48 wm + 16 m + 4 kq + r,  tile = 16 wn + li
+            //      cout = 96 ct + 48 wm + 16 m + 4 kq + r,  tile = 16 wn + li.  The arithmetic runs on the f32x4 fragments
+            //      (four couts at once: register pairs -> packed adds, no shuffling); memory goes through buffer
+            //      instructions: one descriptor per tile (this wave's 48 cout planes of image n), a per-lane byte offset
+            //      and a scalar offset per cout -- no 64-bit vector address arithmetic.
             const W4Cur& tt = c0;
             const int hw_o = d.ho * d.wo;
             const int t = 16 * wn + li;
             const int oy = 8 * tt.by + 2 * (t >> 3), ox = 16 * tt.bx + 2 * (t & 7);
-            const int64_t obase = (int64_t)tt.n * d.cout * hw_o + (int64_t)oy * d.wo + ox;
+            const int lo0 = ((4 * kq) * hw_o + oy * d.wo + ox) * 4, lo1 = lo0 + d.wo * 4;
+            const int64_t sbase = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 48 * wm) * hw_o;
+            const int plane_bytes = 48 * hw_o * 4;
+            auto rsrc_of = [&](const float* p) {
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + sbase), (short)0, plane_bytes, 0x00020000);
+            };
+            auto run = [&](auto DACT_, auto RES_) {
+                constexpr bool DACT = decltype(DACT_)::value, RES = decltype(RES_)::value;
+                const auto r_out = rsrc_of(d.out);
+                const auto r_z = rsrc_of(DACT ? d.dact_z : d.out);
+                const auto r_res = rsrc_of(RES ? d.res : d.out);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = W4_BM * tt.ct + 48 * wm + 16 * m + 4 * kq + r;
-                    // rows (xi): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3, for each nu
-                    float s0[4], s1[4];
+                for (int m = 0; m < 3; ++m) {
+                    // rows (xi): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 for each nu;  columns (nu): the same combination
+                    f32x4 s0[4], s1[4];
 #pragma unroll
                     for (int nu = 0; nu < 4; ++nu) {
-                        const float m0 = acc[nu][m][r], m1 = acc[4 + nu][m][r], m2 = acc[8 + nu][m][r], m3 = acc[12 + nu][m][r];
-                        s0[nu] = (m0 + m1) + m2;
-                        s1[nu] = (m1 - m2) - m3;
+                        s0[nu] = (acc[nu][m] + acc[4 + nu][m]) + acc[8 + nu][m];
+                        s1[nu] = (acc[4 + nu][m] - acc[8 + nu][m]) - acc[12 + nu][m];
                     }
-                    const float bias = d.bias ? d.bias[co] : 0.f;
-                    f32x2 y0, y1;
-                    y0[0] = (s0[0] + s0[1]) + s0[2] + bias; y0[1] = (s0[1] - s0[2]) - s0[3] + bias;
-                    y1[0] = (s1[0] + s1[1]) + s1[2] + bias; y1[1] = (s1[1] - s1[2]) - s1[3] + bias;
-                    const int64_t o = obase + (int64_t)co * hw_o;
-                    if (d.dact_z) {
-                        const f32x2 q0 = *reinterpret_cast<const f32x2*>(d.dact_z + o);
-                        const f32x2 q1 = *reinterpret_cast<const f32x2*>(d.dact_z + o + d.wo);
-                        if (d.act_d == SDA_ACT_SILU) {
-                            y0[0] *= sda_dact(SDA_ACT_SILU, q0[0]); y0[1] *= sda_dact(SDA_ACT_SILU, q0[1]);
-                            y1[0] *= sda_dact(SDA_ACT_SILU, q1[0]); y1[1] *= sda_dact(SDA_ACT_SILU, q1[1]);
-                        } else {
-                            y0[0] *= sda_dact(d.act_d, q0[0]); y0[1] *= sda_dact(d.act_d, q0[1]);
-                            y1[0] *= sda_dact(d.act_d, q1[0]); y1[1] *= sda_dact(d.act_d, q1[1]);
+                    const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
+                    const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int so = (16 * m + r) * hw_o * 4;                      // scalar byte offset of the cout plane
+                        f32x2 y0 = {y00[r], y01[r]}, y1 = {y10[r], y11[r]};
+                        if constexpr (DACT) {
+                            const f32x2 q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo0, so, 0));
+                            const f32x2 q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo1, so, 0));
+                            if (d.act_d == SDA_ACT_SILU) {
+                                y0[0] *= sda_dact(SDA_ACT_SILU, q0[0]); y0[1] *= sda_dact(SDA_ACT_SILU, q0[1]);
+                                y1[0] *= sda_dact(SDA_ACT_SILU, q1[0]); y1[1] *= sda_dact(SDA_ACT_SILU, q1[1]);
+                            } else {
+                                y0[0] *= sda_dact(d.act_d, q0[0]); y0[1] *= sda_dact(d.act_d, q0[1]);
+                                y1[0] *= sda_dact(d.act_d, q1[0]); y1[1] *= sda_dact(d.act_d, q1[1]);
+                            }
+                        }
+                        if constexpr (RES) {
+                            y0 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo0, so, 0));
+                            y1 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo1, so, 0));
+                        }
+                        if (!(g.debug & 8)) {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w4_u32x2, y0), r_out, lo0, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w4_u32x2, y1), r_out, lo1, so, 0);
                         }
                     }
-                    if (d.res) {
-                        y0 += *reinterpret_cast<const f32x2*>(d.res + o);
-                        y1 += *reinterpret_cast<const f32x2*>(d.res + o + d.wo);
-                    }
-                    if (!(g.debug & 8)) {
-                        *reinterpret_cast<f32x2*>(d.out + o) = y0;
-                        *reinterpret_cast<f32x2*>(d.out + o + d.wo) = y1;
-                    }
                 }
+            };
+            if (d.dact_z) {
+                if (d.res) run(std::true_type{}, std::true_type{});
+                else run(std::true_type{}, std::false_type{});
+            } else {
+                if (d.res) run(std::false_type{}, std::true_type{});
+                else run(std::false_type{}, std::false_type{});
             }
         }
         w4_advance(g, c0);
