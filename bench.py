@@ -16,10 +16,17 @@ Synthetic score net: a raw random-init net makes the *reference itself* overflow
 item 5), so the timed noise estimator is eps(x,t) = sigma x/(mu^2+sigma^2) + 0.1 * UNet(x,t): the exact estimator for
 N(0,I) data plus the full U-Net, which still runs (forward and VJP) at every evaluation.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernels = the convolutions: Winograd F(2x2,3x3) where eligible,
-direct implicit GEMM elsewhere; fp32 MFMA bound; achieved = ALGORITHMIC (direct-convolution) flops / HIP-event time of
-the conv launches inside the timed region -- Winograd executes 2.25x fewer multiplies, which is why frac can approach 1) and `cpu_baseline` (the CPU oracle timed on
-this box's host cores on a bounded sample of the same workload; N=1 only).
+Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
+sample of the same workload; N=1 only).
+
+roofline: the dominant kernel is the Winograd F(2x2,3x3) convolution (conv_wino4_kernel; ~85 % of a step).  It is
+MFMA-bound, and what it ISSUES is 1/2.25 of the algorithmic (direct-convolution) flops, so
+    achieved = issued fp32 MFMA TFLOP/s = algorithmic flops of its launches / 2.25 / their HIP-event time,
+    frac     = achieved / 157.3 TFLOP/s  = the matrix-pipe utilisation (what rocprof's SQ_INSTS_MFMA x 512 flop / time gives),
+with the direct-equivalent figure, the other kernel families (direct implicit GEMM: TFLOP/s vs the same peak; LayerNorm:
+GB/s vs 8 TB/s) and their shares of the step alongside in `roofline.families`.  The step is replayed from a captured hipGraph
+in the timed region (`--graph 1`, default); the per-kernel HIP-event timings come from `--profile-steps` extra EAGER steps run
+after it (events cannot bracket launches inside a graph replay) -- same kernels, same shapes, outside `value`.
 """
 import argparse
 import json
@@ -71,6 +78,7 @@ class SyntheticScore(torch.nn.Module):
 
 
 def build_model(wl, device):
+    from sda_amd import observe as Ob
     from sda_amd.score import GaussianScore, MCScoreNet, VPSDE
     torch.manual_seed(0)
     if wl['kind'] == 'kolmogorov':
@@ -81,12 +89,12 @@ def build_model(wl, device):
                                     hidden_channels=K64['hidden_channels'], hidden_blocks=K64['hidden_blocks'],
                                     kernel_size=3, activation=ACTIVATIONS['SiLU'], spatial=2, padding_mode='circular')
         event = (wl['L'], wl['state'], wl['size'], wl['size'])
-        A = lambda x: x[..., ::4, ::4]
+        A = Ob.Subsample.space(4)                    # x[..., ::4, ::4] with a hand-written adjoint: no autograd through A
     else:
         from sda_amd.experiments.lorenz import make_global_score
         net = make_global_score(channels=wl['state'])
         event = (wl['L'], wl['state'])
-        A = lambda x: x[..., ::8, :1]
+        A = Ob.Subsample((slice(None, None, 8), slice(0, 1)))        # x[..., ::8, :1]
     return net, event, A
 
 
@@ -218,6 +226,50 @@ def cpu_baseline(wl, args, guided, corrections):
                        f'scaled by {nwin}/{total_windows}')
 
 
+PEAK_MFMA_F32 = 157.3      # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0          # GB/s
+
+
+def roofline_report(prof, prof_steps, step_s, args, root):
+    """Per kernel family, from HIP-event timings of `prof_steps` steps.  The dominant family's ISSUED MFMA rate over the fp32
+    matrix peak is `frac` (Winograd F(2x2,3x3) issues 1/2.25 of the algorithmic flops); the direct-equivalent rate is an extra."""
+    s = prof.summary()
+    fam = {}
+    for name, r in s['families'].items():
+        alg = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+        issued = alg / 2.25 if name.startswith('wino') else alg
+        fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
+                     'share_of_step': r['ms'] * 1e-3 / prof_steps / step_s,
+                     'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / PEAK_MFMA_F32,
+                     'avg_launch_ms': r['ms'] / max(1, r['launches']),
+                     'avg_launch_gflop_algorithmic': r['flops'] / max(1, r['launches']) / 1e9}
+    for name, r in prof.mem_summary().items():
+        gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
+        fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
+                     'share_of_step': r['ms'] * 1e-3 / prof_steps / step_s, 'bound': 'hbm',
+                     'algorithmic_GBps': gbs, 'frac_of_8TBps': gbs / PEAK_HBM}
+    conv = {k: v for k, v in fam.items() if 'issued_mfma_tflops' in v}
+    dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
+    traffic = None
+    tfile = os.path.join(root, 'profiles', f'r02_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
+    if os.path.exists(tfile):              # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+    kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
+              'wino': 'conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)',
+              'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)'}.get(dom, dom)
+    d = conv.get(dom, {})
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+            'frac': d.get('mfma_util'), 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
+            'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
+            'direct_equivalent_tflops': d.get('algorithmic_tflops'), 'avg_launch_ms': d.get('avg_launch_ms'),
+            'avg_launch_gflop_algorithmic': d.get('avg_launch_gflop_algorithmic'),
+            'timed_with': f'HIP events around every launch of {prof_steps} '
+                          + ('eager step(s) run after the graph-replayed timed region' if args.graph else 'timed step(s)'),
+            'all_conv_algorithmic_tflops': s['total_flops'] / (s['total_ms'] * 1e-3) / 1e12 if s['total_ms'] > 0 else None,
+            'conv_time_share_of_step': s['total_ms'] * 1e-3 / prof_steps / step_s,
+            'families': fam}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -233,7 +285,9 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = calibrate: fastest of 8..128 threads on a probe conv')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--graph', type=int, default=0, help='1: replay each step from a captured hipGraph')
+    ap.add_argument('--graph', type=int, default=1, help='1 (default): replay each step from a captured hipGraph')
+    ap.add_argument('--profile-steps', type=int, default=1, help='extra eager steps (outside the timed region) for the per-kernel HIP-event timings when --graph 1')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help="weak: every rank owns a configuration shard (N = 8 is the configuration itself); strong: the 8-shard global batch is split over the ranks")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -258,18 +312,38 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.per_gpu:
         wl['per_gpu'] = args.per_gpu
+    if args.scaling == 'strong':
+        # the global batch of the configuration (per_gpu x 8) is fixed and split over the ranks
+        global_batch = wl['per_gpu'] * 8
+        lo, hi = parallel.shard_range(global_batch, rank, world)
+        b = hi - lo
+    else:
+        b = wl['per_gpu']
+        global_batch = b * world
+        lo = rank * b
     net, event, A = build_model(wl, device)
-    b = wl['per_gpu']
-    global_batch = b * world
     score = SyntheticScore(net)
     inner = VPSDE(score, shape=())
     object.__setattr__(score, '_sched', inner)       # plain attribute: not a submodule (inner.eps is score)
-    torch.manual_seed(2)
-    y = torch.randn(A(torch.empty((b,) + event)).shape)
+    # observation of this rank's rows: row i of the global y is keyed by i, like the noise (any world size sees the same y)
+    oshape = (event[0], event[1], event[2] // 4, event[3] // 4) if wl['kind'] == 'kolmogorov' else ((event[0] + 7) // 8, 1)
+    y = parallel.sharded_initial_noise(global_batch, oshape, 2, rank, world) if args.scaling == 'strong' else \
+        torch.stack([torch.randn(oshape, generator=torch.Generator().manual_seed(2000003 + lo + i)) for i in range(b)])
     eps_mod = GaussianScore(y, A=A, std=0.1, sde=inner) if args.guided else score
     sde = VPSDE(eps_mod, shape=event).to(device)
-    # every rank draws its rows of the global noise stream (1-GPU and N-GPU jobs sample the same trajectories)
-    sde.initial_noise = parallel.sharded_initial_noise(global_batch, event, 1, rank, world)
+    # every rank draws its rows of the row-keyed noise streams: 1-GPU and N-GPU jobs sample the same trajectories, ranks draw
+    # distinct noise, nothing scales with the world size, and the corrector draw is graph-capturable (sda_randn_rows)
+    if args.scaling == 'strong':
+        sde.initial_noise = parallel.sharded_initial_noise(global_batch, event, 1, rank, world)
+    else:
+        gen = torch.Generator()
+        rows = []
+        for i in range(lo, lo + b):
+            gen.manual_seed((1 * 1000003 + i) & 0x7fffffffffffffff)
+            rows.append(torch.randn(tuple(event), generator=gen))
+        sde.initial_noise = torch.stack(rows)
+    if args.corrections > 0:
+        sde.noise_source = parallel.KeyedNoise((lo, lo + b), event, 2, args.corrections, device)
     sampler = sde.sampler((b,), steps=1000, corrections=args.corrections, tau=args.tau)
 
     def sync():
@@ -278,14 +352,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)           # the RCCL barrier is itself stream work
 
+    graph_note = None
     if args.graph:
-        sampler.capture()
+        try:
+            sampler.capture()
+        except Exception as e:  # noqa: BLE001 -- e.g. the graph's private pool does not fit next to the eager allocations
+            graph_note = f'capture failed, ran eagerly: {type(e).__name__}: {str(e)[:200]}'
+            args.graph = 0
+            torch.cuda.synchronize(device)
+            sampler = sde.sampler((b,), steps=1000, corrections=args.corrections, tau=args.tau)
     for _ in range(args.warmup):
         sampler.step()
     sync()
     prof = None
     if rank == 0 and not args.no_profile and not args.graph:
-        prof = ops.ConvProfile()
+        prof = ops.ConvProfile()                     # eager timed region: the events bracket the timed launches themselves
         ops.conv_profile = prof
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -297,6 +378,19 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+    prof_steps = 0
+    if rank == 0 and not args.no_profile and args.graph and args.profile_steps > 0:
+        # events cannot bracket launches inside a graph replay: time the same kernels in extra EAGER steps, outside `value`
+        sampler._graph = None
+        prof = ops.ConvProfile()
+        ops.conv_profile = prof
+        for _ in range(args.profile_steps):
+            sampler.step()
+        torch.cuda.synchronize(device)
+        ops.conv_profile = None
+        prof_steps = args.profile_steps
+    elif prof is not None:
+        prof_steps = args.steps
 
     finite = bool(torch.isfinite(sampler.x).all().item())
     # the one collective of the job: gather the samples (after the loop; not part of a step)
@@ -307,33 +401,28 @@ def main():
     assert gathered.shape[0] == global_batch
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        # unit of `value`: one diffusion step of one configuration shard (per_gpu trajectories); weak scaling: every rank
+        # advances one shard per step; strong scaling: the job advances the 8-shard global batch once per step
+        shards_per_step = world if args.scaling == 'weak' else 8
+        value = shards_per_step * args.steps / elapsed
         out = {
             'metric': 'diffusion-steps/s (Kolmogorov 64x256x256 posterior sampling; unit = one predictor-corrector step of a '
                       '16-trajectory per-GPU shard)' if args.workload == 'kolmogorov256' else f'diffusion-steps/s ({args.workload})',
             'value': value, 'unit': 'diffusion-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (random-init net + exact Gaussian term, synthetic observations)',
             'config': {'workload': args.workload, 'description': wl['desc'], 'event': list(event),
                        'per_gpu_batch': b, 'global_batch': global_batch, 'guided': bool(args.guided),
                        'corrections': args.corrections, 'tau': args.tau, 'schedule_steps': 1000,
-                       'score_evals_per_step': 1 + args.corrections, 'hipgraph_step': bool(args.graph), 'parallelism': f'dp{world} (batch-sharded, no in-loop collective)'},
+                       'score_evals_per_step': 1 + args.corrections, 'hipgraph_step': bool(args.graph), 'hipgraph_note': graph_note,
+                       'observation': 'fused Subsample (hand-written adjoint; no autograd through A)',
+                       'corrector_noise': 'row-keyed Philox (sda_randn_rows)',
+                       'parallelism': f'dp{world} (batch-sharded, no in-loop collective)'},
             'wallclock_per_1000_steps_s': elapsed / args.steps * 1000,
             'samples_finite': finite, 'final_allgather_ms': gather_ms,
         }
-        if prof is not None:
-            s = prof.summary()
-            ach = s['total_flops'] / (s['total_ms'] * 1e-3) / 1e12 if s['total_ms'] > 0 else 0.0
-            traffic = None
-            tfile = os.path.join(ROOT, 'profiles', f'r01_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
-            if os.path.exists(tfile):          # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command
-                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_wino_kernel + conv_igemm_ws_kernel (fp32 v_mfma_f32_32x32x2_f32; all convolution launches)', 'achieved': ach,
-                               'peak': 157.3, 'unit': 'TFLOP/s', 'frac': ach / 157.3, 'traffic': traffic,
-                               'traffic_source': os.path.basename(tfile) if traffic is not None else None,
-                               'launches': s['launches'], 'avg_launch_ms': s['total_ms'] / max(1, s['launches']),
-                               'avg_launch_gflop': s['total_flops'] / max(1, s['launches']) / 1e9,
-                               'conv_time_share_of_step': s['total_ms'] * 1e-3 / elapsed}
+        if prof is not None and prof_steps > 0:
+            out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, args, bool(args.guided), args.corrections)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']

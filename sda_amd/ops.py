@@ -87,16 +87,35 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
 
 
 class ConvProfile:
-    """Live timing of the dominant kernel for bench.py's roofline leg: when installed as ``ops.conv_profile`` every
-    conv_igemm launch is bracketed by HIP events on the launch stream and its ALGORITHMIC flops are recorded
-    (2 * n * out-pixels * cout * cin * taps over the real channels; zero-inserted taps are not counted)."""
+    """Live timing of the kernels for bench.py's roofline leg: when installed as ``ops.conv_profile`` every conv_igemm
+    launch is bracketed by HIP events on the launch stream and its ALGORITHMIC flops are recorded (2 * n * out-pixels *
+    cout * cin * taps over the real channels; zero-inserted taps are not counted), by kernel family; the HBM-bound LayerNorm
+    kernels are bracketed the same way with their algorithmic bytes (one read / write per operand)."""
 
     def __init__(self):
         self.records = []          # (start_event, stop_event, flops, family)
+        self.mem_records = []      # (start_event, stop_event, bytes, kernel)
 
     def flops(self, d: ConvDesc) -> float:
         pixels = d.ho * d.wo / (d.zins_h * d.zins_w)
         return 2.0 * d.n * pixels * d.cout * (d.cx + d.cctx) * d.kh * d.kw
+
+    def bracket_mem(self, kernel: str, nbytes: float, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.mem_records.append((e0, e1, nbytes, kernel))
+
+    def mem_summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for a, b, nb, k in self.mem_records:
+            r = out.setdefault(k, dict(launches=0, ms=0.0, bytes=0.0))
+            r['launches'] += 1
+            r['ms'] += a.elapsed_time(b)
+            r['bytes'] += nb
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
@@ -183,8 +202,14 @@ def ln_stats(x: Tensor, mod: Optional[Tensor], mod_sn: int, eps: float, unbiased
     _dev(x, mod, mean, rstd)
     n, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
-    _lib.check(_lib.load().sda_ln_stats(x.data_ptr(), n, c, hw, _ptr(mod), mod_sn, eps, int(unbiased),
-                                        mean.data_ptr(), rstd.data_ptr(), _stream()), 'sda_ln_stats')
+
+    def launch():
+        _lib.check(_lib.load().sda_ln_stats(x.data_ptr(), n, c, hw, _ptr(mod), mod_sn, eps, int(unbiased),
+                                            mean.data_ptr(), rstd.data_ptr(), _stream()), 'sda_ln_stats')
+    if conv_profile is not None:
+        conv_profile.bracket_mem('ln_stats', 4.0 * n * hw * (c + 2), launch)       # read x once, write mean + rstd
+    else:
+        launch()
 
 
 def ln_apply(x: Tensor, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: Tensor, y: Tensor):
@@ -200,9 +225,17 @@ def ln_bwd(gh: Tensor, x: Tensor, h: int, w: int, mod: Optional[Tensor], mod_sn:
     """pool: (pool_h, pool_w) -- the nearest-upsample factors whose backward (cell sums of gh) is fused in; (1, 1) = none."""
     _dev(gh, x, mod, mean, rstd, res, gx)
     n, c = x.shape[0], x.shape[1]
-    _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
-                                      rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(), _stream()),
-               'sda_ln_bwd')
+
+    def launch():
+        _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
+                                          rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(),
+                                          _stream()), 'sda_ln_bwd')
+    if conv_profile is not None:
+        # read gh (at the pooled resolution), x, res; write gx; + the statistics
+        nb = 4.0 * n * h * w * (c * (pool[0] * pool[1] + 2 + (1 if res is not None else 0)) + 2)
+        conv_profile.bracket_mem('ln_bwd', nb, launch)
+    else:
+        launch()
 
 
 # ------------------------------------------------------------------------------------------ time embedding

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Scaling curve of bench.py on ONE node: N = 1, 2, 4, 8 ranks (one per GPU, RCCL), weak and strong.
+#   weak:   every rank owns a configuration shard (16 trajectories of 64x2x256x256); N = 8 is BASELINE configs[3] itself
+#   strong: the configuration's global batch (128 trajectories) is split over the ranks; N = 1 streams it in groups
+# usage: tools/run_scale.sh [outdir] [extra bench.py args...]      (no curve has been measured yet: no 8-GPU node was available)
+set -u
+OUT=${1:-gpurun_out/scale}; shift || true
+mkdir -p "$OUT"
+for mode in weak strong; do
+  for n in 1 2 4 8; do
+    steps=4; [ "$mode" = strong ] && [ "$n" -le 2 ] && steps=2
+    if [ "$n" = 1 ]; then
+      python bench.py --gpus 1 --steps $steps --warmup 1 --scaling $mode --no-cpu-baseline "$@" > "$OUT/${mode}_n$n.json" 2> "$OUT/${mode}_n$n.err"
+    else
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) \
+        bench.py --gpus $n --steps $steps --warmup 1 --scaling $mode --no-cpu-baseline "$@" > "$OUT/${mode}_n$n.json" 2> "$OUT/${mode}_n$n.err"
+    fi
+    tail -c 400 "$OUT/${mode}_n$n.json"; echo
+  done
+done
+python - "$OUT" <<'PY'
+import glob, json, sys
+for mode in ('weak', 'strong'):
+    rows = {}
+    for f in glob.glob(f'{sys.argv[1]}/{mode}_n*.json'):
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1]); rows[d['n_gpus']] = d['value']
+        except Exception:
+            pass
+    if 1 in rows:
+        print(mode, {n: f'{v:.4f} steps/s ({v / rows[1]:.2f}x)' for n, v in sorted(rows.items())})
+PY
