@@ -38,11 +38,11 @@
                                        // 32-lane half reads with ds_read_b64 cover the 64 banks exactly once
 #define W4_HPLANE (W4_HRW * W4_HS)     // 240 floats per channel
 #define W4_NSLOT 3                     // ceil(18 * 10 / 64) halo positions per lane and channel
-#define W4_UP (6 * 64 * 2)             // floats per position in a U buffer: [cout fragment 6][lane 64][k4 2]
-#define W4_UBUF (16 * W4_UP)           // 12288 floats = 48 KiB
-#define W4_VKQ 96                      // floats per kq plane of V: [tile 32][k4 2] + 32 floats of skew (ds_read_b64 banks)
-#define W4_VP (4 * W4_VKQ)             // floats per position in a V buffer
-#define W4_VBUF (16 * W4_VP)           // 6144 floats = 24 KiB
+#define W4_UPP (6 * 64 * 4)            // floats per position PAIR in a U buffer: [cout fragment 6][lane 64][h 2][k4 2]
+#define W4_UBUF (8 * W4_UPP)           // 12288 floats = 48 KiB
+#define W4_VKQ 128                     // floats per kq plane of V: [k4 2][tile 32][h 2]
+#define W4_VPP (4 * W4_VKQ)            // floats per position pair in a V buffer
+#define W4_VBUF (8 * W4_VPP)           // 4096 floats = 16 KiB
 #define W4_LDS_BYTES ((2 * W4_UBUF + 2 * W4_VBUF + 4 * 2 * W4_HPLANE) * 4)
 
 struct Wino4Geom {
@@ -98,7 +98,11 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     g->grid = (int)total;
     g->nstage = d->cin_pad / W4_CK;
     if ((int64_t)g->nstage * total > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+#ifdef SDA_W4_VARIANTS
+    g->debug = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0;      // (tooling build: re-read per launch)
+#else
     { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+#endif
     g->trace = nullptr;
     return SDA_OK;
 }
@@ -118,23 +122,35 @@ __device__ __forceinline__ W4Tile w4_decode(const Wino4Geom& g, int tile) {
 // stage cursor (all scalar): stage in tile + the decoded tile.  Stepping to the next stage / tile is an increment with
 // carries: consecutive tiles of a workgroup are the cout tiles of one block, then the next block along the row.
 struct W4Cur { int st, ct, bx, by, n; };
+// 1 if a == n else 0, for a <= n: pure integer arithmetic.  (A bool conjunction of uniform compares is lowered through lane
+// masks and a v_cndmask / v_readfirstlane pair -- vector instructions in a wave that must issue none.)
+__device__ __forceinline__ int w4_eq(int a, int n) { return (int)(((unsigned)(n - a) - 1u) >> 31); }
 __device__ __forceinline__ void w4_advance(const Wino4Geom& g, W4Cur& c) {
-    const bool t_next = c.st + 1 == g.nstage;
-    c.st = t_next ? 0 : c.st + 1;
-    const bool b_next = t_next && c.ct + 1 == g.n_ct;
-    c.ct = t_next ? (b_next ? 0 : c.ct + 1) : c.ct;
-    const bool y_next = b_next && c.bx + 1 == g.bx_n;
-    c.bx = b_next ? (y_next ? 0 : c.bx + 1) : c.bx;
-    const bool n_next = y_next && c.by + 1 == g.by_n;
-    c.by = y_next ? (n_next ? 0 : c.by + 1) : c.by;
-    c.n += n_next ? 1 : 0;
+    const int t_next = w4_eq(c.st + 1, g.nstage);
+    c.st = (c.st + 1) * (1 - t_next);
+    const int b_next = t_next * w4_eq(c.ct + 1, g.n_ct);
+    c.ct = (c.ct + t_next) * (1 - b_next);
+    const int y_next = b_next * w4_eq(c.bx + 1, g.bx_n);
+    c.bx = (c.bx + b_next) * (1 - y_next);
+    const int n_next = y_next * w4_eq(c.by + 1, g.by_n);
+    c.by = (c.by + y_next) * (1 - n_next);
+    c.n += n_next;
 }
 
 // phase stamps of the tracing variant (VAR == 11): T(k) adds the cycles since the previous stamp to phase k
-#define W4_TRACE_DECL long long w4tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long w4tl_ = 0; (void)w4tr_; (void)w4tl_
+#ifdef SDA_W4_ABLATE
+#define W4_DBG(b) (g.debug & (b))      // tooling builds: runtime ablation switches (SDA_CONV_DEBUG), timing experiments only
+#else
+#define W4_DBG(b) false
+#endif
+#define W4_TRACE_DECL long long w4tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long w4tl_ = 0, w4tb_ = 0; (void)w4tr_; (void)w4tl_; (void)w4tb_; if constexpr (VAR == 11) w4tb_ = __builtin_readcyclecounter()
 #define W4_T0() do { if constexpr (VAR == 11) w4tl_ = __builtin_readcyclecounter(); } while (0)
-#define W4_T(k) do { if constexpr (VAR == 11) { const long long n_ = __builtin_readcyclecounter(); w4tr_[k] += n_ - w4tl_; w4tl_ = n_; } } while (0)
-#define W4_TRACE_OUT() do { if constexpr (VAR == 11) { if (g.trace && lane == 0) for (int k_ = 0; k_ < 8; ++k_) g.trace[(blockIdx.x * 8 + wave) * 8 + k_] = w4tr_[k_]; } } while (0)
+#define W4_STAMP(k) do { if constexpr (VAR == 11) if (!(g.debug & 4096)) { const long long n_ = __builtin_readcyclecounter(); w4tr_[k] += n_ - w4tl_; w4tl_ = n_; } } while (0)
+// deferred stamps (VAR == 11, debug bit 8192): s_memtime into SGPRs, read only after the pause they bracket -- no wait in between
+#define W4_MARK(v) do { if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0" : "=s"(v) :: "memory"); } while (0)
+#define W4_MARK_ADD(k, a, b) do { if constexpr (VAR == 11) if (g.debug & 8192) w4tr_[k] += (long long)((b) - (a)); } while (0)
+#define W4_MARK_WAIT() do { if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define W4_TRACE_OUT() do { if constexpr (VAR == 11) { w4tr_[7] = __builtin_readcyclecounter() - w4tb_; if (g.trace && lane == 0) for (int k_ = 0; k_ < 8; ++k_) g.trace[(blockIdx.x * 8 + wave) * 8 + k_] = w4tr_[k_]; } } while (0)
 
 // Helper-wave global loads, hidden from the compiler's s_waitcnt bookkeeping.  The helpers keep loads in flight for several
 // loop iterations (the halo comes from HBM: ~2.5 us under load); hipcc's waitcnt insertion loses count across the loop's
@@ -150,7 +166,6 @@ __device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned of
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(OFF) : "memory");
 }
 
-__device__ __forceinline__ float* ubuf_of(float* ub, int p) { return ub + p * W4_UP; }
 
 // MOD / LN / SILU: the loader fusions of the launch (modulation add, LayerNorm, SiLU) as compile-time switches
 // VAR: ablation variant (0 = shipped; others exist only under -DSDA_W4_VARIANTS for tools/wino4_check.py --variants)
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // Halo addresses / liveness / LayerNorm statistics depend on the tile only: they are recomputed when the issue cursor
         // enters a new tile and travel with each register set.
         const int pw = wave - 4;
+        if (W4_DBG(8192)) return;                          // (ablation: consumers alone; ended waves leave the barriers)
         float* const priv = smem + 2 * W4_UBUF + 2 * W4_VBUF + pw * (2 * W4_HPLANE);
         // halo slot i of this lane: position lane + 64 i of the 10 x 18 halo -> (row, column); tile independent
         int hy[W4_NSLOT], hx[W4_NSLOT], lidx[W4_NSLOT];
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // lane (t, e): tile t = lane & 31 = (ty, tx) = (t >> 3, t & 7), channel e = lane >> 5 of the wave's pair
         const int pe = lane >> 5;
         const int pbase = pe * W4_HPLANE + (2 * ((lane & 31) >> 3)) * W4_HS + 2 * (lane & 7);
-        const int vwr = pw * W4_VKQ + (lane & 31) * 2 + pe;
+        const int vwr = pw * W4_VKQ + lane * 2;                 // [k4 = pe][tile][h]: lane-linear 8-byte stores, no bank conflicts
         const unsigned lane16 = lane * 16u;
 
         // per-tile halo geometry of the issue cursor
@@ -316,35 +332,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             }
             float* dst = vb + vwr;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {                  // columns, same combination
-                dst[(4 * a + 0) * W4_VP] = u[a][0] - u[a][2];
-                dst[(4 * a + 1) * W4_VP] = u[a][1] + u[a][2];
-                dst[(4 * a + 2) * W4_VP] = u[a][2] - u[a][1];
-                dst[(4 * a + 3) * W4_VP] = u[a][1] - u[a][3];
+            for (int a = 0; a < 4; ++a) {                  // columns, same combination; p = 4 a + b -> pair 2 a + (b >> 1), h = b & 1
+                *reinterpret_cast<f32x2*>(dst + (2 * a + 0) * W4_VPP) = f32x2{u[a][0] - u[a][2], u[a][1] + u[a][2]};
+                *reinterpret_cast<f32x2*>(dst + (2 * a + 1) * W4_VPP) = f32x2{u[a][2] - u[a][1], u[a][1] - u[a][3]};
             }
         };
-        // U slab, positions 4 pw .. 4 pw + 3 of a stage: 12 KiB = 12 wave-wide dwordx4
+        // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 12 KiB = 12 wave-wide dwordx4 (one per cout fragment and pair)
         f32x4 ureg[12];
         auto u_load = [&](const W4Cur& t) {
-            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 16 + 4 * pw) * g.mtiles + 6 * t.ct) * 128);
-            const int64_t pstride = (int64_t)g.mtiles * 512;          // bytes between positions
+            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
+            const int64_t pstride = (int64_t)g.mtiles * 1024;         // bytes between position pairs
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
+            for (int pp = 0; pp < 2; ++pp) {
                 const char* sp = src + pp * pstride;
-                w4_ld4<0>(ureg[pp * 3 + 0], sp, lane16);
-                w4_ld4<1024>(ureg[pp * 3 + 1], sp, lane16);
-                w4_ld4<2048>(ureg[pp * 3 + 2], sp, lane16);
+                const char* sq = sp + 3072;
+                w4_ld4<0>(ureg[pp * 6 + 0], sp, lane16);
+                w4_ld4<1024>(ureg[pp * 6 + 1], sp, lane16);
+                w4_ld4<2048>(ureg[pp * 6 + 2], sp, lane16);
+                w4_ld4<0>(ureg[pp * 6 + 3], sq, lane16);
+                w4_ld4<1024>(ureg[pp * 6 + 4], sq, lane16);
+                w4_ld4<2048>(ureg[pp * 6 + 5], sq, lane16);
             }
         };
 #define W4_WAIT_U(N)                                                                                                           \
     asm volatile("s_waitcnt vmcnt(%12)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
                  "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]) : "n"(N) : "memory")
         auto u_store = [&](float* ub) {
-            float* dst = ub + (4 * pw) * W4_UP + lane * 4;
+            float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
+            for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int ck = 0; ck < 3; ++ck) *reinterpret_cast<f32x4*>(dst + pp * W4_UP + ck * 256) = ureg[pp * 3 + ck];
+                for (int m = 0; m < 6; ++m) *reinterpret_cast<f32x4*>(dst + pp * W4_UPP + m * 256) = ureg[pp * 6 + m];
         };
         // hand-off: this wave's LDS writes have landed; its global loads stay in flight across the barrier
         auto handoff = [&]() {
@@ -357,11 +375,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         W4Cur c2 = c0, ci = c0;
         int q2 = 0, qi = 0;                                // stage indices of c2, ci
         auto step2 = [&]() { if (q2 + 1 < Q) { w4_advance(g, c2); ++q2; } };
-        auto step_issue = [&]() {
+        bool new_tile = false;
+        auto step_issue_cursor = [&]() {                   // scalar only
+            new_tile = false;
             if (qi + 1 < Q) {
                 w4_advance(g, ci); ++qi;
-                if (ci.st == 0) geometry(ci);              // (a new tile; one stage per tile: every time)
+                new_tile = ci.st == 0;                     // (one stage per tile: every time)
             }
+        };
+        auto step_issue = [&]() {
+            step_issue_cursor();
+            if (new_tile) geometry(ci);
         };
         W4_TRACE_DECL;
         constexpr int NHL = 2 * W4_NSLOT, NUL = 12;        // loads per halo set / per U slab quarter
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         issue(ci, h0); tag(h0); step_issue();
         issue(ci, h1); tag(h1); step_issue();
         issue(ci, h2); tag(h2); step_issue();
-        issue(ci, h3); tag(h3); step_issue();
+        issue(ci, h3); tag(h3);
         u_load(c2);
         W4_WAIT_HALO(3 * NHL + NUL, h0);
         commit(c2, h0);
@@ -385,44 +409,70 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         W4_WAIT_HALO(NUL, h1);
         commit(c2, h1);
         step2();
-        issue(ci, h0); tag(h0); step_issue();
+        step_issue();
+        issue(ci, h0); tag(h0);
         handoff();
         // One helper iteration, while the consumers multiply stage q.  The fp32 MFMA stream owns the SIMD's vector ALU: a
         // sibling's VALU instruction does not issue at all until the stream pauses (tools/mfma_shadow_gen.py, p_* / x_* rows),
-        // while its LDS, scalar and vector-memory instructions do.  So an iteration has a non-VALU part that runs beside the
-        // MFMAs -- U registers -> LDS, the global loads of the coming stages, the patch reads of stage q + 1 -- and a short
-        // VALU part that runs when the consumers reach the stage barrier: B^T d B of stage q + 1 and the loader fusions of
-        // stage q + 2 (different stages, so no LDS round trip separates them).
+        // while its LDS, scalar and vector-memory instructions do.  A stage therefore has TWO workgroup barriers:
+        //   M_q  after the consumers' step 3: the deliberate pause.  The helpers arrive with their VALU work queued -- B^T d B
+        //        of stage q + 1 (patch already in registers), the loader fusions of stage q + 2, the cursor / geometry update --
+        //        which executes while the consumers wait here; its LDS writes drain behind the MFMAs of steps 4-6.
+        //   E_q  after the consumers' step 6: the hand-off of the stage q + 1 buffers.  Nobody waits at it in the steady state
+        //        (the helpers' remaining work is vector memory only), and the consumers fetch the first operands of stage q + 1
+        //        under the MFMAs of step 7 -- no LDS round trip between stages.
+        // Before M_q the helper runs what needs no VALU: U registers -> LDS, the U loads of stage q + 2, the patch reads of
+        // stage q + 1; between M_q and E_q the halo loads of stage q + 5.
         auto iteration = [&](int q, Halo& hcommit, Halo& hissue) {
             float* ub = ubuf + ((q + 1) & 1) * W4_UBUF;
             float* vb = vbuf + ((q + 1) & 1) * W4_VBUF;
             W4_T0();
             // the U registers were loaded one iteration ago, before that iteration's halo loads
             W4_WAIT_U(NHL);
-            if constexpr (VAR != 6) u_store(ub);
+            if (!W4_DBG(16)) u_store(ub);
             if constexpr (VAR == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_T(0);                                       // U registers -> LDS (incl. the wait for their loads)
+            W4_STAMP(0);                                       // U registers -> LDS (incl. the wait for their loads)
             __builtin_amdgcn_sched_barrier(0);
-            u_load(c2);                                    // (always: the hand-written wait counts assume both load groups)
+            if (!W4_DBG(256)) u_load(c2);                  // (the hand-written wait counts assume both load groups)
             __builtin_amdgcn_sched_barrier(0);
-            issue(ci, hissue);
-            __builtin_amdgcn_sched_barrier(0);
-            patch_read();                                  // halo of stage q + 1 (committed during the previous iteration)
-            __builtin_amdgcn_sched_barrier(0);
-            // the set committed now (stage q + 2) was issued three iterations ago: 3 x (U + halo) loads came after it
-            W4_WAIT_HALO(3 * (NHL + NUL), hcommit);
-            if (raw_commit) commit_raw(hcommit);
-            W4_T(1);                                       // load issue + patch reads (+ the VALU-free commit)
-            __builtin_amdgcn_sched_barrier(0);
-            transform(vb);
-            if (!raw_commit) commit(c2, hcommit);
-            tag(hissue);
-            step_issue();
+            // cursor arithmetic (scalar, ~60 instructions): here, beside the MFMAs, not in the pause
+            const W4Cur ccommit = c2;
             step2();
-            if constexpr (VAR == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_T(2);                                       // the VALU part
-            handoff();
-            W4_T(3);                                       // barrier wait
+            step_issue_cursor();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!W4_DBG(64)) patch_read();   // halo of stage q + 1 (committed during the previous iteration)
+            __builtin_amdgcn_sched_barrier(0);
+            // the set committed now (stage q + 2) was issued three iterations ago; behind it: the (U + halo) loads of two
+            // iterations and this iteration's U loads
+            W4_WAIT_HALO(2 * (NHL + NUL) + NUL, hcommit);
+            if (raw_commit && !W4_DBG(128)) commit_raw(hcommit);
+            W4_STAMP(1);                                       // U loads + patch reads (+ the VALU-free commit)
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long mk0 = 0, mk1 = 0, mk2 = 0, mk3 = 0;
+            W4_MARK(mk0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!W4_DBG(32)) transform(vb);
+            __builtin_amdgcn_sched_barrier(0);
+            W4_MARK(mk1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!raw_commit) commit(ccommit, hcommit);
+            if (new_tile) geometry(ci);
+            tag(hissue);
+            __builtin_amdgcn_sched_barrier(0);
+            W4_MARK(mk2);
+            W4_STAMP(2);                                       // the VALU part
+            __builtin_amdgcn_sched_barrier(0);
+            if (!W4_DBG(512)) __builtin_amdgcn_s_barrier();                  // M_q
+            asm volatile("" ::: "memory");
+            if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mk3), "+s"(mk0), "+s"(mk1), "+s"(mk2) :: "memory");
+            W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
+            W4_STAMP(3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!W4_DBG(256)) issue(ci, hissue);
+            __builtin_amdgcn_sched_barrier(0);
+            W4_STAMP(4);                                       // halo loads
+            handoff();                                     // E_q
+            W4_STAMP(5);
         };
         for (int q = 0; q < Q; q += 4) {
             iteration(q, h2, h1);
@@ -438,62 +488,112 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     // ====================================================================== consumers (MFMA + LDS reads only in the loop)
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kq = lane >> 4;
-    // A fragment of (position p, cout fragment m): U[p][3 wm + m][lane][0..1];  B fragment: V[p][kq][16 wn + li][0..1]
-    const int ard = (3 * wm * 64 + lane) * 2;
+    // A fragments of (position pair s, cout fragment m): U[s][3 wm + m][lane][h][k4] -- one ds_read_b128 = the operands of
+    // positions 2 s, 2 s + 1 and both K quads;  B fragments: V[s][kq][k4][16 wn + li][h], two 8-byte reads (one ds_read2_b64).  (ds_read_b128 moves 256 B per LDS
+    // clock, ds_read2_b64 half of that: tools/w4_feed_gen.py -- the cheaper read is also worth ~5 % of shader clock here,
+    // the kernel runs at the power limit.)
+    const int ard = (3 * wm * 64 + lane) * 4;
     const int brd = kq * W4_VKQ + (16 * wn + li) * 2;
     f32x4 acc[16][3];
     W4_TRACE_DECL;
     __syncthreads();                                       // stage 0 is in buffer 0
     int q = 0;
     W4_T0();
-    // one K-stage: two positions per step -- 8 LDS reads, then 12 MFMAs; the operands of step s + 1 are read during step s.
+    // one K-stage: two positions per step -- 8 LDS reads, then 12 MFMAs; the operands of step s + 1 are read during step s,
+    // those of the NEXT stage's step 0 during step 7 (after the hand-off barrier E_q, see the helpers).
     // FIRST: the tile's first stage starts its accumulators from the C operand instead of reading them -- zero, or the bias
     // for position p = 5 = (xi, nu) = (1, 1): A^T e_11 A is the all-ones 2 x 2 block, so a bias placed there comes out of the
     // inverse transform added to every output pixel (no zero-fill and no bias adds in the epilogue).
+    f32x4 av[2][3];
+    f32x2 bv[2][2];                                        // [buffer][k4] -> (h = 0, h = 1)
+    auto fetch = [&](int qq, int s, int buf) {
+        const float* ua = ubuf + (qq & 1) * W4_UBUF + ard;
+        const float* va = vbuf + (qq & 1) * W4_VBUF + brd;
+        // (volatile: keeps two ds_read_b64 with immediate offsets; merged into a ds_read2_b64 they would need a vector add
+        // per step for the base -- the pair stride exceeds read2's offset range -- and read at half the LDS rate)
+        typedef const volatile f32x2 __attribute__((address_space(3))) * lds_cv2;
+        bv[buf][0] = *(lds_cv2)(va + s * W4_VPP);
+        bv[buf][1] = *(lds_cv2)(va + s * W4_VPP + 64);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + s * W4_UPP + m * 256);
+    };
+    fetch(0, 0, 0);
+    int adv_t = 0, adv_b = 0, adv_y = 0;
     auto stage = [&](auto FIRST_, const f32x4 (&binit)[3]) {
         constexpr bool FIRST = decltype(FIRST_)::value;
-        const float* ua = ubuf + (q & 1) * W4_UBUF + ard;
-        const float* va = vbuf + (q & 1) * W4_VBUF + brd;
-        f32x2 av[2][2][3], bv[2][2];
-        auto fetch = [&](int s, int buf) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = 2 * s + h;
-                bv[buf][h] = *reinterpret_cast<const f32x2*>(va + p * W4_VP);
-#pragma unroll
-                for (int m = 0; m < 3; ++m) av[buf][h][m] = *reinterpret_cast<const f32x2*>(ua + p * W4_UP + m * 128);
-            }
-        };
-        fetch(0, 0);
         w4_static_for<0, 8>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            if constexpr (s + 1 < 8) fetch(s + 1, (s + 1) & 1);
+            if constexpr (s + 1 < 8) fetch(q, s + 1, (s + 1) & 1);
+            else fetch(q + 1, 0, 0);
+            // MFMA order (m, k4, h): the two MFMAs of one accumulator are two apart, and the fragments of cout block m are
+            // needed only from the (4 m)-th MFMA on
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        constexpr int dummy = 0; (void)dummy;
+                    for (int h = 0; h < 2; ++h) {
                         const int p = 2 * s + h;
                         f32x4 c;
                         if (FIRST && k4 == 0) c = (p == 5) ? binit[m] : f32x4{0.f, 0.f, 0.f, 0.f};
                         else c = acc[p][m];
-                        acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][h][m][k4], bv[s & 1][h][k4], c, 0, 0, 0);
+                        acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][m][2 * h + k4], bv[s & 1][k4][h], c, 0, 0, 0);
                     }
-            // pin the software pipeline: the LDS reads of the NEXT step issue first (one group: the first DS instruction
-            // after an MFMA costs ~5 cycles, the following ones ~0.3), then this step's 12 MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            // pin the software pipeline: the four LDS reads of the NEXT step are spread between this step's MFMAs (a read
+            // issued right behind an MFMA costs the stream nothing, a group of four ~12 cycles) -- except in step 6, whose
+            // reads must have returned at the hand-off barrier that follows it
+            if constexpr (s == 6) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            // the cursor advance of a tile's later stages (scalar, ~40 dependent instructions) in four pieces between the
+            // steps: issued as one lump it leaves the matrix pipe idle for ~150 cycles, a piece hides behind an MFMA
+            if constexpr (!FIRST) {
+                if constexpr (s == 0) { adv_t = w4_eq(c0.st + 1, g.nstage); c0.st = (c0.st + 1) * (1 - adv_t); }
+                if constexpr (s == 1) { adv_b = adv_t * w4_eq(c0.ct + 1, g.n_ct); c0.ct = (c0.ct + adv_t) * (1 - adv_b); }
+                if constexpr (s == 2) { adv_y = adv_b * w4_eq(c0.bx + 1, g.bx_n); c0.bx = (c0.bx + adv_b) * (1 - adv_y); }
+                if constexpr (s == 4) {
+                    const int adv_n = adv_y * w4_eq(c0.by + 1, g.by_n);
+                    c0.by = (c0.by + adv_y) * (1 - adv_n);
+                    c0.n += adv_n;
+                }
+                if constexpr (s <= 4) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s == 3) {
+                // M_q: the helpers' vector-ALU work runs during this wait
+                W4_STAMP(0);
+                unsigned long long mc0 = 0, mc1 = 0;
+                W4_MARK(mc0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mc1), "+s"(mc0) :: "memory");
+                W4_MARK_ADD(1, mc0, mc1);
+                W4_STAMP(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s == 6) {
+                // E_q: every operand of stage q is in registers (step 7's were read during step 6), so the helpers may
+                // overwrite its buffers; stage q + 1 is complete in the other pair
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W4_STAMP(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                W4_STAMP(3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s == 7) W4_STAMP(0);
         });
-        // stage hand-off: this wave's reads of stage q have returned (lgkmcnt only: the epilogue's stores of the previous
-        // tile may still be draining and need not be waited for)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W4_T(0);                                           // multiply
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        W4_T(1);                                           // barrier wait
         ++q;
     };
     for (int tl = 0; tl < my_tiles; ++tl) {
@@ -506,8 +606,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         }
         stage(std::true_type{}, binit);
         for (int st = 1; st < g.nstage; ++st) {
-            w4_advance(g, c0);                             // (c0 ends on the tile's last stage: the tile of the epilogue)
-            stage(std::false_type{}, binit);
+            stage(std::false_type{}, binit);               // (advances c0: it ends on the tile's last stage, the epilogue's tile)
         }
         {
             // ---- epilogue of tile c0: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
@@ -576,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             }
         }
         w4_advance(g, c0);
-        W4_T(2);                                           // epilogue
+        W4_STAMP(2);                                           // epilogue
     }
     W4_TRACE_OUT();
 }
@@ -629,13 +728,6 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
 #ifdef SDA_W4_VARIANTS
             const char* ev = getenv("SDA_W4_VAR");
             switch (ev ? atoi(ev) : 0) {
-                case 4: return wino4_launch_t<false, false, false, 4>(d, g, grid, stream);     // no production (stale operands)
-                case 5: return wino4_launch_t<false, false, false, 5>(d, g, grid, stream);     // U DMA only
-                case 6: return wino4_launch_t<false, false, false, 6>(d, g, grid, stream);     // V production only
-                case 7: return wino4_launch_t<false, false, false, 7>(d, g, grid, stream);     // U DMA + halo commit, no transform
-                case 8: return wino4_launch_t<false, false, false, 8>(d, g, grid, stream);     // helpers at priority 3
-                case 9: return wino4_launch_t<false, false, false, 9>(d, g, grid, stream);     // helpers at priority 1
-                case 10: return wino4_launch_t<false, false, false, 10>(d, g, grid, stream);   // consumers at priority 3
                 case 11: {                                                                      // phase tracing
                     static long long* tbuf = nullptr;
                     if (!tbuf && hipMalloc(&tbuf, 256 * 64 * sizeof(long long)) != hipSuccess) return SDA_E_BADARG;
@@ -674,7 +766,7 @@ int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------- weight transform for this kernel (one-off per layer)
-// dst[stage][p][m tile][lane = 16 kq + i][k4]  <-  (G g G^T)[xi][nu] of the filter between contraction channel
+// dst[stage][position pair p >> 1][m tile][lane = 16 kq + i][h = p & 1][k4]  <-  (G g G^T)[xi][nu] of the filter between contraction channel
 // kk = 8 stage + 2 kq + k4 and output channel mm = 16 mtile + i;  forward (transpose = 0): kk = ci, mm = co;
 // backward-data (transpose = 1): kk = co, mm = ci, filter flipped.  k_pad % 8 == 0, m_pad % 96 == 0; padding is zero.
 __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin, int transpose, int cin_keep,
@@ -707,7 +799,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 const float uu = tmp[xi][0] * G[nu][0] + tmp[xi][1] * G[nu][1] + tmp[xi][2] * G[nu][2];
-                dst[((((int64_t)st * 16 + (xi * 4 + nu)) * mtiles + mt) * 64 + (kq_ * 16 + ii)) * 2 + k4] = uu;
+                const int pp = 2 * xi + (nu >> 1), h = nu & 1;         // position p = 4 xi + nu = 2 pp + h
+                dst[((((int64_t)st * 8 + pp) * mtiles + mt) * 64 + (kq_ * 16 + ii)) * 4 + 2 * h + k4] = uu;
             }
     }
 }

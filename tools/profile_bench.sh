@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench.py command line (run on the GPU box):
+# (only gpurun_out/ travels back from the GPU box: re-run the last three commands of this script here to fill profiles/)
 #   1. --kernel-trace --stats     -> profiles/<tag>_kernel_stats.csv   (per-kernel calls / total / average)
 #   2. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, counters alone) -> profiles/<tag>_traffic.json
 #      HBM bytes per convolution launch (conv_wino_kernel + conv_igemm*) = (2*FETCH_SIZE + WRITE_SIZE) * 1024   [gfx950: FETCH_SIZE reports half of a
@@ -13,24 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/bench.py "$@" --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-profile > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-profile > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/sq -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-profile > /dev/null 2> $OUT/sq.err
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-profile > /dev/null 2> $OUT/grbm.err
 cd $R
 python tools/rocpd_summary.py $(ls $OUT/trace/*.db | head -1) --csv profiles/${TAG}_kernel_stats.csv | head -8
 cp $OUT/bench_trace.json profiles/${TAG}_bench_under_rocprof.json
-python - "$OUT" "$TAG" <<'PY'
-import csv, glob, json, sys
-out, tag = sys.argv[1], sys.argv[2]
-def avg(which):
-    tot, n = 0.0, 0
-    for f in glob.glob(f'{out}/{which}/**/*counter_collection.csv', recursive=True):
-        for r in csv.DictReader(open(f)):
-            if 'conv_igemm' in r.get('Kernel_Name', '') or 'conv_wino' in r.get('Kernel_Name', ''):
-                tot += float(r['Counter_Value']); n += 1
-    return (tot / n if n else None), n
-f, nf = avg('fetch'); w, nw = avg('write')
-res = {'kernel': 'conv_wino_kernel + conv_igemm*', 'launches_fetch_pass': nf, 'launches_write_pass': nw,
-       'FETCH_SIZE_KiB_per_launch_raw': f, 'WRITE_SIZE_KiB_per_launch_raw': w,
-       'hbm_bytes_per_launch': None if f is None or w is None else (2 * f + w) * 1024,
-       'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads)'}
-json.dump(res, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
-print(res)
-PY
+python tools/profile_post.py "$OUT" "$TAG" profiles

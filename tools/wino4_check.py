@@ -127,6 +127,10 @@ def main():
     ap.add_argument('--variants', default='', help='comma list of SDA_W4_VAR values to time on the plain layers (needs a -DSDA_W4_VARIANTS build)')
     ap.add_argument('--skip-check', action='store_true')
     args = ap.parse_args()
+    if os.environ.get('W4_CLOCK'):
+        clock_ramp()
+    if os.environ.get('W4_ABLATE'):
+        ablate()
     if args.variants:
         variants([int(v) for v in args.variants.split(',') if int(v) != 11])
         if '11' in args.variants.split(','):
@@ -190,12 +194,77 @@ def variants(vs):
         print(f'{name:16s} ' + '  '.join(row), flush=True)
 
 
+def ablate():
+    """time the plain 96->96 @64 layer under the runtime ablation switches of a -DSDA_W4_VARIANTS build (results are
+    garbage with most of them: timing only) -> cycles per K-stage at the nominal 2.4 GHz"""
+    combos = [int(v) for v in os.environ.get('W4_ABLATE', '0').split(',')]
+    print('--- ablation (bits: 16 U store, 32 transform, 64 patch reads, 128 raw commit, 256 global loads, 512 no M barrier, '
+          '1024 no consumer LDS reads): ms | cycles per stage @2.4 GHz')
+    for name, cin, cout, h, n in (('96->96 @64', 96, 96, 64, 896), ('384->384 @16', 384, 384, 16, 896)):
+        x = torch.randn(n, cin, h, h, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        pk = ops.PackedConv(w, None)
+        out = torch.empty(n, cout, h, h, device=dev)
+        stages = n * (h // 8) * (h // 16) * (cout // 96) * (cin // 8) / 256
+        for dbg in combos:
+            os.environ['SDA_CONV_DEBUG'] = str(dbg)
+            for _ in range(2):
+                launch_conv(pk, planar_source(x), out, h, h, circular=True)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    launch_conv(pk, planar_source(x), out, h, h, circular=True)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 4)
+            print(f'{name:14s} debug={dbg:5d}: {best:7.3f} ms  {best * 2.4e6 / stages:7.0f} cycles/stage', flush=True)
+        os.environ['SDA_CONV_DEBUG'] = '0'
+
+
+def clock_ramp():
+    """shader clock over consecutive launches (total cycles of the tracing variant without stamps / launch wall time)"""
+    import ctypes
+    from sda_amd import _lib
+    lib = _lib.load()
+    lib.sda_w4_trace_read.argtypes = [ctypes.c_void_p]
+    os.environ['SDA_CONV_DEBUG'] = '4096'
+    os.environ['SDA_W4_VAR'] = '11'
+    cin = cout = 96; h = 64; n = 896
+    x = torch.randn(n, cin, h, h, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    pk = ops.PackedConv(w, None)
+    out = torch.empty(n, cout, h, h, device=dev)
+    buf = (ctypes.c_double * 64)()
+    rows = []
+    for i in range(60):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch_conv(pk, planar_source(x), out, h, h, circular=True)
+        e1.record()
+        torch.cuda.synchronize()
+        lib.sda_w4_trace_read(ctypes.cast(buf, ctypes.c_void_p))
+        rows.append((e0.elapsed_time(e1), buf[7]))
+    print('--- clock ramp, 96->96 @64 x 60 launches: ms | cycles per workgroup | GHz')
+    for i, (ms, cyc) in enumerate(rows):
+        if i < 10 or i % 10 == 9:
+            print(f'   launch {i:2d}: {ms:.3f} ms  {cyc:.0f} cycles  {cyc / ms / 1e6:.2f} GHz')
+    os.environ['SDA_CONV_DEBUG'] = '0'
+    os.environ['SDA_W4_VAR'] = '0'
+
+
 def trace():
     """phase cycle sums per wave role (SDA_W4_VAR=11 of a -DSDA_W4_VARIANTS build), plain 96->96 @64"""
     import ctypes
     from sda_amd import _lib
     lib = _lib.load()
-    for name, cin, cout, h, n in (('96->96 @64', 96, 96, 64, 896), ('384->384 @16', 384, 384, 16, 896)):
+    dbgs = [int(v) for v in os.environ.get('W4_TRACE_DEBUG', '0').split(',')]
+    for dbg in dbgs:
+      os.environ['SDA_CONV_DEBUG'] = str(dbg)
+      print(f'=== helper skips (debug bits: 16 U store, 32 transform, 64 patch reads, 128 raw commit) = {dbg}')
+      for name, cin, cout, h, n in (('96->96 @64', 96, 96, 64, 896), ('384->384 @16', 384, 384, 16, 896)):
         x = torch.randn(n, cin, h, h, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         pk = ops.PackedConv(w, None)
@@ -204,6 +273,12 @@ def trace():
         for _ in range(2):
             launch_conv(pk, planar_source(x), out, h, h, circular=True)
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch_conv(pk, planar_source(x), out, h, h, circular=True)
+        e1.record()
+        torch.cuda.synchronize()
+        wall_ms = e0.elapsed_time(e1)
         os.environ['SDA_W4_VAR'] = '0'
         buf = (ctypes.c_double * 64)()
         lib.sda_w4_trace_read.argtypes = [ctypes.c_void_p]
@@ -211,10 +286,11 @@ def trace():
         v = [buf[i] for i in range(64)]
         tiles = n * (h // 8) * (h // 16) * (cout // 96)
         stages = tiles * (cin // 8) / 256
-        print(f'--- trace {name}: rc={rc}, ~{stages:.0f} stages per workgroup; cycles per stage by wave and phase')
-        labels = {0: 'consumer [multiply, barrier, epilogue/tile]', 4: 'helper [U store, loads + patch reads, VALU part, barrier]'}
+        print(f'--- trace {name}: rc={rc}, ~{stages:.0f} stages per workgroup; cycles per stage by wave and phase; '
+              f'launch {wall_ms:.3f} ms -> shader clock {v[7] / (wall_ms * 1e-3) / 1e9:.2f} GHz')
+        labels = {0: 'consumer [multiply, M wait, epilogue, E wait]', 4: 'helper [U store, U loads + patch reads, VALU part, M wait, halo loads, E wait]'}
         for wv in range(8):
-            print(f'   wave {wv}: ' + ' '.join(f'{v[wv * 8 + k] / stages:8.0f}' for k in range(5)) + '   ' + labels.get(wv, ''))
+            print(f'   wave {wv}: ' + ' '.join(f'{v[wv * 8 + k] / stages:8.0f}' for k in range(6)) + f' | total {v[wv * 8 + 7] / stages:8.0f}   ' + labels.get(wv, ''))
 
 
 def bench():
@@ -252,6 +328,8 @@ def bench():
                     pk.wino4 = None
                 d = launch_conv(pk, planar_source(x), out, h, h, **kw)
                 path = ops.conv_path(d)
+                for _ in range(25):                        # (the shader clock takes ~10 launches / 30 ms to ramp up)
+                    launch_conv(pk, planar_source(x), out, h, h, **kw)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
