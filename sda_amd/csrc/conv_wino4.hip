@@ -355,8 +355,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             }
         };
 #define W4_WAIT_U(N)                                                                                                           \
-    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
-                 "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]) : "n"(N) : "memory")
+    asm volatile("s_waitcnt vmcnt(%14)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
+                 "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]), "+v"(pfreg[0]),   \
+                 "+v"(pfreg[1]) : "n"(N) : "memory")
         auto u_store = [&](float* ub) {
             float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
 #pragma unroll
@@ -369,6 +370,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+        };
+        // Epilogue operands (the residual / the activation-derivative input: one value per output element, read once, by the
+        // consumers, with nothing to hide the HBM round trip behind) are pulled into the XCD's L2 ahead of time: while the
+        // issue cursor is in the last three stages of a tile (the consumers are then 5 stages behind), each helper touches
+        // one dword of 64 of the tile's 768 64-byte row segments per iteration (lane -> cout plane 8 pw + (lane >> 3) (+ 32
+        // per stage), row lane & 7).  The destination registers are dummies (two, alternating: a load has retired by the U
+        // wait two iterations later, where both are pinned); launches without such an operand issue the load all the same,
+        // on the weights, so that the hand-counted vmcnt values do not depend on the launch.
+        const float* const pf_t = d.res ? d.res : d.dact_z;
+        const unsigned pf_off = (unsigned)(((pw * 8 + (lane >> 3)) * (d.ho * d.wo) + (lane & 7) * d.wo) * 4);
+        float pfreg[2] = {0.f, 0.f};
+        const int pf_first = g.nstage > 3 ? g.nstage - 3 : 0;
+        auto prefetch = [&](const W4Cur& t, float& dst) {
+            const int k = t.st - pf_first;
+            if (pf_t && k >= 0 && k < 3) {
+                const float* base = pf_t + ((int64_t)t.n * d.cout + W4_BM * t.ct + 32 * k) * ((int64_t)d.ho * d.wo) +
+                                    (8 * t.by) * d.wo + 16 * t.bx;
+                w4_ld1(dst, reinterpret_cast<const char*>(base), pf_off);
+            } else {
+                w4_ld1(dst, reinterpret_cast<const char*>(d.w_wino4), lane16);
+            }
         };
         // cursors: stage q + 2 (U load, halo commit) and stage q + 5 (halo issue), clamped to the last stage (which is then
         // produced again into buffers nobody reads)
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if (new_tile) geometry(ci);
         };
         W4_TRACE_DECL;
-        constexpr int NHL = 2 * W4_NSLOT, NUL = 12;        // loads per halo set / per U slab quarter
+        constexpr int NHL = 2 * W4_NSLOT, NUL = 12, NPF = 1;   // loads per halo set / per U slab quarter / per prefetch
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;
@@ -410,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         commit(c2, h1);
         step2();
         step_issue();
+        prefetch(ci, pfreg[1]);
         issue(ci, h0); tag(h0);
         handoff();
         // One helper iteration, while the consumers multiply stage q.  The fp32 MFMA stream owns the SIMD's vector ALU: a
@@ -423,12 +446,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         //        under the MFMAs of step 7 -- no LDS round trip between stages.
         // Before M_q the helper runs what needs no VALU: U registers -> LDS, the U loads of stage q + 2, the patch reads of
         // stage q + 1; between M_q and E_q the halo loads of stage q + 5.
-        auto iteration = [&](int q, Halo& hcommit, Halo& hissue) {
+        auto iteration = [&](int q, Halo& hcommit, Halo& hissue, float& pfdst) {
             float* ub = ubuf + ((q + 1) & 1) * W4_UBUF;
             float* vb = vbuf + ((q + 1) & 1) * W4_VBUF;
             W4_T0();
             // the U registers were loaded one iteration ago, before that iteration's halo loads
-            W4_WAIT_U(NHL);
+            W4_WAIT_U(NHL + NPF);
             if (!W4_DBG(16)) u_store(ub);
             if constexpr (VAR == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             W4_STAMP(0);                                       // U registers -> LDS (incl. the wait for their loads)
@@ -442,9 +465,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             __builtin_amdgcn_sched_barrier(0);
             if (!W4_DBG(64)) patch_read();   // halo of stage q + 1 (committed during the previous iteration)
             __builtin_amdgcn_sched_barrier(0);
-            // the set committed now (stage q + 2) was issued three iterations ago; behind it: the (U + halo) loads of two
-            // iterations and this iteration's U loads
-            W4_WAIT_HALO(2 * (NHL + NUL) + NUL, hcommit);
+            // the set committed now (stage q + 2) was issued three iterations ago; behind it: the (U + prefetch + halo) loads
+            // of two iterations and this iteration's U loads
+            W4_WAIT_HALO(2 * (NHL + NPF + NUL) + NUL, hcommit);
             if (raw_commit && !W4_DBG(128)) commit_raw(hcommit);
             W4_STAMP(1);                                       // U loads + patch reads (+ the VALU-free commit)
             __builtin_amdgcn_sched_barrier(0);
@@ -468,6 +491,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
             W4_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
+            prefetch(ci, pfdst);
             if (!W4_DBG(256)) issue(ci, hissue);
             __builtin_amdgcn_sched_barrier(0);
             W4_STAMP(4);                                       // halo loads
@@ -475,10 +499,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_STAMP(5);
         };
         for (int q = 0; q < Q; q += 4) {
-            iteration(q, h2, h1);
-            if (q + 1 < Q) iteration(q + 1, h3, h2);
-            if (q + 2 < Q) iteration(q + 2, h0, h3);
-            if (q + 3 < Q) iteration(q + 3, h1, h0);
+            iteration(q, h2, h1, pfreg[0]);
+            if (q + 1 < Q) iteration(q + 1, h3, h2, pfreg[1]);
+            if (q + 2 < Q) iteration(q + 2, h0, h3, pfreg[0]);
+            if (q + 3 < Q) iteration(q + 3, h1, h0, pfreg[1]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W4_TRACE_OUT();

@@ -264,18 +264,24 @@ def trace():
     for dbg in dbgs:
       os.environ['SDA_CONV_DEBUG'] = str(dbg)
       print(f'=== helper skips (debug bits: 16 U store, 32 transform, 64 patch reads, 128 raw commit) = {dbg}')
-      for name, cin, cout, h, n in (('96->96 @64', 96, 96, 64, 896), ('384->384 @16', 384, 384, 16, 896)):
+      for name, cin, cout, h, n, epi in (('96->96 @64', 96, 96, 64, 896, ''), ('96->96 @64 +dact', 96, 96, 64, 896, 'dact'),
+                                         ('96->96 @64 +res', 96, 96, 64, 896, 'res'), ('384->384 @16', 384, 384, 16, 896, '')):
         x = torch.randn(n, cin, h, h, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         pk = ops.PackedConv(w, None)
         out = torch.empty(n, cout, h, h, device=dev)
+        kw = dict(circular=True)
+        if epi == 'dact':
+            kw.update(dact_z=torch.randn_like(out), act_d=1)
+        if epi == 'res':
+            kw.update(res=torch.randn_like(out))
         os.environ['SDA_W4_VAR'] = '11'
-        for _ in range(2):
-            launch_conv(pk, planar_source(x), out, h, h, circular=True)
+        for _ in range(12):
+            launch_conv(pk, planar_source(x), out, h, h, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        launch_conv(pk, planar_source(x), out, h, h, circular=True)
+        launch_conv(pk, planar_source(x), out, h, h, **kw)
         e1.record()
         torch.cuda.synchronize()
         wall_ms = e0.elapsed_time(e1)
