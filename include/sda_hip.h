@@ -261,6 +261,10 @@ int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, int w, float
 int sda_pairwise_dist(const float* x, int m, const float* y, int n, int64_t d, int take_sqrt, float* out, void* stream);
 int sda_mmd_kernel_sums(const float* d2, int64_t count, double* partial, int nblocks, void* stream);
 int sda_assignment_cost(const float* cost, int n, double* total, int* col_of_row);
+/*   sda_transport_cost : HOST pointers.  The same LP for m != n samples (uniform marginals 1/m, 1/n; sda/utils.py:203-219 with
+ *       unequal sample counts): *total = min_P <P, cost>, an integral min-cost flow after scaling by m n.  cost: m x n row-major,
+ *       finite and >= 0. */
+int sda_transport_cost(const float* cost, int m, int n, double* total);
 
 #ifdef __cplusplus
 }

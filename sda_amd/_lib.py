@@ -93,6 +93,7 @@ SIGNATURES = {
     'sda_pairwise_dist': (c_int, [c_fp, c_int, c_fp, c_int, c_int64, c_int, c_fp, c_void_p]),
     'sda_mmd_kernel_sums': (c_int, [c_fp, c_int64, c_void_p, c_int, c_void_p]),
     'sda_assignment_cost': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'sda_transport_cost': (c_int, [c_void_p, c_int, c_int, c_void_p]),
 }
 
 _lib = None

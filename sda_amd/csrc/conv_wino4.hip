@@ -231,8 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         const unsigned lane16 = lane * 16u;
 
         // per-tile halo geometry of the issue cursor
-        unsigned goff[W4_NSLOT], glive = 0;
-        float gmean[W4_NSLOT], grstd[W4_NSLOT];
+        unsigned goff[W4_NSLOT], gstat[W4_NSLOT] = {0u, 0u, 0u}, glive = 0;   // gstat: byte offset of the pixel's LN statistics
         const float* gimg = d.x;
         auto geometry = [&](const W4Cur& t) {
             gimg = d.x + (int64_t)(t.n + d.x_n_off) * d.x_sn_outer;
@@ -248,16 +247,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const int sy = vy >> up_sh_h, sx = vx >> up_sh_w;
                 goff[i] = (unsigned)(sy * (int)d.x_sy + sx * (int)d.x_sx) * 4u;
                 glive |= ok ? (1u << i) : 0u;
-                gmean[i] = 0.f; grstd[i] = 1.f;
-                if constexpr (LN) {
-                    const int st = (t.n * d.hs + sy) * d.ws + sx;
-                    gmean[i] = d.ln_mean[st];
-                    grstd[i] = d.ln_rstd[st];
-                }
+                if constexpr (LN) gstat[i] = (unsigned)((t.n * d.hs + sy) * d.ws + sx) * 4u;
             }
         };
         // what travels from the issue of a stage's halo loads to their commit
-        struct Halo { float v[2][W4_NSLOT]; float mean[W4_NSLOT], rstd[W4_NSLOT]; unsigned live; };
+        // (mv: the modulation of the wave's two channels; mean / rstd: the LayerNorm statistics of the set's pixels -- loaded
+        // WITH the set, by the same hand-counted asm loads: fetched where they are used, through compiler-visible loads, each
+        // commit would drain every load the helper has in flight -- s_waitcnt vmcnt(0) inside the pause)
+        struct Halo { float v[2][W4_NSLOT]; float mean[W4_NSLOT], rstd[W4_NSLOT], mv[2]; unsigned live; };
         // (vector-memory and scalar instructions only: runs beside the consumers' MFMAs)
         auto issue = [&](const W4Cur& t, Halo& h) {
 #pragma unroll
@@ -267,21 +264,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const char* xc = reinterpret_cast<const char*>(gimg + (int64_t)cce * d.x_sc);
 #pragma unroll
                 for (int i = 0; i < W4_NSLOT; ++i) w4_ld1(h.v[ch][i], xc, goff[i]);
+                if constexpr (MOD) w4_ld1(h.mv[ch], reinterpret_cast<const char*>(d.mod + cce), 0u);
             }
-        };
-        // the geometry the set's loads were issued with (VALU copies: part of the pause work)
-        auto tag = [&](Halo& h) {
-            h.live = glive;
             if constexpr (LN) {
 #pragma unroll
-                for (int i = 0; i < W4_NSLOT; ++i) { h.mean[i] = gmean[i]; h.rstd[i] = grstd[i]; }
+                for (int i = 0; i < W4_NSLOT; ++i) {
+                    w4_ld1(h.mean[i], reinterpret_cast<const char*>(d.ln_mean), gstat[i]);
+                    w4_ld1(h.rstd[i], reinterpret_cast<const char*>(d.ln_rstd), gstat[i]);
+                }
             }
         };
+        // the geometry the set's loads were issued with (a VALU copy: part of the pause work)
+        auto tag = [&](Halo& h) { h.live = glive; };
         // wait until at most N of this wave's loads are outstanding; the set's registers pass through the statement, so that
         // nothing that reads them can be scheduled above it
 #define W4_WAIT_HALO(N, h)                                                                                                     \
-    asm volatile("s_waitcnt vmcnt(%6)" : "+v"((h).v[0][0]), "+v"((h).v[0][1]), "+v"((h).v[0][2]), "+v"((h).v[1][0]),             \
-                 "+v"((h).v[1][1]), "+v"((h).v[1][2]) : "n"(N) : "memory")
+    do {                                                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"((h).v[0][0]), "+v"((h).v[0][1]), "+v"((h).v[0][2]), "+v"((h).v[1][0]),         \
+                     "+v"((h).v[1][1]), "+v"((h).v[1][2]) : "n"((N) > 63 ? 63 : (N)) : "memory");   /* (6-bit counter: 63 is stricter) */ \
+        if constexpr (LN) asm volatile("" : "+v"((h).mean[0]), "+v"((h).mean[1]), "+v"((h).mean[2]), "+v"((h).rstd[0]),        \
+                                       "+v"((h).rstd[1]), "+v"((h).rstd[2]) :: "memory");                                      \
+        if constexpr (MOD) asm volatile("" : "+v"((h).mv[0]), "+v"((h).mv[1]) :: "memory");                                    \
+    } while (0)
         // a launch without loader fusions whose halo positions and channels all carry data (circular padding, cin % 8 == 0 --
         // every backward-data convolution of the reference nets) commits with plain LDS stores: no VALU, so the commit moves
         // into the part of the iteration that runs beside the MFMAs
@@ -297,17 +301,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             for (int ch = 0; ch < 2; ++ch) {
                 const int cc = W4_CK * t.st + 2 * pw + ch;
                 const bool real = cc < g.cin;              // wave uniform (false only in a partial last stage)
-                float mv = 0.f;
-                if constexpr (MOD) mv = d.mod[real ? cc : 0];
-                const unsigned keep = real ? h.live : 0u;
+                float val[W4_NSLOT];
 #pragma unroll
                 for (int i = 0; i < W4_NSLOT; ++i) {
                     float v = h.v[ch][i];
-                    if constexpr (MOD) v += mv;
+                    if constexpr (MOD) v += h.mv[ch];
                     if constexpr (LN) v = (v - h.mean[i]) * h.rstd[i];
                     if constexpr (SILU) v = sda_act(SDA_ACT_SILU, v);
+                    val[i] = v;
+                }
+                if (circ && real) {
+                    // every halo position carries data (a lane's slots beyond the 180 positions land on the padding cell)
+#pragma unroll
+                    for (int i = 0; i < W4_NSLOT; ++i) priv[ch * W4_HPLANE + lidx[i]] = val[i];
+                } else {
                     // padding / out-of-range positions and padded channels stage zeros
-                    priv[ch * W4_HPLANE + lidx[i]] = ((keep >> i) & 1u) ? v : 0.f;
+                    const unsigned keep = real ? h.live : 0u;
+#pragma unroll
+                    for (int i = 0; i < W4_NSLOT; ++i) priv[ch * W4_HPLANE + lidx[i]] = ((keep >> i) & 1u) ? val[i] : 0.f;
                 }
             }
         };
@@ -321,20 +332,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 phi[a] = *reinterpret_cast<const f32x2*>(src + a * W4_HS + 2);
             }
         };
-        // ... -> B^T d B -> V[p][pw][t][pe]
+        // ... -> B^T d B -> V[pair][pw][pe][t][h].  Sixteen packed adds (the compiler's own pairing needs a dozen moves on
+        // top): rows on the column pairs the patch reads delivered, u0 = d0 - d2, u1 = d1 + d2, u2 = d2 - d1, u3 = d1 - d3;
+        // columns with operand-half selects, (o0, o1) = (u0 - u2, u1 + u2) and (o2, o3) = (u2 - u1, u1 - u3) from the pairs
+        // A = (u0, u1), B = (u2, u3).
         auto transform = [&](float* vb) {
-            float u[4][4];                                 // rows: u0 = d0 - d2, u1 = d1 + d2, u2 = d2 - d1, u3 = d1 - d3
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float d0 = c < 2 ? plo[0][c & 1] : phi[0][c & 1], d1 = c < 2 ? plo[1][c & 1] : phi[1][c & 1];
-                const float d2 = c < 2 ? plo[2][c & 1] : phi[2][c & 1], d3 = c < 2 ? plo[3][c & 1] : phi[3][c & 1];
-                u[0][c] = d0 - d2; u[1][c] = d1 + d2; u[2][c] = d2 - d1; u[3][c] = d1 - d3;
-            }
+            f32x2 ua[4], ub[4];                            // [row] -> columns (0, 1) and (2, 3)
+            ua[0] = plo[0] - plo[2]; ub[0] = phi[0] - phi[2];
+            ua[1] = plo[1] + plo[2]; ub[1] = phi[1] + phi[2];
+            ua[2] = plo[2] - plo[1]; ub[2] = phi[2] - phi[1];
+            ua[3] = plo[1] - plo[3]; ub[3] = phi[1] - phi[3];
             float* dst = vb + vwr;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {                  // columns, same combination; p = 4 a + b -> pair 2 a + (b >> 1), h = b & 1
-                *reinterpret_cast<f32x2*>(dst + (2 * a + 0) * W4_VPP) = f32x2{u[a][0] - u[a][2], u[a][1] + u[a][2]};
-                *reinterpret_cast<f32x2*>(dst + (2 * a + 1) * W4_VPP) = f32x2{u[a][2] - u[a][1], u[a][1] - u[a][3]};
+            for (int a = 0; a < 4; ++a) {
+                f32x2 o01, o23;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(ua[a]), "v"(ub[a]));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o23) : "v"(ub[a]), "v"(ua[a]));
+                *reinterpret_cast<f32x2*>(dst + (2 * a + 0) * W4_VPP) = o01;       // positions 4 a + 0, 4 a + 1
+                *reinterpret_cast<f32x2*>(dst + (2 * a + 1) * W4_VPP) = o23;       // positions 4 a + 2, 4 a + 3
             }
         };
         // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 12 KiB = 12 wave-wide dwordx4 (one per cout fragment and pair)
@@ -410,7 +425,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if (new_tile) geometry(ci);
         };
         W4_TRACE_DECL;
-        constexpr int NHL = 2 * W4_NSLOT, NUL = 12, NPF = 1;   // loads per halo set / per U slab quarter / per prefetch
+        constexpr int NHL = 2 * W4_NSLOT + (LN ? 2 * W4_NSLOT : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
+        constexpr int NUL = 12, NPF = 1;                   // loads per U slab quarter / per prefetch
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;

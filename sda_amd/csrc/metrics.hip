@@ -150,3 +150,77 @@ extern "C" int sda_assignment_cost(const float* cost, int n, double* total, int*
     *total = sum;
     return SDA_OK;
 }
+
+// min over couplings P >= 0 with row sums 1/m and column sums 1/n of <P, cost>  (cost: m x n row-major, HOST memory): the
+// optimal-transport LP behind emd() for UNEQUAL sample counts (sda/utils.py:203-219 passes empty weight vectors to POT =
+// uniform marginals).  Scaled by m n the marginals are integers (every row ships n units, every column takes m), so this is
+// an integral min-cost flow on the complete bipartite graph: successive shortest paths with node potentials (dense Dijkstra
+// from all rows with supply left to the nearest column with demand left, early exit), augmenting by the bottleneck of
+// supply, demand and the flows on the path's backward arcs.  Double precision; O((m + n)^2) per augmentation.
+extern "C" int sda_transport_cost(const float* cost, int m, int n, double* total) {
+    if (!cost || !total || m <= 0 || n <= 0) return SDA_E_BADARG;
+    const double INF = std::numeric_limits<double>::infinity();
+    const int V = m + n;                                   // nodes: rows 0 .. m-1, columns m .. m+n-1
+    std::vector<long long> flow((size_t)m * n, 0), supply(m, n), demand(n, m);
+    std::vector<double> pi(V, 0.0), dist(V);
+    std::vector<int> prev(V);
+    std::vector<char> done(V);
+    long long left = (long long)m * n;
+    for (int64_t e = 0; e < (int64_t)m * n; ++e)
+        if (!(cost[e] >= 0.f) || !(cost[e] < std::numeric_limits<float>::infinity())) return SDA_E_BADARG;   // NaN / inf / negative
+    while (left > 0) {
+        for (int v = 0; v < V; ++v) { dist[v] = INF; done[v] = 0; prev[v] = -1; }
+        for (int i = 0; i < m; ++i) if (supply[i] > 0) dist[i] = 0.0;
+        int target = -1;
+        for (;;) {
+            int v = -1;
+            double best = INF;
+            for (int w = 0; w < V; ++w) if (!done[w] && dist[w] < best) { best = dist[w]; v = w; }
+            if (v < 0) return SDA_E_BADARG;                // (cannot happen: the graph is complete)
+            done[v] = 1;
+            if (v >= m) {
+                const int j = v - m;
+                if (demand[j] > 0) { target = v; break; }
+                for (int i = 0; i < m; ++i) {              // backward arcs j -> i where flow is routed
+                    if (done[i] || flow[(size_t)i * n + j] == 0) continue;
+                    double rc = -(double)cost[(size_t)i * n + j] + pi[v] - pi[i];
+                    if (rc < 0) rc = 0;                    // (round-off: reduced costs of flow arcs are zero)
+                    if (best + rc < dist[i]) { dist[i] = best + rc; prev[i] = v; }
+                }
+            } else {
+                const float* row = cost + (size_t)v * n;
+                for (int j = 0; j < n; ++j) {
+                    if (done[m + j]) continue;
+                    double rc = (double)row[j] + pi[v] - pi[m + j];
+                    if (rc < 0) rc = 0;
+                    if (best + rc < dist[m + j]) { dist[m + j] = best + rc; prev[m + j] = v; }
+                }
+            }
+        }
+        const double dt = dist[target];
+        for (int v = 0; v < V; ++v) pi[v] += (done[v] && dist[v] < dt) ? dist[v] : dt;
+        // bottleneck along the path
+        long long amount = demand[target - m];
+        int v = target;
+        while (prev[v] >= 0) {
+            const int p = prev[v];
+            if (p >= m) { const long long f = flow[(size_t)v * n + (p - m)]; if (f < amount) amount = f; }   // backward arc p -> v
+            v = p;
+        }
+        if (supply[v] < amount) amount = supply[v];
+        supply[v] -= amount;
+        demand[target - m] -= amount;
+        left -= amount;
+        v = target;
+        while (prev[v] >= 0) {
+            const int p = prev[v];
+            if (p < m) flow[(size_t)p * n + (v - m)] += amount;
+            else flow[(size_t)v * n + (p - m)] -= amount;
+            v = p;
+        }
+    }
+    double sum = 0.0;
+    for (int64_t e = 0; e < (int64_t)m * n; ++e) sum += (double)flow[e] * (double)cost[e];
+    *total = sum / ((double)m * (double)n);
+    return SDA_OK;
+}

@@ -22,15 +22,16 @@ from ._lib import SdaHipError
 
 
 def emd(x: Tensor, y: Tensor) -> Tensor:
-    r"""Earth mover's distance between two equally weighted sample sets ``x`` (M, \*) and ``y`` (N, \*), M == N
-    (sda/utils.py:203-219)."""
+    r"""Earth mover's distance between two equally weighted sample sets ``x`` (M, \*) and ``y`` (N, \*)
+    (sda/utils.py:203-219: ``ot.emd2`` with empty weight vectors = uniform marginals).  The cost matrix is formed on the
+    device; the transport LP is solved on the host (as POT does): a linear assignment for M == N, an integral min-cost flow
+    otherwise."""
     xf, yf = x.flatten(1).float(), y.flatten(1).float()
-    if xf.shape[0] != yf.shape[0]:
-        raise SdaHipError(f'emd: {xf.shape[0]} vs {yf.shape[0]} samples -- only equal counts (uniform assignment) are '
-                          'supported')
-    cost = ops.pairwise_dist(xf, yf, squared=False)
-    total, _ = ops.assignment_cost(cost.cpu())
-    return x.new_tensor(total / xf.shape[0])
+    cost = ops.pairwise_dist(xf, yf, squared=False).cpu()
+    if xf.shape[0] == yf.shape[0]:
+        total, _ = ops.assignment_cost(cost)
+        return x.new_tensor(total / xf.shape[0])
+    return x.new_tensor(ops.transport_cost(cost))
 
 
 def mmd(x: Tensor, y: Tensor) -> Tensor:

@@ -427,6 +427,18 @@ def mmd_kernel_sum(d2: Tensor) -> Tensor:
     return partial.sum()
 
 
+def transport_cost(cost: Tensor) -> float:
+    """Host optimal-transport solve with uniform marginals of an (m, n) fp32 host cost matrix: min_P <P, cost>."""
+    if cost.is_cuda or cost.dtype != torch.float32 or cost.dim() != 2:
+        raise _lib.SdaHipError('transport_cost expects an fp32 host matrix')
+    import ctypes
+    cost = cost.contiguous()
+    total = ctypes.c_double(0.0)
+    _lib.check(_lib.load().sda_transport_cost(cost.data_ptr(), cost.shape[0], cost.shape[1], ctypes.addressof(total)),
+               'sda_transport_cost')
+    return total.value
+
+
 def assignment_cost(cost: Tensor):
     """Host linear-assignment solve of a square cost matrix (CPU tensor): (minimum total cost, column of each row)."""
     if cost.is_cuda or cost.dtype != torch.float32 or cost.dim() != 2 or cost.shape[0] != cost.shape[1]:

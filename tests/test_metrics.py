@@ -78,6 +78,48 @@ def test_host_assignment_solver_matches_scipy():
     assert total == 5.0 and sorted(cols.tolist()) == list(range(5))
 
 
+def test_host_transport_solver_matches_linprog_and_replication():
+    """emd for M != N: the host min-cost-flow solve against scipy's LP solver (HiGHS) on the transport LP itself, against
+    the assignment solver on the lcm-replicated problem (uniform marginals: exact), and the 1-D closed form."""
+    from scipy.optimize import linprog
+    from sda_amd import ops
+    rng = np.random.default_rng(11)
+
+    def lp(c):
+        m, n = c.shape
+        a_eq = np.zeros((m + n, m * n))
+        for i in range(m):
+            a_eq[i, i * n:(i + 1) * n] = 1
+        for j in range(n):
+            a_eq[m + j, j::n] = 1
+        b_eq = np.concatenate([np.full(m, 1 / m), np.full(n, 1 / n)])
+        return linprog(c.reshape(-1), A_eq=a_eq, b_eq=b_eq, bounds=(0, None), method='highs').fun
+
+    for m, n in ((1, 1), (1, 7), (5, 1), (2, 3), (7, 5), (12, 18), (31, 64), (40, 33)):
+        c = rng.random((m, n)).astype(np.float32) * 4
+        got = ops.transport_cost(torch.from_numpy(c))
+        assert abs(got - lp(c.astype(np.float64))) < 1e-9 * max(1.0, got), (m, n)
+        # every row n/g times, every column m/g times (g = gcd): an assignment problem with the same optimum
+        g = int(np.gcd(m, n))
+        rep = np.repeat(np.repeat(c, n // g, axis=0), m // g, axis=1)
+        tot, _ = ops.assignment_cost(torch.from_numpy(np.ascontiguousarray(rep)))
+        assert abs(got - tot / rep.shape[0]) < 1e-9 * max(1.0, got), (m, n)
+    # square input: the same value as the assignment path
+    c = rng.random((23, 23)).astype(np.float32)
+    assert abs(ops.transport_cost(torch.from_numpy(c)) - ops.assignment_cost(torch.from_numpy(c))[0] / 23) < 1e-12
+    # 1-D: W1 = integral |F^-1 - G^-1| of the two empirical quantile functions
+    x, y = np.sort(rng.normal(size=9)), np.sort(rng.normal(size=6) + 1)
+    c = np.abs(x[:, None] - y[None, :]).astype(np.float32)
+    grid = (np.arange(18) + 0.5) / 18
+    w1 = np.abs(x[np.minimum((grid * 9).astype(int), 8)] - y[np.minimum((grid * 6).astype(int), 5)]).mean()
+    assert abs(ops.transport_cost(torch.from_numpy(c)) - w1) < 1e-6
+    # ties, and rejected input
+    assert ops.transport_cost(torch.ones(4, 6)) == pytest.approx(1.0, abs=1e-12)
+    from sda_amd._lib import SdaHipError
+    with pytest.raises(SdaHipError):
+        ops.transport_cost(torch.tensor([[1.0, float('nan')]]))
+
+
 def test_metrics_reject_cpu_tensors():
     from sda_amd._lib import SdaHipError
     from sda_amd.metrics import emd, mmd
@@ -119,6 +161,10 @@ def test_emd_vs_oracle(dev):
     torch.manual_seed(9)
     for n, shape in ((37, (1,)), (128, (65, 3)), (512, (16, 3))):
         x, y = torch.randn(n, *shape), torch.randn(n, *shape) * 1.3 + 0.2
+        assert_close(emd(x.to(dev), y.to(dev)).cpu(), O.emd(x, y), 1e-5)
+    # unequal sample counts: the transport LP (oracle: scipy linprog)
+    for (m, n), shape in (((9, 6), (4,)), ((40, 64), (5, 3)), ((96, 37), (16, 2))):
+        x, y = torch.randn(m, *shape), torch.randn(n, *shape) * 0.8 - 0.4
         assert_close(emd(x.to(dev), y.to(dev)).cpu(), O.emd(x, y), 1e-5)
     x = torch.randn(64, 1)
     y = torch.randn(64, 1) + 3
