@@ -7,6 +7,7 @@
 // The normalisation itself is never materialised in the network path: sda_conv_igemm's loader applies
 // (x + mod - mean) * rstd while it stages the halo tile.  sda_ln_apply exists for tests / unfused callers.
 #include "sda_common.hpp"
+#include <stdlib.h>
 
 #define LN_THREADS 256
 
@@ -293,6 +294,79 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* _
     }
 }
 
+// No pooling, hw % 4 == 0, c <= SPLIT * CPL: a lane owns FOUR consecutive pixels (16-byte loads and stores) and every
+// SPLIT-th channel; a wavefront covers 64 / SPLIT pixel quads, so each channel plane is touched in contiguous runs of
+// (64 / SPLIT) * 16 bytes -- a whole 128-byte line for SPLIT = 8 (the dword version above moves 64-byte runs with four times
+// the instructions).  The SPLIT lanes of a quad sit 64 / SPLIT apart and combine their partial sums with cross-lane adds.
+template <int SPLIT, int CPL>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __restrict__ gh, const float* __restrict__ x,
+                                                                 int64_t nquad, int c, int hw, const float* __restrict__ mod,
+                                                                 int64_t mod_sn, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int unbiased,
+                                                                 const float* __restrict__ res, float* __restrict__ gx) {
+    constexpr int QW = 64 / SPLIT;                          // quads per wavefront
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    const int64_t quad = wave * QW + (lane & (QW - 1));
+    const int sub = lane / QW;
+    const bool live = quad < nquad;
+    const int64_t pix = (live ? quad : 0) * 4;
+    const int64_t n = pix / hw;
+    const int p = (int)(pix - n * hw);
+    const int64_t base = n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + pix), r4 = *reinterpret_cast<const float4*>(rstd + pix);
+    float4 g[CPL], hh[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int k = sub + SPLIT * j;
+        const bool on = k < c;
+        const int64_t off = base + (int64_t)(on ? k : 0) * hw;
+        g[j] = *reinterpret_cast<const float4*>(gh + off);
+        hh[j] = *reinterpret_cast<const float4*>(x + off);
+        if (!on) { g[j] = make_float4(0.f, 0.f, 0.f, 0.f); hh[j] = make_float4(m4.x, m4.y, m4.z, m4.w); }
+    }
+    if (mp) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int k = sub + SPLIT * j;
+            const float mv = k < c ? mp[k] : 0.f;
+            hh[j].x += mv; hh[j].y += mv; hh[j].z += mv; hh[j].w += mv;
+        }
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        hh[j].x = (hh[j].x - m4.x) * r4.x; hh[j].y = (hh[j].y - m4.y) * r4.y;
+        hh[j].z = (hh[j].z - m4.z) * r4.z; hh[j].w = (hh[j].w - m4.w) * r4.w;
+        s1.x += g[j].x; s1.y += g[j].y; s1.z += g[j].z; s1.w += g[j].w;
+        s2.x += g[j].x * hh[j].x; s2.y += g[j].y * hh[j].y; s2.z += g[j].z * hh[j].z; s2.w += g[j].w * hh[j].w;
+    }
+#pragma unroll
+    for (int o = QW; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+    }
+    if (!live) return;
+    const float ia = 1.f / (float)c, ib = 1.f / (float)(unbiased ? c - 1 : c);
+    const float4 a = make_float4(s1.x * ia, s1.y * ia, s1.z * ia, s1.w * ia);
+    const float4 b = make_float4(s2.x * ib, s2.y * ib, s2.z * ib, s2.w * ib);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int k = sub + SPLIT * j;
+        if (k < c) {
+            const int64_t off = base + (int64_t)k * hw;
+            float4 v = make_float4(r4.x * (g[j].x - a.x - hh[j].x * b.x), r4.y * (g[j].y - a.y - hh[j].y * b.y),
+                                   r4.z * (g[j].z - a.z - hh[j].z * b.z), r4.w * (g[j].w - a.w - hh[j].w * b.w));
+            if (res) {
+                const float4 rr = *reinterpret_cast<const float4*>(res + off);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            *reinterpret_cast<float4*>(gx + off) = v;
+        }
+    }
+}
+
 template <int POOL_H, int POOL_W>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_wave_kernel(const float* __restrict__ gh, const float* __restrict__ x,
                                                                  int64_t npix, int c, int h, int w,
@@ -361,7 +435,26 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
                                unbiased, res, gx);
         return sda_launch_status();
     }
-    if (shape == 11 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
+    const bool quad_ok = shape == 11 && (h * w) % 4 == 0 && c > 48 && c <= 384 &&
+                         ((reinterpret_cast<uintptr_t>(gh) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gx) |
+                           reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) |
+                           reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    static const int quad_mode = getenv("SDA_LN_BWD_QUAD") ? atoi(getenv("SDA_LN_BWD_QUAD")) : 1;
+    if (quad_ok && quad_mode) {
+        const int hw = h * w;
+        const int64_t nquad = npix / 4;
+        // (lanes per quad x channels per lane: c = 96: 8 x 12, 128-byte runs; c = 192 / 384: 16 x 12 / 16 x 24, 64-byte runs)
+        if (c <= 96) {
+            dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (c <= 192) {
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else {
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        }
+    } else if (shape == 11 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
         // lanes per pixel x channels per lane, picked per width from measurements on the Kolmogorov net's three levels
         // (c = 96: 4 x 24 1.57 ms vs 2 x 48 2.43, 8 x 12 1.85;  c = 192: 8 x 24 0.86 vs 4 x 48 1.13;  c = 384: 8 x 48 0.59 vs 16 x 24 0.82)
         const int hw = h * w;

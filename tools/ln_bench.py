@@ -1,0 +1,30 @@
+import os, sys, torch
+sys.path.insert(0, '/root/repo')
+from sda_amd import ops
+dev = torch.device('cuda:0')
+for c, hw_, n in ((96, 256, 16), (192, 128, 16), (384, 64, 16), (96, 64, 128)):
+    h = w = hw_
+    x = torch.randn(n, c, h, w, device=dev); gh = torch.randn_like(x); res = torch.randn_like(x)
+    mod = torch.randn(1, c, device=dev)
+    mean = torch.empty(n * h * w, device=dev); rstd = torch.empty_like(mean)
+    ops.ln_stats(x, mod, 0, 1e-5, True, mean, rstd)
+    gx = torch.empty_like(x)
+    def run():
+        ops.ln_bwd(gh, x, h, w, mod, 0, mean, rstd, True, (1, 1), res, gx)
+    for _ in range(5): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    nb = 4.0 * n * h * w * (c * 4 + 2)
+    print(f'c={c} {h}x{w} n={n}: {ms:.3f} ms  {nb / ms / 1e9:.2f} TB/s  quad={os.environ.get("SDA_LN_BWD_QUAD", "1")}')
+    # reference check
+    xm = (x + mod[:, :, None, None]).double()
+    xm.requires_grad_(True)
+    var, mu = torch.var_mean(xm, dim=1, unbiased=True, keepdim=True)
+    y = (xm - mu) / torch.sqrt(var + 1e-5)
+    ref, = torch.autograd.grad(y, xm, gh.double())
+    ref = ref + res.double()
+    print('   rel err', ((gx.double() - ref).abs().max() / ref.abs().max()).item())
