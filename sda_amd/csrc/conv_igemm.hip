@@ -789,6 +789,7 @@ static int conv_launch_m(const sda_conv_desc* d, const ConvGeom& g, hipStream_t 
 struct WinoGeom;
 int sda_wino_try(const sda_conv_desc* d, hipStream_t stream);   // SDA_E_UNSUPPORTED -> use the direct kernel
 int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream);  // one-wave-per-SIMD Winograd (conv_wino4.hip)
+int sda_small1d_try(const sda_conv_desc* d, hipStream_t stream); // small 1-D layers: one round trip per launch (conv_small1d.hip)
 
 extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -799,6 +800,10 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     if (d && d->w_wino) {
         const int rcw = sda_wino_try(d, s);
         if (rcw != SDA_E_UNSUPPORTED) return rcw;
+    }
+    if (d && d->kh == 1 && d->kw == 3) {
+        const int rcs = sda_small1d_try(d, s);
+        if (rcs != SDA_E_UNSUPPORTED) return rcs;
     }
     static const bool force_v1 = getenv("SDA_CONV_V1") != nullptr;
     const bool parity_shape = d && d->mt == 3 && d->kh >= 1 && d->kh <= 2 && d->kw >= 1 && d->kw <= 2;
