@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 3
+#define SDA_ABI_VERSION 4
 
 enum {
     SDA_OK = 0,
@@ -124,6 +124,33 @@ int sda_conv_igemm(const sda_conv_desc* d, void* stream);
 int sda_conv_igemm_path(const sda_conv_desc* d);
 /* bytes of dynamic LDS the launch would use (or <0 error), for planning / tests */
 int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * One modulated residual block of a 1-D U-Net in ONE launch (sda/nn.py:18-28, 113-176 with spatial = 1):
+ *     y = a + conv2(act(conv1(LN(a + mod)))),   both convolutions c -> c, kernel 3, stride 1, same padding mode;
+ * and its input VJP  gx = g + LN^T(conv1^T(act'(z) . conv2^T(g))).  For the latency-bound nets of the Lorenz experiments
+ * (c <= 64): three launches forward / three backward become one each.  a, y, z, g, gx: planar [n][c][len] contiguous;
+ * mean / rstd: [n][len].  w1 / w2: sda_pack_conv_weight packings [3][k_pad][m_pad] -- FORWARD form for sda_block1d_fwd,
+ * BACKWARD-DATA form (transpose = 1) for sda_block1d_bwd.  SDA_E_UNSUPPORTED when the shape is outside the kernel's range
+ * (callers fall back to sda_ln_stats + sda_conv_igemm + sda_ln_bwd). */
+typedef struct sda_block1d_desc {
+    int32_t n, c, len;
+    int32_t circular, act, unbiased;   /* padding mode of both convolutions; SDA_ACT_*; LayerNorm variance convention */
+    float eps;
+    int32_t k_pad, m_pad;
+    const float* a;
+    const float* mod;                  /* [*][c] additive modulation (NULL = none) */
+    int64_t mod_sn;                    /* per-image stride of mod (0 = shared) */
+    const float* w1; const float* b1;  /* b1 / b2 may be NULL; unused by the VJP */
+    const float* w2; const float* b2;
+    float* z;                          /* fwd: out (pre-activation of conv1, NULL = not kept); bwd: in */
+    float* mean; float* rstd;          /* fwd: out (NULL = not kept); bwd: in */
+    float* y;                          /* fwd: out */
+    const float* g;                    /* bwd: in */
+    float* gx;                         /* bwd: out */
+} sda_block1d_desc;
+int sda_block1d_fwd(const sda_block1d_desc* d, void* stream);
+int sda_block1d_bwd(const sda_block1d_desc* d, void* stream);
 
 /* Repack torch-layout conv weights [cout][cin][kh][kw] for sda_conv_igemm.
  *   transpose = 0: forward          dst[tap][ci][co]        = w[co][ci][dy][dx]

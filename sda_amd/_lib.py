@@ -56,9 +56,31 @@ class ConvDesc(Structure):
 
 
 # name -> (restype, argtypes); exactly the symbols include/sda_hip.h declares
+class Block1dDesc(Structure):
+    """Mirror of `struct sda_block1d_desc` (include/sda_hip.h)."""
+    _fields_ = [
+        ('n', c_int32), ('c', c_int32), ('len', c_int32),
+        ('circular', c_int32), ('act', c_int32), ('unbiased', c_int32),
+        ('eps', c_float),
+        ('k_pad', c_int32), ('m_pad', c_int32),
+        ('a', c_fp),
+        ('mod', c_fp),
+        ('mod_sn', c_int64),
+        ('w1', c_fp), ('b1', c_fp),
+        ('w2', c_fp), ('b2', c_fp),
+        ('z', c_fp),
+        ('mean', c_fp), ('rstd', c_fp),
+        ('y', c_fp),
+        ('g', c_fp),
+        ('gx', c_fp),
+    ]
+
+
 SIGNATURES = {
     'sda_abi_version': (c_int, []),
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
+    'sda_block1d_fwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
+    'sda_block1d_bwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),

@@ -97,19 +97,48 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     }
     __syncthreads();
     if (!wave_on) return;
-    // ---- multiply: acc[nf] = sum_{tap, cb} A(tap, cb) B(cb, nf, tap)
+    // ---- the epilogue's operands (bias, act' input, residual) are requested now: their round trip runs under the multiply
+    float ebias[4], ez[4][4], eres[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * kq + r;
+        const int coc = co < d.cout ? co : d.cout - 1;     // (clamped: unconditional loads, see above)
+        ebias[r] = d.bias ? d.bias[coc] : 0.f;
+        const int64_t row = ((int64_t)n * d.cout + coc) * d.wo;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int pos = p0 + 16 * nf + li;
+            const int pc = pos < d.wo ? pos : d.wo - 1;
+            ez[r][nf] = d.dact_z ? d.dact_z[row + pc] : 0.f;
+            eres[r][nf] = d.res ? d.res[row + pc] : 0.f;
+        }
+    }
+    // ---- multiply: acc[nf] = sum_{tap, cb} A(tap, cb) B(cb, nf, tap); the B values of K fragment cb + 1 are read from LDS
+    // before the 12 MFMAs of fragment cb are issued
     s1_f32x4 acc[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[nf] = s1_f32x4{0.f, 0.f, 0.f, 0.f};
     const float* brow = sin + kq * S1_LD + li;             // + 4 cb rows, + 16 nf + tap columns
+    float bv[2][4][3];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) bv[0][nf][tap] = brow[16 * nf + tap];
 #pragma unroll
     for (int cb = 0; cb < 16; ++cb) {
         if (cb < ncb) {
+            const int cn = cb + 1 < ncb ? cb + 1 : cb;     // (the last fragment re-reads itself)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * S1_LD + 16 * nf + tap];
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                 for (int nf = 0; nf < 4; ++nf)
-                    acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], brow[4 * cb * S1_LD + 16 * nf + tap], acc[nf], 0, 0, 0);
+                    acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
     }
     // ---- epilogue: lane holds couts co0 + 4 kq + r, position p0 + 16 nf + li
@@ -118,18 +147,14 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     for (int r = 0; r < 4; ++r) {
         const int co = co0 + 4 * kq + r;
         if (co >= d.cout) continue;
-        const float b = d.bias ? d.bias[co] : 0.f;
         const int64_t row = ((int64_t)n * d.cout + co) * d.wo;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const int pos = p0 + 16 * nf + li;
             if (pos < d.wo) {
-                float v = acc[nf][r] + b;
-                if (d.dact_z) {
-                    const float z = d.dact_z[row + pos];
-                    v *= d.act_d == SDA_ACT_SILU ? sda_dact(SDA_ACT_SILU, z) : dact_any(z);
-                }
-                if (d.res) v += d.res[row + pos];
+                float v = acc[nf][r] + ebias[r];
+                if (d.dact_z) v *= d.act_d == SDA_ACT_SILU ? sda_dact(SDA_ACT_SILU, ez[r][nf]) : dact_any(ez[r][nf]);
+                if (d.res) v += eres[r][nf];
                 d.out[row + pos] = v;
             }
         }

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_wave_kernel(const float* 
     if (lane == 0) { mean[idx] = m; rstd[idx] = 1.0f / sqrtf(var + eps); }
 }
 
-#define LN_SMALL_PIXELS 16384      // below this many pixels the wave-per-pixel kernels are used
+// below this many pixels the wave-per-pixel kernels are used (measured on the Lorenz-96 net, 8192 pixels x 64 channels:
+// statistics 6.4 us wave-per-pixel vs 9.5 us register kernel; backward 15 us wave-per-pixel vs 6.2 us quad kernel)
+#define LN_SMALL_PIXELS 16384
+#define LN_BWD_SMALL_PIXELS 4096
 
 extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* mod, int64_t mod_sn, float eps,
                             int unbiased, float* mean, float* rstd, void* stream) {
@@ -422,7 +425,7 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     dim3 grid((unsigned)blocks), block(LN_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (npix < LN_SMALL_PIXELS) {
+    if (npix < LN_BWD_SMALL_PIXELS) {
         dim3 gs((unsigned)((npix + 3) / 4));
         if (shape == 11)
             hipLaunchKernelGGL((ln_bwd_wave_kernel<1, 1>), gs, block, 0, s, gh, x, npix, c, h, w, mod, mod_sn, mean, rstd,

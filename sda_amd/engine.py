@@ -335,11 +335,24 @@ class UNetEngine:
         n, c, h, w = a.shape
         dev = a.device
         mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
+        c1, c2 = blk.conv1, blk.conv2
+        if (c1.circular == c2.circular and (c1.sh, c1.sw, c2.sh, c2.sw) == (1, 1, 1, 1) and
+                ops.block1d_eligible(c, h, c1.fwd(), c2.fwd())):
+            # latency-bound 1-D nets: the whole block in one launch (block1d.hip)
+            y = torch.empty_like(a)
+            if saved is not None:
+                mean = torch.empty(n * h * w, device=dev, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                z = torch.empty_like(a)
+                ops.block1d_fwd(a, mod, mod_sn, c1.fwd(), c2.fwd(), c1.circular, blk.act, blk.ln.eps, self.unbiased, y, z, mean, rstd)
+                saved.append((a, mean, rstd, z))
+            else:
+                ops.block1d_fwd(a, mod, mod_sn, c1.fwd(), c2.fwd(), c1.circular, blk.act, blk.ln.eps, self.unbiased, y)
+            return y
         mean = torch.empty(n * h * w, device=dev, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         ops.ln_stats(a, mod, mod_sn, blk.ln.eps, self.unbiased, mean, rstd)
         z = torch.empty_like(a)
-        c1 = blk.conv1
         pk = c1.fwd()
         launch_conv(pk, planar_source(a), z, h, w, circular=c1.circular, bias=pk.bias, mod=mod, mod_sn=mod_sn,
                     ln=(mean, rstd))
@@ -423,8 +436,13 @@ class UNetEngine:
         a, mean, rstd, z = rec
         n, c, h, w = a.shape
         mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
+        c1, c2 = blk.conv1, blk.conv2
+        if (c1.circular == c2.circular and (c1.sh, c1.sw, c2.sh, c2.sw) == (1, 1, 1, 1) and
+                ops.block1d_eligible(c, h, c1.fwd(), c2.fwd())):
+            gx = torch.empty_like(a)
+            ops.block1d_bwd(g, a, z, mean, rstd, mod, mod_sn, c1.bwd(), c2.bwd(), c1.circular, blk.act, self.unbiased, gx)
+            return gx
         gz = torch.empty_like(a)
-        c2 = blk.conv2
         launch_conv(c2.bwd(), planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act)
         gh = torch.empty_like(a)
         c1 = blk.conv1

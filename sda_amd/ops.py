@@ -6,6 +6,8 @@ tensors must live on a HIP device (`_dev()` raises otherwise).
 import ctypes
 from typing import Optional
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -193,6 +195,52 @@ class PackedConv:
             _lib.check(_lib.load().sda_pack_conv_weight_wino4(w.data_ptr(), cout, cin, int(transpose), keep,
                                                               self.wino4.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino4')
+
+
+# ------------------------------------------------------------------------------------------ fused 1-D residual block
+
+BLOCK1D = os.environ.get('SDA_BLOCK1D', '1') != '0'
+
+
+def block1d_eligible(c: int, h: int, pk1: 'PackedConv', pk2: 'PackedConv') -> bool:
+    """One-launch residual block (block1d.hip): 1-D, <= 64 channels, two k = 3 stride-1 convolutions c -> c."""
+    return (BLOCK1D and h == 1 and 2 <= c <= 64 and (pk1.kh, pk1.kw) == (1, 3) and (pk2.kh, pk2.kw) == (1, 3) and
+            pk1.k_pad <= 64 and pk1.m_pad <= 64 and pk2.k_pad == pk1.k_pad and pk2.m_pad == pk1.m_pad and
+            pk1.k_real == c and pk1.m_real == c and pk2.k_real == c and pk2.m_real == c)
+
+
+def _block1d_desc(a, mod, mod_sn, pk1, pk2, circular, act, eps, unbiased):
+    d = _lib.Block1dDesc()
+    d.n, d.c, d.len = a.shape[0], a.shape[1], a.shape[-1]
+    d.circular, d.act, d.unbiased, d.eps = int(circular), act, int(unbiased), eps
+    d.k_pad, d.m_pad = pk1.k_pad, pk1.m_pad
+    d.a = a.data_ptr()
+    d.mod, d.mod_sn = _ptr(mod), mod_sn
+    d.w1, d.w2 = pk1.packed.data_ptr(), pk2.packed.data_ptr()
+    d.b1 = None if pk1.bias is None else pk1.bias.data_ptr()
+    d.b2 = None if pk2.bias is None else pk2.bias.data_ptr()
+    return d
+
+
+def block1d_fwd(a: Tensor, mod, mod_sn: int, pk1: 'PackedConv', pk2: 'PackedConv', circular: bool, act: int, eps: float,
+                unbiased: bool, y: Tensor, z: Optional[Tensor] = None, mean: Optional[Tensor] = None,
+                rstd: Optional[Tensor] = None):
+    """y = a + conv2(act(conv1(LN(a + mod)))) for planar a (n, c, 1, len); z / mean / rstd are kept for the VJP when given."""
+    _dev(a, mod, y, z, mean, rstd)
+    d = _block1d_desc(a, mod, mod_sn, pk1, pk2, circular, act, eps, unbiased)
+    d.y, d.z, d.mean, d.rstd = y.data_ptr(), _ptr(z), _ptr(mean), _ptr(rstd)
+    import ctypes
+    _lib.check(_lib.load().sda_block1d_fwd(ctypes.byref(d), _stream()), 'sda_block1d_fwd')
+
+
+def block1d_bwd(g: Tensor, a: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, mod, mod_sn: int, pk1b: 'PackedConv',
+                pk2b: 'PackedConv', circular: bool, act: int, unbiased: bool, gx: Tensor):
+    """gx = g + LN^T(conv1^T(act'(z) . conv2^T(g))); pk1b / pk2b: the backward-data packings."""
+    _dev(g, a, z, mean, rstd, mod, gx)
+    d = _block1d_desc(a, mod, mod_sn, pk1b, pk2b, circular, act, 0.0, unbiased)
+    d.z, d.mean, d.rstd, d.g, d.gx = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), gx.data_ptr()
+    import ctypes
+    _lib.check(_lib.load().sda_block1d_bwd(ctypes.byref(d), _stream()), 'sda_block1d_bwd')
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm pieces

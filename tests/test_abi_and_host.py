@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in sda_hip.h but not exported'
     assert set(declared) == set(_lib.SIGNATURES), (set(declared) ^ set(_lib.SIGNATURES))
-    assert lib.sda_abi_version() == 3
+    assert lib.sda_abi_version() == 4
 
 
 def test_conv_desc_layout_matches_c(tmp_path):

@@ -482,3 +482,44 @@ def test_random_guided_and_local_paths():
         if msg:
             failures.append((cfg, msg))
     assert not failures, failures[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('channels,hidden,length,batch,padding,act', [
+    (3, 64, 64, 2, 'zeros', 'SiLU'), (40, 64, 128, 3, 'zeros', 'SiLU'), (5, 48, 37, 2, 'circular', 'SiLU'),
+    (7, 24, 200, 1, 'zeros', 'GELU'), (4, 64, 130, 2, 'circular', 'ELU'), (6, 10, 5, 3, 'zeros', 'SiLU'),
+])
+def test_fused_1d_block_equals_per_layer_path_and_oracle(dev, monkeypatch, channels, hidden, length, batch, padding, act):
+    """The one-launch residual block of the 1-D nets (block1d.hip) against the per-layer path (LayerNorm statistics + two
+    convolutions + LayerNorm backward) and the float64 oracle: forward and input VJP, tile-boundary / padding cases."""
+    import torch.nn as nn
+    from sda_amd import ops
+    from sda_amd.nn import UNet
+    from oracle import sda_oracle as O
+    torch.manual_seed(hash((channels, hidden, length)) % 1000)
+    net = UNet(channels, channels, 16, hidden_channels=(hidden,), hidden_blocks=(2,), kernel_size=3, activation=getattr(nn, act),
+               spatial=1, padding_mode=padding).to(dev)
+    x = torch.randn(batch, channels, length, device=dev)
+    emb = torch.randn(batch, 16, device=dev)
+    g = torch.randn(batch, channels, length, device=dev)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        y = net(xx, emb)
+        gx, = torch.autograd.grad(y, xx, g)
+        return y.detach(), gx
+
+    assert ops.BLOCK1D
+    y_f, gx_f = run()
+    monkeypatch.setattr(ops, 'BLOCK1D', False)
+    y_l, gx_l = run()
+    assert_close(y_f, y_l, 1e-5, what='fused vs per-layer forward')
+    assert_close(gx_f, gx_l, 1e-5, what='fused vs per-layer VJP')
+    # float64 oracle
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    cfg = O.UNetConfig(channels, channels, 16, (hidden,), (2,), 3, 2, act, 1, padding)
+    xo = x.cpu().double().requires_grad_(True)
+    yo = O.unet_forward(sd, "", cfg, xo, emb.cpu().double())
+    gxo, = torch.autograd.grad(yo, xo, g.cpu().double())
+    assert_close(y_f, yo.detach().float(), 1e-4, what='fused forward vs oracle')
+    assert_close(gx_f, gxo.float(), 1e-4, what='fused VJP vs oracle')

@@ -1,4 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2b
-timeout 900 python tools/wino4_check.py --cases 80 --bench > gpurun_out/r2b/wino4_check.txt 2>&1; echo "rc=$?" >> gpurun_out/r2b/wino4_check.txt
-tail -60 gpurun_out/r2b/wino4_check.txt
+timeout 900 python -m pytest tests/test_gpu_net.py -x -q -m gpu -k "fused_1d or unet1d or lorenz or hipgraph" > gpurun_out/r2b/pytest1.log 2>&1; tail -15 gpurun_out/r2b/pytest1.log
+for wl in lorenz96 lorenz63; do
+  timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --profile-steps 0 2>gpurun_out/r2b/bench_$wl.err | python -c "
+import json, sys
+j=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$wl', j['value'], j['ms_per_step'])"
+done
