@@ -11,11 +11,10 @@
 // Column j of an LDS tile = position p0 - 2 + j (input tiles, 82 columns) or p0 - 1 + j (conv1 / conv2^T outputs, 80 columns).
 #include "sda_common.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
-#define B1_TP 64
 #define B1_LD 112                      // (112 mod 32 = 16: the two k rows of a 32-lane LDS access group hit disjoint banks)
 #define B1_MAXC 64
-#define B1_COLS 82
 
 typedef float b1_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -74,7 +73,10 @@ __device__ __forceinline__ int b1_pos(const sda_block1d_desc& d, int p, bool& in
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
+template <int B1_TP>
 __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc d, int ptiles) {
+    constexpr int NF2 = B1_TP / 16, NF1 = NF2 + 1, B1_COLS = 16 * NF1 + 2;      // conv2 / conv1 fragments, input columns
+    constexpr int NPASS = B1_COLS > 64 ? 2 : 1;
     __shared__ float tin[B1_MAXC * B1_LD];                 // LN(a + mod), columns p0 - 2 ..
     __shared__ float tz[B1_MAXC * B1_LD];                  // act(z), columns p0 - 1 ..
     __shared__ float part[4 * 96];                         // per-column partial sums of the four channel groups
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     const float* an = d.a + (int64_t)c.n * d.c * d.len;
     const float* mp = d.mod ? d.mod + (int64_t)c.n * d.mod_sn : nullptr;
     // ---- the residual / bias operands of the epilogue, requested early (MFMA D layout: channel co0 + 4 kq + r, position p0 + 16 nf + li)
-    float eb1[4], eb2[4], ea[4][4];
+    float eb1[4], eb2[4], ea[4][NF2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = c.co0 + 4 * c.kq + r, coc = co < d.c ? co : d.c - 1;
         eb1[r] = d.b1 ? d.b1[coc] : 0.f;
         eb2[r] = d.b2 ? d.b2[coc] : 0.f;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF2; ++nf) {
             const int pos = c.p0 + 16 * nf + c.li, pc = pos < d.len ? pos : d.len - 1;
             ea[r][nf] = an[(int64_t)coc * d.len + pc];
         }
@@ -107,10 +109,10 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     bool cin_[2];
     colj[0] = c.lane; cols_sub[0] = c.wave;
     colj[1] = 64 + (c.tid >> 2); cols_sub[1] = c.tid & 3;
-    const bool second = c.tid < 4 * (B1_COLS - 64);
+    const bool second = B1_COLS > 64 && c.tid < 4 * (B1_COLS - 64);
     const float* mq = mp ? mp : d.a;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         bool inside;
         const int ps = b1_pos(d, c.p0 - 2 + colj[pass], inside);
         cin_[pass] = inside;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     // ---- LayerNorm statistics per column (two passes over registers: mean, then centred sum of squares)
     auto reduce_cols = [&](auto F) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             if (pass == 0 || second) {
                 float s = 0.f;
 #pragma unroll
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     reduce_cols([&](int pass, int i) { return v[pass][i]; });
     float mean[2], rstd[2];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int j = pass == 0 || second ? colj[pass] : 0;
         mean[pass] = (part[j] + part[96 + j] + part[192 + j] + part[288 + j]) / (float)d.c;
     }
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
         return (cols_sub[pass] + 4 * i) < d.c ? dl * dl : 0.f;
     });
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int j = pass == 0 || second ? colj[pass] : 0;
         const float var = (part[j] + part[96 + j] + part[192 + j] + part[288 + j]) / (float)(d.unbiased ? d.c - 1 : d.c);
         rstd[pass] = 1.0f / sqrtf(var + d.eps);
     }
     // ---- normalised tile -> LDS; statistics of the tile's own 64 positions -> global (the VJP needs them)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         if (pass == 0 || second) {
             const int j = colj[pass];
 #pragma unroll
@@ -172,15 +174,15 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     __syncthreads();
     // ---- conv1 on 80 columns (positions p0 - 1 ..): z = conv + b1 -> global (own 64 positions), act(z) -> LDS
     if (c.wave_on) {
-        b1_f32x4 acc[5];
+        b1_f32x4 acc[NF1];
 #pragma unroll
-        for (int nf = 0; nf < 5; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-        b1_mm<5>(w1, c.ncb, tin, c, acc);
+        for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
+        b1_mm<NF1>(w1, c.ncb, tin, c, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c.co0 + 4 * c.kq + r;
 #pragma unroll
-            for (int nf = 0; nf < 5; ++nf) {
+            for (int nf = 0; nf < NF1; ++nf) {
                 const int col = 16 * nf + c.li;                       // position p0 - 1 + col
                 bool inside;
                 const int ps = b1_pos(d, c.p0 - 1 + col, inside);
@@ -195,16 +197,16 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     __syncthreads();
     // ---- conv2 on the 64 positions, + b2 + a
     if (c.wave_on) {
-        b1_f32x4 acc[4];
+        b1_f32x4 acc[NF2];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-        b1_mm<4>(w2, c.ncb, tz, c, acc);
+        for (int nf = 0; nf < NF2; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
+        b1_mm<NF2>(w2, c.ncb, tz, c, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c.co0 + 4 * c.kq + r;
             if (co >= d.c) continue;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
+            for (int nf = 0; nf < NF2; ++nf) {
                 const int pos = c.p0 + 16 * nf + c.li;
                 if (pos < d.len) d.y[((int64_t)c.n * d.c + co) * d.len + pos] = acc[nf][r] + eb2[r] + ea[r][nf];
             }
@@ -214,7 +216,10 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
 
 // ------------------------------------------------------------------------------------------------------------ input VJP
 // w1 / w2 are the BACKWARD-DATA packings here (sda_pack_conv_weight with transpose = 1).
+template <int B1_TP>
 __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc d, int ptiles) {
+    constexpr int NF2 = B1_TP / 16, NF1 = NF2 + 1, B1_COLS = 16 * NF1 + 2;
+    constexpr int NPASS = B1_COLS > 64 ? 2 : 1;
     __shared__ float tg[B1_MAXC * B1_LD];                  // g, columns p0 - 2 ..
     __shared__ float tq[B1_MAXC * B1_LD];                  // conv2^T(g) * act'(z), columns p0 - 1 ..
     __shared__ float red[4 * B1_TP * 2];                   // per-wave partial channel sums of the LayerNorm backward
@@ -229,27 +234,27 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
     const float* gn = d.g + img;
     const float* mp = d.mod ? d.mod + (int64_t)c.n * d.mod_sn : nullptr;
     // ---- operands in MFMA D layout, requested early: z on the 80 conv2^T columns; a, g, statistics on the 64 positions
-    float ez[4][5];
-    float ea[4][4], eg[4][4], emean[4], erstd[4], emod[4];
+    float ez[4][NF1];
+    float ea[4][NF2], eg[4][NF2], emean[NF2], erstd[NF2], emod[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = c.co0 + 4 * c.kq + r, coc = co < d.c ? co : d.c - 1;
         emod[r] = mp ? mp[coc] : 0.f;
 #pragma unroll
-        for (int nf = 0; nf < 5; ++nf) {
+        for (int nf = 0; nf < NF1; ++nf) {
             bool inside;
             const int ps = b1_pos(d, c.p0 - 1 + 16 * nf + c.li, inside);
             ez[r][nf] = d.z[img + (int64_t)coc * d.len + ps];
         }
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF2; ++nf) {
             const int pos = c.p0 + 16 * nf + c.li, pc = pos < d.len ? pos : d.len - 1;
             ea[r][nf] = d.a[img + (int64_t)coc * d.len + pc];
             eg[r][nf] = gn[(int64_t)coc * d.len + pc];
         }
     }
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < NF2; ++nf) {
         const int pos = c.p0 + 16 * nf + c.li, pc = pos < d.len ? pos : d.len - 1;
         emean[nf] = d.mean[(int64_t)c.n * d.len + pc];
         erstd[nf] = d.rstd[(int64_t)c.n * d.len + pc];
@@ -259,11 +264,11 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
         int colj[2], sub[2];
         colj[0] = c.lane; sub[0] = c.wave;
         colj[1] = 64 + (c.tid >> 2); sub[1] = c.tid & 3;
-        const bool second = c.tid < 4 * (B1_COLS - 64);
+        const bool second = B1_COLS > 64 && c.tid < 4 * (B1_COLS - 64);
         float v[2][16];
         bool ins[2];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             bool inside;
             const int ps = b1_pos(d, c.p0 - 2 + colj[pass], inside);
             ins[pass] = inside;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
             }
         }
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
+        for (int pass = 0; pass < NPASS; ++pass)
             if (pass == 0 || second)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -285,15 +290,15 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
     __syncthreads();
     // ---- conv2^T on 80 columns, x act'(z) -> LDS
     if (c.wave_on) {
-        b1_f32x4 acc[5];
+        b1_f32x4 acc[NF1];
 #pragma unroll
-        for (int nf = 0; nf < 5; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-        b1_mm<5>(w2, c.ncb, tg, c, acc);
+        for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
+        b1_mm<NF1>(w2, c.ncb, tg, c, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c.co0 + 4 * c.kq + r;
 #pragma unroll
-            for (int nf = 0; nf < 5; ++nf) {
+            for (int nf = 0; nf < NF1; ++nf) {
                 const int col = 16 * nf + c.li;
                 bool inside;
                 (void)b1_pos(d, c.p0 - 1 + col, inside);
@@ -303,13 +308,13 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
     }
     __syncthreads();
     // ---- conv1^T on the 64 positions -> gh; LayerNorm backward: gx = rstd (gh - mean_c(gh) - xh mean'_c(gh xh)) + g
-    b1_f32x4 gh[4];
+    b1_f32x4 gh[NF2];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) gh[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c.wave_on) b1_mm<4>(w1, c.ncb, tq, c, gh);
-    float xh[4][4];
+    for (int nf = 0; nf < NF2; ++nf) gh[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c.wave_on) b1_mm<NF2>(w1, c.ncb, tq, c, gh);
+    float xh[4][NF2];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < NF2; ++nf) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
     if (!c.wave_on) return;
     const float ia = 1.f / (float)d.c, ib = 1.f / (float)(d.unbiased ? d.c - 1 : d.c);
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < NF2; ++nf) {
         const int m = 16 * nf + c.li;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -348,22 +353,32 @@ static int block1d_check(const sda_block1d_desc* d, bool bwd) {
         return SDA_E_UNSUPPORTED;
     if (bwd ? (!d->g || !d->gx || !d->z || !d->mean || !d->rstd) : (!d->y || ((d->mean == nullptr) != (d->rstd == nullptr))))
         return SDA_E_BADARG;
-    if ((int64_t)d->n * ((d->len + B1_TP - 1) / B1_TP) > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    if ((int64_t)d->n * ((d->len + 31) / 32) > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     return SDA_OK;
+}
+
+// 64-position tiles when they fill the chip; 32-position tiles (twice the workgroups, half the MFMA work each) for the small
+// batches these kernels exist for
+static int block1d_tile(const sda_block1d_desc* d) {
+    static const int forced = getenv("SDA_BLOCK1D_TP") ? atoi(getenv("SDA_BLOCK1D_TP")) : 0;
+    if (forced == 32 || forced == 64) return forced;
+    return (int64_t)d->n * ((d->len + 63) / 64) >= 512 ? 64 : 32;
 }
 
 extern "C" int sda_block1d_fwd(const sda_block1d_desc* d, void* stream) {
     const int rc = block1d_check(d, false);
     if (rc != SDA_OK) return rc;
-    const int ptiles = (d->len + B1_TP - 1) / B1_TP;
-    hipLaunchKernelGGL(block1d_fwd_kernel, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    const int tp = block1d_tile(d), ptiles = (d->len + tp - 1) / tp;
+    if (tp == 64) hipLaunchKernelGGL(block1d_fwd_kernel<64>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    else hipLaunchKernelGGL(block1d_fwd_kernel<32>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     return sda_launch_status();
 }
 
 extern "C" int sda_block1d_bwd(const sda_block1d_desc* d, void* stream) {
     const int rc = block1d_check(d, true);
     if (rc != SDA_OK) return rc;
-    const int ptiles = (d->len + B1_TP - 1) / B1_TP;
-    hipLaunchKernelGGL(block1d_bwd_kernel, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    const int tp = block1d_tile(d), ptiles = (d->len + tp - 1) / tp;
+    if (tp == 64) hipLaunchKernelGGL(block1d_bwd_kernel<64>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    else hipLaunchKernelGGL(block1d_bwd_kernel<32>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     return sda_launch_status();
 }
