@@ -258,6 +258,10 @@ int sda_denoise(const float* x, const float* eps, int64_t numel, float mu, float
                 float* xhat, void* stream);
 int sda_guided_combine(const float* eps, const float* ghat, const float* vjp, int64_t numel, float mu, float sigma,
                        const float* coef_dev, float* out, void* stream);
+/* out = (y - ax) / (std^2 + gamma (sigma/mu)^2): the cotangent of log N(y | A x_hat, var) (sda/score.py:389-392) for scalar
+ * std / gamma; y broadcasts over the leading axis (y_numel divides numel); (mu, sigma) from coef_dev when non-NULL */
+int sda_gauss_cotangent(const float* y, int64_t y_numel, const float* ax, int64_t numel, float std, float gamma, float mu,
+                        float sigma, const float* coef_dev, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Linear observation operators A of the reference's experiments and their adjoints A^T, so that GaussianScore

@@ -79,6 +79,7 @@ class Block1dDesc(Structure):
 SIGNATURES = {
     'sda_abi_version': (c_int, []),
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
+    'sda_gauss_cotangent': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'sda_block1d_fwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_block1d_bwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),

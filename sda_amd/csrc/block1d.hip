@@ -353,16 +353,20 @@ static int block1d_check(const sda_block1d_desc* d, bool bwd) {
         return SDA_E_UNSUPPORTED;
     if (bwd ? (!d->g || !d->gx || !d->z || !d->mean || !d->rstd) : (!d->y || ((d->mean == nullptr) != (d->rstd == nullptr))))
         return SDA_E_BADARG;
-    if ((int64_t)d->n * ((d->len + 31) / 32) > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    if ((int64_t)d->n * ((d->len + 15) / 16) > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     return SDA_OK;
 }
 
-// 64-position tiles when they fill the chip; 32-position tiles (twice the workgroups, half the MFMA work each) for the small
-// batches these kernels exist for
+// 64-position tiles when they fill the chip; 32- or 16-position tiles (more workgroups, less MFMA work each, a larger share of
+// halo columns) for the small batches these kernels exist for
 static int block1d_tile(const sda_block1d_desc* d) {
     static const int forced = getenv("SDA_BLOCK1D_TP") ? atoi(getenv("SDA_BLOCK1D_TP")) : 0;
-    if (forced == 32 || forced == 64) return forced;
-    return (int64_t)d->n * ((d->len + 63) / 64) >= 512 ? 64 : 32;
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    // (measured, Lorenz-96 batch 64 x 128 positions: 0.85 / 0.68 / 0.67 ms per sampling step with 64 / 32 / 16; Lorenz-63, one
+    //  image of 64 positions: 0.70 / 0.53 / 0.44)
+    if ((int64_t)d->n * ((d->len + 15) / 16) <= 1024) return 16;
+    if ((int64_t)d->n * ((d->len + 31) / 32) <= 1024) return 32;
+    return 64;
 }
 
 extern "C" int sda_block1d_fwd(const sda_block1d_desc* d, void* stream) {
@@ -370,6 +374,7 @@ extern "C" int sda_block1d_fwd(const sda_block1d_desc* d, void* stream) {
     if (rc != SDA_OK) return rc;
     const int tp = block1d_tile(d), ptiles = (d->len + tp - 1) / tp;
     if (tp == 64) hipLaunchKernelGGL(block1d_fwd_kernel<64>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    else if (tp == 16) hipLaunchKernelGGL(block1d_fwd_kernel<16>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     else hipLaunchKernelGGL(block1d_fwd_kernel<32>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     return sda_launch_status();
 }
@@ -379,6 +384,7 @@ extern "C" int sda_block1d_bwd(const sda_block1d_desc* d, void* stream) {
     if (rc != SDA_OK) return rc;
     const int tp = block1d_tile(d), ptiles = (d->len + tp - 1) / tp;
     if (tp == 64) hipLaunchKernelGGL(block1d_bwd_kernel<64>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
+    else if (tp == 16) hipLaunchKernelGGL(block1d_bwd_kernel<16>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     else hipLaunchKernelGGL(block1d_bwd_kernel<32>, dim3((unsigned)(d->n * ptiles)), dim3(256), 0, (hipStream_t)stream, *d, ptiles);
     return sda_launch_status();
 }

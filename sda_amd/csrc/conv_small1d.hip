@@ -11,13 +11,14 @@
 #include "sda_common.hpp"
 #include <type_traits>
 
-#define S1_TP 64                       // positions per workgroup
 #define S1_LD 80                       // LDS row stride (66 used; 80 mod 32 = 16: the two k rows of a 32-lane group hit disjoint banks)
 #define S1_MAXC 64
 
 typedef float s1_f32x4 __attribute__((ext_vector_type(4)));
 
+template <int S1_TP>                   // positions per workgroup: 64, 32 or 16
 __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d, int ptiles) {
+    constexpr int NF = S1_TP / 16;
     __shared__ float sin[S1_MAXC * S1_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x / ptiles, p0 = (blockIdx.x - n * ptiles) * S1_TP;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
             }
         };
         auto both = [&](auto AM_) {
-            column(1 + lane, wave, 4, std::integral_constant<int, 16>{}, AM_);
+            if (lane < S1_TP) column(1 + lane, wave, 4, std::integral_constant<int, 16>{}, AM_);
             if (tid < 128) column(tid < 64 ? 0 : S1_TP + 1, tid & 63, 1, std::integral_constant<int, 1>{}, AM_);
         };
         if (d.act_in == SDA_ACT_NONE) both(std::integral_constant<int, 0>{});
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     __syncthreads();
     if (!wave_on) return;
     // ---- the epilogue's operands (bias, act' input, residual) are requested now: their round trip runs under the multiply
-    float ebias[4], ez[4][4], eres[4][4];
+    float ebias[4], ez[4][NF], eres[4][NF];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = co0 + 4 * kq + r;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
         ebias[r] = d.bias ? d.bias[coc] : 0.f;
         const int64_t row = ((int64_t)n * d.cout + coc) * d.wo;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
             const int pos = p0 + 16 * nf + li;
             const int pc = pos < d.wo ? pos : d.wo - 1;
             ez[r][nf] = d.dact_z ? d.dact_z[row + pc] : 0.f;
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     }
     // ---- multiply: acc[nf] = sum_{tap, cb} A(tap, cb) B(cb, nf, tap); the B values of K fragment cb + 1 are read from LDS
     // before the 12 MFMAs of fragment cb are issued
-    s1_f32x4 acc[4];
+    s1_f32x4 acc[NF];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) acc[nf] = s1_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NF; ++nf) acc[nf] = s1_f32x4{0.f, 0.f, 0.f, 0.f};
     const float* brow = sin + kq * S1_LD + li;             // + 4 cb rows, + 16 nf + tap columns
-    float bv[2][4][3];
+    float bv[2][NF][3];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) bv[0][nf][tap] = brow[16 * nf + tap];
 #pragma unroll
@@ -129,16 +130,16 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
         if (cb < ncb) {
             const int cn = cb + 1 < ncb ? cb + 1 : cb;     // (the last fragment re-reads itself)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * S1_LD + 16 * nf + tap];
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
+                for (int nf = 0; nf < NF; ++nf)
                     acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
         }
     }
     // ---- epilogue: lane holds couts co0 + 4 kq + r, position p0 + 16 nf + li
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
         if (co >= d.cout) continue;
         const int64_t row = ((int64_t)n * d.cout + co) * d.wo;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
             const int pos = p0 + 16 * nf + li;
             if (pos < d.wo) {
                 float v = acc[nf][r] + ebias[r];
@@ -172,10 +173,14 @@ int sda_small1d_try(const sda_conv_desc* d, hipStream_t stream) {
         d->wo != d->ws || d->wo < 1 || d->n < 1 || d->n_inner < 1 || !d->x || !d->w || !d->out)
         return SDA_E_UNSUPPORTED;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return SDA_E_BADARG;
-    const int ptiles = (d->wo + S1_TP - 1) / S1_TP;
+    // 64-position tiles for batches that fill the chip, smaller ones otherwise (see block1d.hip)
+    const int tp = (int64_t)d->n * ((d->wo + 15) / 16) <= 1024 ? 16 : ((int64_t)d->n * ((d->wo + 31) / 32) <= 1024 ? 32 : 64);
+    const int ptiles = (d->wo + tp - 1) / tp;
     const int64_t grid = (int64_t)d->n * ptiles;
     // this kernel is for launches that cannot fill the chip with the staged kernel's tiles; big batches stay there
     if (grid > 4096) return SDA_E_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_small1d_kernel, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
+    if (tp == 16) hipLaunchKernelGGL(conv_small1d_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
+    else if (tp == 32) hipLaunchKernelGGL(conv_small1d_kernel<32>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
+    else hipLaunchKernelGGL(conv_small1d_kernel<64>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
     return sda_launch_status();
 }

@@ -294,3 +294,25 @@ extern "C" int sda_guided_combine(const float* eps, const float* ghat, const flo
                        vjp, numel, mu, sigma, coef_dev, out);
     return sda_launch_status();
 }
+
+// (y - A x_hat) / (std^2 + gamma (sigma / mu)^2): the cotangent of the Gaussian likelihood (sda/score.py:389-392) for scalar
+// std / gamma, in one launch instead of seven tiny elementwise ones; y broadcasts over the leading (batch) axis when it is
+// shorter than ax (y_numel divides numel).
+__global__ void gauss_cotangent_kernel(const float* __restrict__ y, int64_t y_numel, const float* __restrict__ ax, int64_t numel,
+                                       float std, float gamma, float mu, float sigma, const float* __restrict__ coef,
+                                       float* __restrict__ out) {
+    if (coef) { mu = coef[0]; sigma = coef[1]; }
+    // (the reference's operation order, rounded step by step: no fused multiply-add, a division per element)
+    const float r = __fdiv_rn(sigma, mu);
+    const float var = __fadd_rn(__fmul_rn(std, std), __fmul_rn(gamma, __fmul_rn(r, r)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = __fdiv_rn(y[y_numel == numel ? i : i % y_numel] - ax[i], var);
+}
+
+extern "C" int sda_gauss_cotangent(const float* y, int64_t y_numel, const float* ax, int64_t numel, float std, float gamma,
+                                   float mu, float sigma, const float* coef_dev, float* out, void* stream) {
+    if (!y || !ax || !out || numel <= 0 || y_numel <= 0 || numel % y_numel) return SDA_E_BADARG;
+    hipLaunchKernelGGL(gauss_cotangent_kernel, dim3(grid_for(numel, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, y_numel, ax,
+                       numel, std, gamma, mu, sigma, coef_dev, out);
+    return sda_launch_status();
+}

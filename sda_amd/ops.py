@@ -451,6 +451,17 @@ def guided_combine(eps: Tensor, ghat: Tensor, vjp: Optional[Tensor], mu, sigma, 
                                               out.data_ptr(), _stream()), 'sda_guided_combine')
 
 
+def gauss_cotangent(y: Tensor, ax: Tensor, std: float, gamma: float, mu, sigma) -> Tensor:
+    """(y - ax) / (std^2 + gamma (sigma/mu)^2) for scalar std / gamma; y broadcasts over ax's leading axis."""
+    _dev(y, ax)
+    y, ax = y.contiguous(), ax.contiguous()
+    out = torch.empty_like(ax)
+    m, s, pair = _coef(mu, sigma)
+    _lib.check(_lib.load().sda_gauss_cotangent(y.data_ptr(), y.numel(), ax.data_ptr(), ax.numel(), float(std), float(gamma), m, s,
+                                               _ptr(pair), out.data_ptr(), _stream()), 'sda_gauss_cotangent')
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- evaluation metrics
 def pairwise_dist(x: Tensor, y: Tensor, squared: bool) -> Tensor:
     """x: (m, d), y: (n, d) -> (m, n) Euclidean distances (or their squares)."""

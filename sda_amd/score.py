@@ -513,6 +513,10 @@ class GaussianScore(nn.Module):
         self.A = A
         self.sde = sde
         self.detach = detach
+        # scalar std / gamma (every experiment of the reference): the likelihood cotangent is one fused launch
+        self._scalars = None
+        if torch.as_tensor(std).numel() == 1 and torch.as_tensor(gamma).numel() == 1:
+            self._scalars = (float(torch.as_tensor(std)), float(torch.as_tensor(gamma)))
 
     #: samples per streamed group: None = decide from free HBM, 0 = never split, n = force groups of n (tests)
     group_size: Optional[int] = None
@@ -585,9 +589,16 @@ class GaussianScore(nn.Module):
         if hasattr(self.A, 'adjoint'):
             # linear operator with a hand-written adjoint (sda_amd.observe): d log p / d x_hat = A^T((y - A x_hat)/var)
             ax = self.A(xhat)
-            err = observed(ax) - ax
-            var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
-            ghat = self.A.adjoint((err / var).contiguous(), xhat.shape).contiguous()
+            yo = observed(ax)
+            if (self._scalars is not None and ax.dtype == torch.float32 and yo.dtype == torch.float32 and
+                    (yo.shape == ax.shape or yo.shape == ax.shape[1:] or
+                     (yo.dim() == ax.dim() and yo.shape[0] == 1 and yo.shape[1:] == ax.shape[1:]))):
+                # (the same path for every batch size: sharded and single-rank runs stay bit-identical)
+                cot = ops.gauss_cotangent(yo, ax, self._scalars[0], self._scalars[1], mu, sigma)
+            else:
+                var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
+                cot = ((yo - ax) / var).contiguous()
+            ghat = self.A.adjoint(cot, xhat.shape).contiguous()
         else:
             with torch.enable_grad():
                 xhat.requires_grad_(True)

@@ -166,7 +166,10 @@ def install(monkeypatch):
         out.copy_(torch.from_numpy(z).reshape(out.shape))
         return out
 
-    for name, fn in dict(_dev=_dev, randn_rows=randn_rows, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
+    def gauss_cotangent(y, ax, std, gamma, mu, sigma):
+        return (y - ax) / (std ** 2 + gamma * (torch.as_tensor(sigma) / torch.as_tensor(mu)) ** 2)
+
+    for name, fn in dict(_dev=_dev, randn_rows=randn_rows, gauss_cotangent=gauss_cotangent, conv_igemm=conv_igemm, pack_conv_weight=pack, ln_stats=ln_stats, ln_apply=ln_apply,
                          ln_bwd=ln_bwd, time_embed=time_embed, linear_small=linear_small, fold=fold,
                          fold_adjoint=fold_adjoint, unfold_adjoint=unfold_adjoint, pc_predict=pc_predict,
                          sumsq_partial=sumsq_partial, pc_correct=pc_correct, denoise=denoise,
