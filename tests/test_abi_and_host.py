@@ -32,20 +32,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.sda_abi_version() == 4
 
 
-def test_conv_desc_layout_matches_c(tmp_path):
-    """sizeof/offsetof of the ctypes mirror == what gcc sees in the header."""
-    from sda_amd._lib import ConvDesc
-    fields = [f[0] for f in ConvDesc._fields_]
+@pytest.mark.parametrize('mirror,ctype', [('ConvDesc', 'sda_conv_desc'), ('Block1dDesc', 'sda_block1d_desc')])
+def test_desc_layouts_match_c(tmp_path, mirror, ctype):
+    """sizeof/offsetof of the ctypes mirrors == what gcc sees in the header."""
+    from sda_amd import _lib
+    Desc = getattr(_lib, mirror)
+    fields = [f[0] for f in Desc._fields_]
     src = tmp_path / 'layout.c'
-    prints = '\n'.join(f'printf("{f} %zu\\n", offsetof(sda_conv_desc, {f}));' for f in fields)
+    prints = '\n'.join(f'printf("{f} %zu\\n", offsetof({ctype}, {f}));' for f in fields)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{printf("size %zu\\n", '
-                   f'sizeof(sda_conv_desc));\n{prints}\nreturn 0;}}')
+                   f'sizeof({ctype}));\n{prints}\nreturn 0;}}')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', str(src), '-o', str(exe)])
     out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
-    assert int(out['size']) == ctypes.sizeof(ConvDesc)
+    assert int(out['size']) == ctypes.sizeof(Desc)
     for f in fields:
-        assert int(out[f]) == getattr(ConvDesc, f).offset, f
+        assert int(out[f]) == getattr(Desc, f).offset, f
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

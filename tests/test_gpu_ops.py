@@ -342,3 +342,49 @@ def test_small_operators_randomised_sweep(dev):
     with pytest.raises(SdaHipError):                       # an undersized partial-sum buffer is refused, not overrun
         ops_ = __import__('sda_amd.ops', fromlist=['ops'])
         ops_.sumsq_partial(torch.randn(4, 10, device=dev), 4, torch.empty(4, 8, device=dev))
+
+
+@pytest.mark.gpu
+def test_gauss_cotangent_matches_torch(dev):
+    """(y - A x)/var in one launch, against the reference's expression evaluated by torch (same operation order: bit exact),
+    with y shared over the batch, per sample, and with (mu, sigma) as device scalars."""
+    from sda_amd import ops
+    torch.manual_seed(3)
+    ax = torch.randn(5, 3, 7, 11, device=dev)
+    std, gamma = 0.37, 1e-2
+    for y in (torch.randn(5, 3, 7, 11, device=dev), torch.randn(1, 3, 7, 11, device=dev), torch.randn(3, 7, 11, device=dev)):
+        for mu, sigma in ((0.83, 0.41), (torch.tensor(0.83, device=dev), torch.tensor(0.41, device=dev))):
+            got = ops.gauss_cotangent(y, ax, std, gamma, mu, sigma)
+            s_, m_ = torch.as_tensor(sigma, device=dev, dtype=torch.float32), torch.as_tensor(mu, device=dev, dtype=torch.float32)
+            want = (y - ax) / (torch.tensor(std, device=dev) ** 2 + torch.tensor(gamma, device=dev) * (s_ / m_) ** 2)
+            assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_small_1d_conv_kernel_serves_the_lorenz_shapes(dev):
+    """conv_small1d (one round trip per launch) against torch on the layer shapes of the Lorenz nets, every fusion on, both
+    paddings, lengths that are not multiples of the tile; SDA_CONV_SMALL1D=0 is the staged kernel (compared too)."""
+    import torch.nn.functional as F
+    from sda_amd._lib import ACT_IDS
+    torch.manual_seed(5)
+    for (n, cin, cout, length, circular) in ((64, 40, 64, 128, False), (1, 3, 64, 64, True), (3, 64, 64, 77, True),
+                                              (2, 64, 40, 130, False), (5, 17, 33, 16, True)):
+        x = torch.randn(n, cin, 1, length)
+        wgt = torch.randn(cout, cin, 3) / (3 * cin) ** 0.5
+        b = torch.randn(cout)
+        mod = torch.randn(1, cin)
+        xin = x.double() + mod.double()[:, :, None, None]
+        var, mean = torch.var_mean(xin, dim=1, unbiased=True, keepdim=True)
+        rstd = 1 / torch.sqrt(var + 1e-5)
+        xin = F.silu((xin - mean) * rstd)
+        xp = F.pad(xin[:, :, 0], (1, 1), mode='circular' if circular else 'constant')
+        ref = F.conv1d(xp, wgt.double(), b.double())[:, :, None]
+        z = torch.randn(ref.shape)
+        zz = z.double().requires_grad_(True)
+        dz, = torch.autograd.grad(F.silu(zz).sum(), zz)
+        res = torch.randn(ref.shape)
+        ref = ref * dz + res.double()
+        out = hip_conv(x, wgt[:, :, None], b, 1, length, dev, circular=circular, mod=mod,
+                       ln=(mean.float().reshape(n, -1), rstd.float().reshape(n, -1)), act_in=ACT_IDS['SiLU'],
+                       dact_z=z, act_d=ACT_IDS['SiLU'], res=res)
+        assert_close(out.cpu(), ref.float(), 1e-4, what=f'small 1-D conv {(n, cin, cout, length, circular)}')
