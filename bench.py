@@ -74,7 +74,10 @@ class SyntheticScore(torch.nn.Module):
         else:
             mu = torch.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
             sigma = (1 - mu ** 2 + self.eta ** 2).sqrt()
-        return x * (sigma / (mu * mu + sigma * sigma)) + self.scale * self.net(x, t, c)
+        # (the same expression in five elementwise launches instead of seven, three instead of five in its autograd VJP: on the
+        # latency-bound Lorenz workloads every scalar-tensor launch is ~1 % of a step)
+        k = sigma / torch.addcmul(sigma * sigma, mu, mu)
+        return torch.add(x * k, self.net(x, t, c), alpha=self.scale)
 
 
 def build_model(wl, device):
