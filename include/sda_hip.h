@@ -273,6 +273,11 @@ int sda_gauss_cotangent(const float* y, int64_t y_numel, const float* ax, int64_
  * ------------------------------------------------------------------------------------------ */
 int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, float* out, void* stream);
 int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, float* gx, void* stream);
+/* g = A^T((y - A((x - sigma eps)/mu)) / (std^2 + gamma (sigma/mu)^2)) for the subsampling A above, scalar std / gamma, in one
+ * launch (sda/score.py:387-394); y broadcasts over the leading axis; (mu, sigma) from coef_dev when non-NULL */
+int sda_obs_subsample_guidance(const float* x, const float* eps, const float* y, int64_t y_numel, const int* size5,
+                               const int* start5, const int* step5, const int* stop5 /* exclusive ends per dim, or NULL */,
+                               float std, float gamma, float mu, float sigma, const float* coef_dev, float* g, void* stream);
 int sda_obs_coarsen(const float* x, int64_t planes, int h, int w, int f, float* out, void* stream);
 int sda_obs_coarsen_adjoint(const float* r, int64_t planes, int h, int w, int f, float* gx, void* stream);
 int sda_obs_vorticity(const float* x, int64_t pairs, int h, int w, float* out, void* stream);

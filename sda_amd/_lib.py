@@ -98,6 +98,8 @@ SIGNATURES = {
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
     'sda_obs_subsample_adjoint': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_subsample_guidance': (c_int, [c_fp, c_fp, c_fp, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                           c_float, c_float, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_obs_coarsen': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_obs_coarsen_adjoint': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_fp, c_void_p]),
     'sda_obs_vorticity': (c_int, [c_fp, c_int64, c_int, c_int, c_fp, c_void_p]),

@@ -82,6 +82,58 @@ extern "C" int sda_obs_subsample_adjoint(const float* r, const int* size5, const
     return sda_launch_status();
 }
 
+// Gaussian-likelihood guidance through a subsampling observation in ONE launch (sda/score.py:387-394 with A = x[..., ::s]):
+//   g[i] = (y[o(i)] - (x[i] - sigma eps[i]) / mu) / (std^2 + gamma (sigma/mu)^2)   on the observed lattice, 0 elsewhere
+// = A^T((y - A x_hat) / var), i.e. sda_denoise + sda_obs_subsample + sda_gauss_cotangent + sda_obs_subsample_adjoint (four
+// launches of ~5 us each on the latency-bound Lorenz workloads).  y broadcasts over the leading axis (y_numel divides |A x|).
+__global__ void subsample_guidance_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ y,
+                                          int64_t y_numel, Slice5 s, int64_t total_x, float std, float gamma, float mu, float sigma,
+                                          const float* __restrict__ coef, float* __restrict__ g) {
+    if (coef) { mu = coef[0]; sigma = coef[1]; }
+    const float r = __fdiv_rn(sigma, mu);
+    const float var = __fadd_rn(__fmul_rn(std, std), __fmul_rn(gamma, __fmul_rn(r, r)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_x; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t q = i, dst = 0, mul = 1;
+        bool hit = true;
+        int o[5];
+#pragma unroll
+        for (int d = 4; d >= 0; --d) {
+            const int c = (int)(q % s.size[d]); q /= s.size[d];
+            const int rel = c - s.start[d];
+            hit = hit && rel >= 0 && (rel % s.step[d]) == 0 && (rel / s.step[d]) < s.osize[d];
+            o[d] = rel / s.step[d];
+        }
+        float v = 0.f;
+        if (hit) {
+#pragma unroll
+            for (int d = 4; d >= 0; --d) { dst += (int64_t)o[d] * mul; mul *= s.osize[d]; }
+            const float xh = (x[i] - sigma * eps[i]) / mu;
+            v = __fdiv_rn(y[dst % y_numel] - xh, var);
+        }
+        g[i] = v;
+    }
+}
+
+extern "C" int sda_obs_subsample_guidance(const float* x, const float* eps, const float* y, int64_t y_numel, const int* size5,
+                                          const int* start5, const int* step5, const int* stop5, float std, float gamma,
+                                          float mu, float sigma, const float* coef_dev, float* g, void* stream) {
+    if (!x || !eps || !y || !g || !size5 || !start5 || !step5 || y_numel <= 0) return SDA_E_BADARG;
+    Slice5 s;
+    int rc = fill_slice(&s, size5, start5, step5);
+    if (rc) return rc;
+    if (stop5)                                             // slices with a stop: fewer observed positions along that axis
+        for (int d = 0; d < 5; ++d) {
+            if (stop5[d] <= start5[d] || stop5[d] > size5[d]) return SDA_E_BADARG;
+            s.osize[d] = (stop5[d] - start5[d] + step5[d] - 1) / step5[d];
+        }
+    int64_t total = 1, ototal = 1;
+    for (int d = 0; d < 5; ++d) { total *= s.size[d]; ototal *= s.osize[d]; }
+    if (ototal % y_numel) return SDA_E_BADARG;
+    hipLaunchKernelGGL(subsample_guidance_kernel, dim3(obs_grid(total)), dim3(256), 0, (hipStream_t)stream, x, eps, y, y_numel, s,
+                       total, std, gamma, mu, sigma, coef_dev, g);
+    return sda_launch_status();
+}
+
 // coarsen: out[n][y][x] = mean over the f x f cell   (planes = product of leading dims)
 __global__ void coarsen_kernel(const float* __restrict__ x, int64_t planes, int h, int w, int f, float* __restrict__ out) {
     const int ho = h / f, wo = w / f;

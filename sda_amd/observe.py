@@ -95,6 +95,27 @@ class Subsample(LinearObservation):
                                                  _stream()), 'sda_obs_subsample')
         return out
 
+    def gaussian_guidance(self, x: Tensor, eps: Tensor, y: Tensor, std: float, gamma: float, mu, sigma) -> Optional[Tensor]:
+        """``A^T((y - A((x - sigma eps)/mu)) / (std^2 + gamma (sigma/mu)^2))`` in one launch, or None when this operator /
+        these shapes need the general path (y not broadcastable over the leading axis, other dtypes)."""
+        ops._dev(x, eps, y)
+        oshape = tuple(self._osize(x.shape))
+        if not (tuple(y.shape) == oshape or tuple(y.shape) == oshape[1:] or
+                (y.dim() == len(oshape) and y.shape[0] == 1 and tuple(y.shape[1:]) == oshape[1:])):
+            return None
+        if x.dtype != torch.float32 or eps.dtype != torch.float32 or y.dtype != torch.float32:
+            return None
+        xs, es, ys = x.contiguous(), eps.contiguous(), y.contiguous()
+        size, start, step, stops = self._spec(xs.shape)
+        stop = list(size)
+        stop[5 - len(stops):] = stops                      # (exclusive ends of the sliced trailing dims)
+        g = torch.empty_like(xs)
+        m, s_, pair = ops._coef(mu, sigma)
+        _lib.check(_lib.load().sda_obs_subsample_guidance(xs.data_ptr(), es.data_ptr(), ys.data_ptr(), ys.numel(), _I5(*size),
+                                                          _I5(*start), _I5(*step), _I5(*stop), float(std), float(gamma), m, s_,
+                                                          ops._ptr(pair), g.data_ptr(), _stream()), 'sda_obs_subsample_guidance')
+        return g
+
     def adjoint(self, r: Tensor, x_shape) -> Tensor:
         ops._dev(r)
         x_shape = tuple(x_shape)

@@ -577,6 +577,17 @@ class GaussianScore(nn.Module):
         mu, sigma = _mu_sigma(self.sde, t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
         eps_d = eps.detach().contiguous()
+
+        ghat = None
+        fused = getattr(self.A, 'gaussian_guidance', None)
+        if fused is not None and self._scalars is not None:
+            # subsampling observation, scalar std / gamma: denoise + A + cotangent + A^T in one launch
+            yq = self.y
+            if rows is not None and yq.dim() == x.dim() and yq.shape[0] == rows[2]:
+                yq = yq[rows[0]:rows[1]]
+            ghat = fused(x.contiguous(), eps_d, yq, self._scalars[0], self._scalars[1], mu, sigma)
+        if ghat is not None:
+            return self._finish(eps_d, ghat, vjp, mu, sigma, out, grad_only)
         xhat = torch.empty_like(eps_d)
         ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
 
@@ -612,6 +623,9 @@ class GaussianScore(nn.Module):
                 cot = cot.sum_to_size(ax.shape)
             ghat, = torch.autograd.grad(ax, xhat, cot)
             ghat = ghat.contiguous()
+        return self._finish(eps_d, ghat, vjp, mu, sigma, out, grad_only)
+
+    def _finish(self, eps_d: Tensor, ghat: Tensor, vjp, mu, sigma, out, grad_only: bool) -> Tensor:
         if out is None:
             out = torch.empty_like(eps_d)
         v = None if vjp is None else vjp(ghat).contiguous()

@@ -523,3 +523,33 @@ def test_fused_1d_block_equals_per_layer_path_and_oracle(dev, monkeypatch, chann
     gxo, = torch.autograd.grad(yo, xo, g.cpu().double())
     assert_close(y_f, yo.detach().float(), 1e-4, what='fused forward vs oracle')
     assert_close(gx_f, gxo.float(), 1e-4, what='fused VJP vs oracle')
+
+
+@pytest.mark.gpu
+def test_fused_subsample_guidance_equals_general_path(dev, monkeypatch):
+    """GaussianScore with a subsampling observation: the one-launch guidance (denoise + A + cotangent + A^T) against the
+    general path (separate kernels), for a shared y, a leading-1 y and a per-sample y; slices with a stop fall back."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    net = build_unet1d_tiny().to(dev)
+    torch.manual_seed(4)
+    x = torch.randn(3, 16, 3, device=dev)
+    t = torch.tensor(0.37, device=dev)
+    A = Ob.Subsample((slice(None, None, 4), slice(0, None, 2)))
+    ax_shape = A(x).shape
+    for y in (torch.randn(ax_shape[1:], device=dev), torch.randn((1,) + tuple(ax_shape[1:]), device=dev), torch.randn(ax_shape, device=dev)):
+        gs = GaussianScore(y, A=A, std=0.3, sde=VPSDE(net, shape=()), gamma=2e-2).to(dev)
+        fused = gs(x, t)
+        with monkeypatch.context() as m:
+            m.setattr(Ob.Subsample, 'gaussian_guidance', lambda self, *a, **k: None)
+            general = gs(x, t)
+        assert_close(fused, general, 1e-6, what=f'fused guidance, y {tuple(y.shape)}')
+    # slices with a stop (x[..., ::8, :1] of lorenz/eval.py:75; a cut-off range)
+    for sl in ((slice(None, None, 8), slice(0, 1)), (slice(2, 12, 4), slice(1, 3))):
+        As = Ob.Subsample(sl)
+        gs = GaussianScore(torch.randn(As(x).shape, device=dev), A=As, std=0.3, sde=VPSDE(net, shape=()), gamma=2e-2).to(dev)
+        fused = gs(x, t)
+        with monkeypatch.context() as m:
+            m.setattr(Ob.Subsample, 'gaussian_guidance', lambda self, *a, **k: None)
+            general = gs(x, t)
+        assert_close(fused, general, 1e-6, what=f'fused guidance, slices {sl}')
