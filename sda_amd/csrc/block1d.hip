@@ -18,6 +18,20 @@
 
 typedef float b1_f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef SDA_B1_TRACE                    // tooling: per-phase cycle sums of workgroup 0 / wave 0 (tools/block1d_trace.py)
+__device__ long long b1_trace[16];
+#define B1_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); b1_trace[k] += n_ - b1_tl; b1_tl = n_; } } while (0)
+#define B1_T0() long long b1_tl = __builtin_readcyclecounter()
+extern "C" int sda_b1_trace_read(long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(b1_trace), sizeof(long long) * 16) != hipSuccess) return SDA_E_BADARG;
+    if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(b1_trace), z, sizeof(z)); }
+    return SDA_OK;
+}
+#else
+#define B1_STAMP(k) do {} while (0)
+#define B1_T0() do {} while (0)
+#endif
+
 struct B1Ctx {
     int tid, lane, wave, kq, li, co0, n, p0, ncb;
     bool wave_on;
@@ -25,12 +39,15 @@ struct B1Ctx {
 
 // all A fragments of one convolution for this wave (unconditional loads from clamped addresses: one batch, one round trip)
 __device__ __forceinline__ void b1_load_w(const sda_block1d_desc& d, const float* w, const B1Ctx& c, float (&wreg)[3][16]) {
+    // per-lane base + wave-uniform fragment offset (scalar arithmetic: the loads take an SGPR offset), 32-bit throughout
+    const float* wl = w + c.kq * d.m_pad + (c.wave_on ? c.co0 : 0) + c.li;
+    const int frag = 4 * d.m_pad, tapstride = d.k_pad * d.m_pad, last = (c.ncb - 1) * frag;
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
         for (int cb = 0; cb < 16; ++cb) {
-            const int cbc = cb < c.ncb ? cb : c.ncb - 1;
-            wreg[tap][cb] = w[((int64_t)tap * d.k_pad + 4 * cbc + c.kq) * d.m_pad + (c.wave_on ? c.co0 : 0) + c.li];
+            const int off = cb * frag < last ? cb * frag : last;           // (clamped: fragments beyond ncb are never multiplied)
+            wreg[tap][cb] = wl[__builtin_amdgcn_readfirstlane(tap * tapstride + off)];
         }
 }
 
@@ -43,22 +60,25 @@ __device__ __forceinline__ void b1_mm(const float (&wreg)[3][16], int ncb, const
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) bv[0][nf][tap] = brow[16 * nf + tap];
+    // (all 16 K fragments, unconditionally: a runtime trip count splits the unrolled loop into branches with accumulator
+    //  copies around each -- measured 11 000 cycles for 96 MFMAs; rows of the tile beyond the channel count are zero, so the
+    //  surplus fragments of a narrower net multiply clamped-address weights by zeros)
+    (void)ncb;
 #pragma unroll
     for (int cb = 0; cb < 16; ++cb) {
-        if (cb < ncb) {
-            const int cn = cb + 1 < ncb ? cb + 1 : cb;
+        constexpr int dummy = 0; (void)dummy;
+        const int cn = cb + 1 < 16 ? cb + 1 : cb;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * B1_LD + 16 * nf + tap];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * B1_LD + 16 * nf + tap];
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-                    acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
-        }
+                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
     }
 }
 
@@ -84,6 +104,7 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.kq = c.lane >> 4; c.li = c.lane & 15;
     c.co0 = 16 * c.wave; c.n = blockIdx.x / ptiles; c.p0 = (blockIdx.x - c.n * ptiles) * B1_TP; c.ncb = d.k_pad >> 2;
     c.wave_on = c.co0 < d.m_pad;
+    B1_T0();
     float w1[3][16], w2[3][16];
     b1_load_w(d, d.w1, c, w1);
     b1_load_w(d, d.w2, c, w2);
@@ -136,7 +157,9 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
         }
         __syncthreads();
     };
+    B1_STAMP(0);                                           // address arithmetic + issue of every load
     reduce_cols([&](int pass, int i) { return v[pass][i]; });
+    B1_STAMP(1);                                           // first use of the input loads: the global round trip + 1st reduction
     float mean[2], rstd[2];
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ci = cols_sub[pass] + 4 * i;
-                if (ci < d.k_pad) tin[ci * B1_LD + j] = (cin_[pass] && ci < d.c) ? (v[pass][i] - mean[pass]) * rstd[pass] : 0.f;
+                tin[ci * B1_LD + j] = (cin_[pass] && ci < d.c) ? (v[pass][i] - mean[pass]) * rstd[pass] : 0.f;
             }
             const int pos = c.p0 - 2 + j;
             if (cols_sub[pass] == 0 && j >= 2 && j < 2 + B1_TP && pos < d.len && d.mean) {
@@ -172,12 +195,15 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
         }
     }
     __syncthreads();
+    B1_STAMP(2);                                           // second reduction, normalised tile -> LDS
     // ---- conv1 on 80 columns (positions p0 - 1 ..): z = conv + b1 -> global (own 64 positions), act(z) -> LDS
-    if (c.wave_on) {
+    const bool silu = d.act == SDA_ACT_SILU;               // (the reference nets; other activations through one out-of-line switch)
+    auto act_any = [&](float z) __attribute__((noinline)) { return sda_act(d.act, z); };
+    {
         b1_f32x4 acc[NF1];
 #pragma unroll
         for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-        b1_mm<NF1>(w1, c.ncb, tin, c, acc);
+        if (c.wave_on) b1_mm<NF1>(w1, c.ncb, tin, c, acc);             // (waves beyond m_pad only zero their rows of the next tile)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c.co0 + 4 * c.kq + r;
@@ -190,11 +216,13 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
                 if (co < d.c && col >= 1 && col <= B1_TP && c.p0 - 1 + col < d.len && d.z)
                     d.z[((int64_t)c.n * d.c + co) * d.len + (c.p0 - 1 + col)] = z;
                 (void)ps;
-                if (co < d.k_pad) tz[co * B1_LD + col] = (inside && co < d.c) ? sda_act(d.act, z) : 0.f;
+                const float az = silu ? sda_act(SDA_ACT_SILU, z) : act_any(z);
+                tz[co * B1_LD + col] = (inside && co < d.c) ? az : 0.f;
             }
         }
     }
     __syncthreads();
+    B1_STAMP(3);                                           // conv1 (waits for the weight loads), z store, act -> LDS
     // ---- conv2 on the 64 positions, + b2 + a
     if (c.wave_on) {
         b1_f32x4 acc[NF2];
@@ -212,6 +240,7 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
             }
         }
     }
+    B1_STAMP(4);                                           // conv2 + store issue
 }
 
 // ------------------------------------------------------------------------------------------------------------ input VJP
@@ -284,16 +313,18 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ci = sub[pass] + 4 * i;
-                    if (ci < d.k_pad) tg[ci * B1_LD + colj[pass]] = (ins[pass] && ci < d.c) ? v[pass][i] : 0.f;
+                    tg[ci * B1_LD + colj[pass]] = (ins[pass] && ci < d.c) ? v[pass][i] : 0.f;
                 }
     }
     __syncthreads();
     // ---- conv2^T on 80 columns, x act'(z) -> LDS
-    if (c.wave_on) {
+    const bool silu = d.act == SDA_ACT_SILU;
+    auto dact_any = [&](float z) __attribute__((noinline)) { return sda_dact(d.act, z); };
+    {
         b1_f32x4 acc[NF1];
 #pragma unroll
         for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
-        b1_mm<NF1>(w2, c.ncb, tg, c, acc);
+        if (c.wave_on) b1_mm<NF1>(w2, c.ncb, tg, c, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c.co0 + 4 * c.kq + r;
@@ -302,7 +333,8 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
                 const int col = 16 * nf + c.li;
                 bool inside;
                 (void)b1_pos(d, c.p0 - 1 + col, inside);
-                if (co < d.k_pad) tq[co * B1_LD + col] = (inside && co < d.c) ? acc[nf][r] * sda_dact(d.act, ez[r][nf]) : 0.f;
+                const float dz = silu ? sda_dact(SDA_ACT_SILU, ez[r][nf]) : dact_any(ez[r][nf]);
+                tq[co * B1_LD + col] = (inside && co < d.c) ? acc[nf][r] * dz : 0.f;
             }
         }
     }

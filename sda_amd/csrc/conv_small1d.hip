@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
                     if (mp) t += mv[i];
                     t = (t - mean) * rstd;
                     if constexpr (AM == 1) t = sda_act(SDA_ACT_SILU, t);
-                    if (ci < d.cin_pad) sin[ci * S1_LD + j] = (inside && ci < d.cx) ? t : 0.f;
+                    if (ci < S1_MAXC) sin[ci * S1_LD + j] = (inside && ci < d.cx) ? t : 0.f;
                 }
             } else {
 #pragma unroll 1
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
                     float t = v[i];
                     if (mp) t += mv[i];
                     t = sda_act(d.act_in, (t - mean) * rstd);
-                    if (ci < d.cin_pad) sin[ci * S1_LD + j] = (inside && ci < d.cx) ? t : 0.f;
+                    if (ci < S1_MAXC) sin[ci * S1_LD + j] = (inside && ci < d.cx) ? t : 0.f;
                 }
             }
         };
@@ -125,22 +125,22 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) bv[0][nf][tap] = brow[16 * nf + tap];
+    // (all 16 K fragments unconditionally: a runtime trip count turns the unrolled loop into branches with accumulator copies
+    //  around each; the LDS rows beyond cin are zero, so surplus fragments multiply clamped-address weights by zeros)
 #pragma unroll
     for (int cb = 0; cb < 16; ++cb) {
-        if (cb < ncb) {
-            const int cn = cb + 1 < ncb ? cb + 1 : cb;     // (the last fragment re-reads itself)
+        const int cn = cb + 1 < 16 ? cb + 1 : cb;          // (the last fragment re-reads itself)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * S1_LD + 16 * nf + tap];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * S1_LD + 16 * nf + tap];
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-                    acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
-        }
+                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
     }
     // ---- epilogue: lane holds couts co0 + 4 kq + r, position p0 + 16 nf + li
     auto dact_any = [&](float z) __attribute__((noinline)) { return sda_dact(d.act_d, z); };
