@@ -47,7 +47,7 @@ __device__ __forceinline__ void b1_load_w(const sda_block1d_desc& d, const float
 #pragma unroll
         for (int cb = 0; cb < 16; ++cb) {
             const int off = cb * frag < last ? cb * frag : last;           // (clamped: fragments beyond ncb are never multiplied)
-            wreg[tap][cb] = wl[__builtin_amdgcn_readfirstlane(tap * tapstride + off)];
+            wreg[tap][cb] = wl[tap * tapstride + off];     // (uniform: kernel arguments and constants only)
         }
 }
 
@@ -140,7 +140,14 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ci = cols_sub[pass] + 4 * i, cic = ci < d.c ? ci : d.c - 1;
-            float t = an[(int64_t)cic * d.len + ps] + (mp ? mq[cic] : 0.f);
+            float t;
+            if (pass == 0) {
+                // (first pass: the channel is wave uniform -- per-lane base + scalar offsets, a scalar load for the modulation)
+                const int cu = __builtin_amdgcn_readfirstlane(cic);
+                t = (an + ps)[cu * d.len] + (mp ? mq[cu] : 0.f);
+            } else {
+                t = an[(int64_t)cic * d.len + ps] + (mp ? mq[cic] : 0.f);
+            }
             v[pass][i] = (ci < d.c) ? t : 0.f;
         }
     }
@@ -198,28 +205,40 @@ __global__ __launch_bounds__(256) void block1d_fwd_kernel(const sda_block1d_desc
     B1_STAMP(2);                                           // second reduction, normalised tile -> LDS
     // ---- conv1 on 80 columns (positions p0 - 1 ..): z = conv + b1 -> global (own 64 positions), act(z) -> LDS
     const bool silu = d.act == SDA_ACT_SILU;               // (the reference nets; other activations through one out-of-line switch)
-    auto act_any = [&](float z) __attribute__((noinline)) { return sda_act(d.act, z); };
     {
         b1_f32x4 acc[NF1];
 #pragma unroll
         for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
         if (c.wave_on) b1_mm<NF1>(w1, c.ncb, tin, c, acc);             // (waves beyond m_pad only zero their rows of the next tile)
+        // per-column facts once (not per element): carries data / is one of the tile's own positions
+        bool cin1[NF1], cown[NF1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = c.co0 + 4 * c.kq + r;
-#pragma unroll
-            for (int nf = 0; nf < NF1; ++nf) {
-                const int col = 16 * nf + c.li;                       // position p0 - 1 + col
-                bool inside;
-                const int ps = b1_pos(d, c.p0 - 1 + col, inside);
-                const float z = acc[nf][r] + eb1[r];
-                if (co < d.c && col >= 1 && col <= B1_TP && c.p0 - 1 + col < d.len && d.z)
-                    d.z[((int64_t)c.n * d.c + co) * d.len + (c.p0 - 1 + col)] = z;
-                (void)ps;
-                const float az = silu ? sda_act(SDA_ACT_SILU, z) : act_any(z);
-                tz[co * B1_LD + col] = (inside && co < d.c) ? az : 0.f;
-            }
+        for (int nf = 0; nf < NF1; ++nf) {
+            const int col = 16 * nf + c.li;                           // position p0 - 1 + col
+            bool inside;
+            (void)b1_pos(d, c.p0 - 1 + col, inside);
+            cin1[nf] = inside;
+            cown[nf] = d.z != nullptr && col >= 1 && col <= B1_TP && c.p0 - 1 + col < d.len;
         }
+        float* const zt = d.z ? d.z + (int64_t)c.n * d.c * d.len + (c.p0 - 1) : nullptr;
+        auto epilogue = [&](auto SILU_) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c.co0 + 4 * c.kq + r;
+                const bool on = co < d.c;
+                float* const zr = zt + (on ? co : 0) * d.len;
+#pragma unroll
+                for (int nf = 0; nf < NF1; ++nf) {
+                    const int col = 16 * nf + c.li;
+                    const float z = acc[nf][r] + eb1[r];
+                    if (on && cown[nf]) zr[col] = z;
+                    const float az = decltype(SILU_)::value ? sda_act(SDA_ACT_SILU, z) : sda_act(d.act, z);
+                    tz[co * B1_LD + col] = (cin1[nf] && on) ? az : 0.f;
+                }
+            }
+        };
+        if (silu) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     __syncthreads();
     B1_STAMP(3);                                           // conv1 (waits for the weight loads), z store, act -> LDS
@@ -304,7 +323,8 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ci = sub[pass] + 4 * i, cic = ci < d.c ? ci : d.c - 1;
-                v[pass][i] = gn[(int64_t)cic * d.len + ps];
+                if (pass == 0) v[pass][i] = (gn + ps)[__builtin_amdgcn_readfirstlane(cic) * d.len];
+                else v[pass][i] = gn[(int64_t)cic * d.len + ps];
             }
         }
 #pragma unroll
@@ -319,24 +339,32 @@ __global__ __launch_bounds__(256) void block1d_bwd_kernel(const sda_block1d_desc
     __syncthreads();
     // ---- conv2^T on 80 columns, x act'(z) -> LDS
     const bool silu = d.act == SDA_ACT_SILU;
-    auto dact_any = [&](float z) __attribute__((noinline)) { return sda_dact(d.act, z); };
     {
         b1_f32x4 acc[NF1];
 #pragma unroll
         for (int nf = 0; nf < NF1; ++nf) acc[nf] = b1_f32x4{0.f, 0.f, 0.f, 0.f};
         if (c.wave_on) b1_mm<NF1>(w2, c.ncb, tg, c, acc);
+        bool cin1[NF1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = c.co0 + 4 * c.kq + r;
-#pragma unroll
-            for (int nf = 0; nf < NF1; ++nf) {
-                const int col = 16 * nf + c.li;
-                bool inside;
-                (void)b1_pos(d, c.p0 - 1 + col, inside);
-                const float dz = silu ? sda_dact(SDA_ACT_SILU, ez[r][nf]) : dact_any(ez[r][nf]);
-                tq[co * B1_LD + col] = (inside && co < d.c) ? acc[nf][r] * dz : 0.f;
-            }
+        for (int nf = 0; nf < NF1; ++nf) {
+            bool inside;
+            (void)b1_pos(d, c.p0 - 1 + 16 * nf + c.li, inside);
+            cin1[nf] = inside;
         }
+        auto epilogue = [&](auto SILU_) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c.co0 + 4 * c.kq + r;
+                const bool on = co < d.c;
+#pragma unroll
+                for (int nf = 0; nf < NF1; ++nf) {
+                    const float dz = decltype(SILU_)::value ? sda_dact(SDA_ACT_SILU, ez[r][nf]) : sda_dact(d.act, ez[r][nf]);
+                    tq[co * B1_LD + 16 * nf + c.li] = (cin1[nf] && on) ? acc[nf][r] * dz : 0.f;
+                }
+            }
+        };
+        if (silu) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     __syncthreads();
     // ---- conv1^T on the 64 positions -> gh; LayerNorm backward: gx = rstd (gh - mean_c(gh) - xh mean'_c(gh xh)) + g
