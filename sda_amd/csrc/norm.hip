@@ -94,6 +94,69 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_reg_kernel(const float* _
     }
 }
 
+// hw % 4 == 0, c <= SPLIT * CPL: a lane owns FOUR consecutive pixels (16-byte loads) and every SPLIT-th channel, the SPLIT lanes
+// of a quad sit 64 / SPLIT apart (see ln_bwd_quad_kernel); the channel vectors stay in registers between the mean and the
+// centred pass.
+template <int SPLIT, int CPL>
+__global__ __launch_bounds__(LN_THREADS) void ln_stats_quad_kernel(const float* __restrict__ x, int64_t nquad, int c, int hw,
+                                                                   const float* __restrict__ mod, int64_t mod_sn, float eps,
+                                                                   int unbiased, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd) {
+    constexpr int QW = 64 / SPLIT;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    const int64_t quad = wave * QW + (lane & (QW - 1));
+    const int sub = lane / QW;
+    const bool live = quad < nquad;
+    const int64_t pix = (live ? quad : 0) * 4;
+    const int64_t n = pix / hw;
+    const int p = (int)(pix - n * hw);
+    const float* xp = x + n * (int64_t)c * hw + p;
+    const float* mp = mod ? mod + n * mod_sn : nullptr;
+    float4 v[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int k = sub + SPLIT * j;
+        v[j] = *reinterpret_cast<const float4*>(xp + (int64_t)(k < c ? k : 0) * hw);
+        if (k >= c) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (mp) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int k = sub + SPLIT * j;
+            const float mv = k < c ? mp[k] : 0.f;
+            v[j].x += mv; v[j].y += mv; v[j].z += mv; v[j].w += mv;
+        }
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+#pragma unroll
+    for (int o = QW; o < 64; o <<= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+    }
+    const float ic = 1.f / (float)c;
+    const float4 m = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (sub + SPLIT * j < c) {
+            const float a = v[j].x - m.x, b = v[j].y - m.y, cc = v[j].z - m.z, dd = v[j].w - m.w;
+            q.x += a * a; q.y += b * b; q.z += cc * cc; q.w += dd * dd;
+        }
+    }
+#pragma unroll
+    for (int o = QW; o < 64; o <<= 1) {
+        q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64); q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
+    }
+    if (live && sub == 0) {
+        const float iv = 1.f / (float)(unbiased ? c - 1 : c);
+        *reinterpret_cast<float4*>(mean + pix) = m;
+        *reinterpret_cast<float4*>(rstd + pix) = make_float4(1.0f / sqrtf(q.x * iv + eps), 1.0f / sqrtf(q.y * iv + eps),
+                                                             1.0f / sqrtf(q.z * iv + eps), 1.0f / sqrtf(q.w * iv + eps));
+    }
+}
+
 // Few pixels (the 1-D Lorenz nets: n*hw in the hundreds): one thread per pixel would leave the chip idle and serialise a
 // dependent load per channel, so one WAVEFRONT takes a pixel, its 64 lanes stride the channel axis and reduce with shuffles.
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_wave_kernel(const float* __restrict__ x, int64_t npix, int c, int hw,
@@ -136,6 +199,17 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
     }
     const int64_t blocks = (npix + LN_THREADS - 1) / LN_THREADS;
     if (blocks > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    static const int quad_mode = getenv("SDA_LN_STATS_QUAD") ? atoi(getenv("SDA_LN_STATS_QUAD")) : 1;
+    if (quad_mode && hw % 4 == 0 && c > 48 && c <= 384 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15) == 0) {
+        const int64_t nquad = npix / 4;
+        hipStream_t st = (hipStream_t)stream;
+        dim3 bl(LN_THREADS);
+        if (c <= 96) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else if (c <= 192) hipLaunchKernelGGL((ln_stats_quad_kernel<16, 12>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else hipLaunchKernelGGL((ln_stats_quad_kernel<16, 24>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        return sda_launch_status();
+    }
     if (c > LN_REG_C / 2 && c <= 4 * LN_REG_C && blocks * 4 <= 0x7fffffffLL) {
         const int split = c <= LN_REG_C ? 1 : (c <= 2 * LN_REG_C ? 2 : 4);
         dim3 gr((unsigned)((npix * split + LN_THREADS - 1) / LN_THREADS)), bl(LN_THREADS);
@@ -301,9 +375,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* _
 // SPLIT-th channel; a wavefront covers 64 / SPLIT pixel quads, so each channel plane is touched in contiguous runs of
 // (64 / SPLIT) * 16 bytes -- a whole 128-byte line for SPLIT = 8 (the dword version above moves 64-byte runs with four times
 // the instructions).  The SPLIT lanes of a quad sit 64 / SPLIT apart and combine their partial sums with cross-lane adds.
-template <int SPLIT, int CPL>
+template <int SPLIT, int CPL, int POOL = 1>          // POOL == 2: gh at twice the resolution, summed over 2 x 2 cells (w = row length)
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __restrict__ gh, const float* __restrict__ x,
-                                                                 int64_t nquad, int c, int hw, const float* __restrict__ mod,
+                                                                 int64_t nquad, int c, int hw, int w, const float* __restrict__ mod,
                                                                  int64_t mod_sn, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, int unbiased,
                                                                  const float* __restrict__ res, float* __restrict__ gx) {
@@ -325,7 +399,16 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
         const int k = sub + SPLIT * j;
         const bool on = k < c;
         const int64_t off = base + (int64_t)(on ? k : 0) * hw;
-        g[j] = *reinterpret_cast<const float4*>(gh + off);
+        if (POOL == 1) {
+            g[j] = *reinterpret_cast<const float4*>(gh + off);
+        } else {
+            const int py = p / w, px = p - py * w;
+            const float* gp = gh + (n * (int64_t)c + (on ? k : 0)) * (4 * (int64_t)hw) + (int64_t)(2 * py) * (2 * w) + 2 * px;
+            const float4 a0 = *reinterpret_cast<const float4*>(gp), a1 = *reinterpret_cast<const float4*>(gp + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(gp + 2 * w), b1 = *reinterpret_cast<const float4*>(gp + 2 * w + 4);
+            g[j] = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y),
+                               (a1.z + a1.w) + (b1.z + b1.w));
+        }
         hh[j] = *reinterpret_cast<const float4*>(x + off);
         if (!on) { g[j] = make_float4(0.f, 0.f, 0.f, 0.f); hh[j] = make_float4(m4.x, m4.y, m4.z, m4.w); }
     }
@@ -449,13 +532,13 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         // (lanes per quad x channels per lane: c = 96: 8 x 12, 128-byte runs; c = 192 / 384: 16 x 12 / 16 x 24, 64-byte runs)
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else if (c <= 192) {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         }
     } else if (shape == 11 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
         // lanes per pixel x channels per lane, picked per width from measurements on the Kolmogorov net's three levels
@@ -466,6 +549,22 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         if (c <= 96) hipLaunchKernelGGL((ln_bwd_split_kernel<4, 24>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         else if (c <= 192) hipLaunchKernelGGL((ln_bwd_split_kernel<8, 24>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         else hipLaunchKernelGGL((ln_bwd_split_kernel<8, 48>), gr, block, 0, s, gh, x, npix, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+    } else if (shape == 22 && quad_mode && w % 4 == 0 && c > 48 && c <= 384 &&
+               ((reinterpret_cast<uintptr_t>(gh) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gx) |
+                 reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(res)) & 15) == 0) {
+        // (the up-sampling tails: gh at twice the resolution; 2 w floats per row keep every 16-byte load aligned)
+        const int hw = h * w;
+        const int64_t nquad = npix / 4;
+        if (c <= 96) {
+            dim3 gr((unsigned)((nquad + 31) / 32));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (c <= 192) {
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else {
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        }
     } else if (shape == 22 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
         const int hw = h * w;
         const int split = c <= 96 ? 4 : 8;
