@@ -72,7 +72,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
         return SDA_E_UNSUPPORTED;
     if (d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx) return SDA_E_UNSUPPORTED;
-    if (d->cctx > 0 || d->cout % W4_BM || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
+    if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || d->cout % W4_BM || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
     if ((d->ho & 7) || (d->wo & 15) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
     if (d->mod && d->mod_sn != 0) return SDA_E_UNSUPPORTED;
@@ -83,12 +83,17 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
         (d->dact_z && (reinterpret_cast<uintptr_t>(d->dact_z) & 7)) || (reinterpret_cast<uintptr_t>(d->w_wino4) & 15) ||
         (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)))
         return SDA_E_UNSUPPORTED;
-    if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 || d->n_inner != 1) return SDA_E_UNSUPPORTED;      // (no window view)
+    if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 || d->n_inner < 1) return SDA_E_UNSUPPORTED;
+    // context channels (planar [cctx][hs][ws], appended after the cx source channels -- the forcing channel of the Kolmogorov
+    // head convolution) share the halo offsets of the source: needs a source with planar rows and no loader fusion
+    if (d->cctx > 0 && (d->x_sy != d->ws || d->x_sx != 1 || d->mod || d->ln_mean || d->act_in != SDA_ACT_NONE || d->up_h != 1 ||
+                        d->up_w != 1 || d->ctx_sn < 0 || (int64_t)d->cctx * d->hs * d->ws >= (1LL << 28)))
+        return SDA_E_UNSUPPORTED;
     // 32-bit BYTE offsets inside one image (channel base included)
     if ((int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 30)) return SDA_E_UNSUPPORTED;
     if ((int64_t)48 * d->ho * d->wo * 4 >= (1LL << 31)) return SDA_E_UNSUPPORTED;            // (epilogue buffer descriptors)
     if ((int64_t)d->cout * d->ho * d->wo >= (1LL << 30) || (int64_t)d->n * d->hs * d->ws >= (1LL << 31)) return SDA_E_UNSUPPORTED;
-    g->cin = d->cx;
+    g->cin = d->cx + d->cctx;
     g->hv = d->ho; g->wv = d->wo;
     g->bx_n = d->wo / 16; g->by_n = d->ho / 8;
     g->n_ct = d->cout / W4_BM;
@@ -233,8 +238,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // per-tile halo geometry of the issue cursor
         unsigned goff[W4_NSLOT], gstat[W4_NSLOT] = {0u, 0u, 0u}, glive = 0;   // gstat: byte offset of the pixel's LN statistics
         const float* gimg = d.x;
+        const float* gctx = d.ctx;                         // context planes of the tile's image (NULL = none)
         auto geometry = [&](const W4Cur& t) {
-            gimg = d.x + (int64_t)(t.n + d.x_n_off) * d.x_sn_outer;
+            const int m_img = t.n + d.x_n_off;             // image -> (trajectory, window) for the sliding-window view
+            const int m_out = d.n_inner == 1 ? m_img : m_img / d.n_inner;
+            gimg = d.x + (int64_t)m_out * d.x_sn_outer + (int64_t)(m_img - m_out * d.n_inner) * d.x_sn_inner;
+            if (d.cctx > 0) gctx = d.ctx + (int64_t)t.n * d.ctx_sn;
             glive = 0;
 #pragma unroll
             for (int i = 0; i < W4_NSLOT; ++i) {
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const int cc = W4_CK * t.st + 2 * pw + ch;
                 const int cce = cc < g.cin ? cc : 0;       // (padded channels read channel 0 and are zeroed at commit)
                 const char* xc = reinterpret_cast<const char*>(gimg + (int64_t)cce * d.x_sc);
+                if (cce >= d.cx) xc = reinterpret_cast<const char*>(gctx + (int64_t)(cce - d.cx) * (d.hs * d.ws));   // (wave uniform)
 #pragma unroll
                 for (int i = 0; i < W4_NSLOT; ++i) w4_ld1(h.v[ch][i], xc, goff[i]);
                 if constexpr (MOD) w4_ld1(h.mv[ch], reinterpret_cast<const char*>(d.mod + cce), 0u);
