@@ -388,3 +388,36 @@ def test_small_1d_conv_kernel_serves_the_lorenz_shapes(dev):
                        ln=(mean.float().reshape(n, -1), rstd.float().reshape(n, -1)), act_in=ACT_IDS['SiLU'],
                        dact_z=z, act_d=ACT_IDS['SiLU'], res=res)
         assert_close(out.cpu(), ref.float(), 1e-4, what=f'small 1-D conv {(n, cin, cout, length, circular)}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('circular', [True, False])
+def test_winograd4_window_view_and_context_channel(dev, circular):
+    """The Kolmogorov head convolution on the second-generation Winograd kernel: MCScoreNet windows read straight out of
+    (B, L, C, H, W) (two-level image index), the forcing plane as a broadcast context channel, 11 -> 96 channels (a partial
+    second K-stage); also a per-image context and a chunk offset."""
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv
+    torch.manual_seed(12)
+    B, L, C, H, W, k = 2, 7, 2, 16, 32, 2
+    x = torch.randn(B, L, C, H, W)
+    wgt, b = torch.randn(96, (2 * k + 1) * C + 1, 3, 3) * 0.2, torch.randn(96)
+    nw = L - 2 * k
+    win = O.unfold(x, k)                                                    # (B, nw, 10, H, W)
+    pk = ops.PackedConv(wgt.to(dev), b.to(dev))
+    xd = x.to(dev)
+    for ctx, ctx_sn in ((torch.randn(1, H, W), 0), (torch.randn(B * nw, 1, H, W), H * W)):
+        cfull = ctx.expand(B * nw, 1, H, W) if ctx_sn == 0 else ctx
+        full = torch.cat((win.reshape(B * nw, -1, H, W), cfull), dim=1)
+        ref = ref_conv(full, wgt, b, 1, circular)
+        for lo in (0, 2):
+            n = B * nw - lo
+            out = torch.full((n, 96, H, W), float('nan'), device=dev)
+            src = dict(x_ptr=xd.data_ptr(), n=n, cx=(2 * k + 1) * C, hs=H, ws=W, x_sn_outer=xd.stride(0), x_sn_inner=xd.stride(1),
+                       n_inner=nw, x_n_off=lo, x_sc=H * W, x_sy=W, x_sx=1)
+            cd = ctx.to(dev).contiguous()
+            cview = cd if ctx_sn == 0 else cd[lo:]
+            desc = launch_conv(pk, src, out, H, W, circular=circular, bias=pk.bias, ctx=cview, cctx=1, ctx_sn=ctx_sn)
+            torch.cuda.synchronize()
+            assert ops.conv_path(desc) == 2, 'expected the second-generation Winograd kernel'
+            assert_close(out.cpu(), ref[lo:], 1e-4, what=f'window view + context (ctx_sn={ctx_sn}, lo={lo})')
