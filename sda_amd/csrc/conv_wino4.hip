@@ -166,6 +166,9 @@ __device__ __forceinline__ void w4_advance(const Wino4Geom& g, W4Cur& c) {
 __device__ __forceinline__ void w4_ld1(float& dst, const char* base, unsigned off) {
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
 }
+__device__ __forceinline__ void w4_ld2(f32x2& dst, const char* base, unsigned off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
 template <int OFF>
 __device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned off) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(OFF) : "memory");
@@ -173,8 +176,10 @@ __device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned of
 
 
 // MOD / LN / SILU: the loader fusions of the launch (modulation add, LayerNorm, SiLU) as compile-time switches
+// EPI: the epilogue operand (residual or activation-derivative input) reaches the consumers through the helpers' registers and
+//      LDS instead of their own global loads (see "epilogue operand" in the helpers)
 // VAR: ablation variant (0 = shipped; others exist only under -DSDA_W4_VARIANTS for tools/wino4_check.py --variants)
-template <bool MOD, bool LN, bool SILU, int VAR = 0>
+template <bool MOD, bool LN, bool SILU, bool EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
 #define W4_WAIT_U(N)                                                                                                           \
     asm volatile("s_waitcnt vmcnt(%14)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
                  "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]), "+v"(pfreg[0]),   \
-                 "+v"(pfreg[1]) : "n"(N) : "memory")
+                 "+v"(pfreg[1]) : "n"(N) : "memory");                                                                         \
+    W4_PIN_EPI()
         auto u_store = [&](float* ub) {
             float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
 #pragma unroll
@@ -405,7 +411,72 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // on the weights, so that the hand-counted vmcnt values do not depend on the launch.
         const float* const pf_t = d.res ? d.res : d.dact_z;
         const unsigned pf_off = (unsigned)(((pw * 8 + (lane >> 3)) * (d.ho * d.wo) + (lane & 7) * d.wo) * 4);
-        float pfreg[2] = {0.f, 0.f};
+        float pfreg[EPI ? 8 : 2] = {0.f, 0.f};
+        // EPI launches: the helpers LOAD the operand instead (wave pw for consumer wave pw, lane for lane: the 24 8-byte pairs
+        // the consumer lane's epilogue needs -- plane 16 m + r, rows 0 / 1 of its 2 x 2 output block), four pairs per iteration
+        // while the issue cursor is in the tile's last six stages, into 48 registers that wait for the tile's end.  There the
+        // pairs go to LDS -- the U buffer the consumers released at the tile's last hand-off, [wave][pair 24][lane] x 8 bytes,
+        // lane-linear both ways -- between two extra barriers: X1 (operand in LDS; the consumers arrive after the first
+        // inverse transform) and X2 (operand read; the helper refills the buffer).  A consumer-side global load would queue
+        // behind everything the helpers have in flight on the CU's vector-memory path: ~1 us per dependent round trip, three
+        // of them per tile.  Outside the window the four loads are issued all the same (dummies on the weights: static counts).
+        f32x2 eop[EPI ? 24 : 1];
+#pragma unroll
+        for (int j = 0; j < (EPI ? 24 : 1); ++j) eop[j] = f32x2{0.f, 0.f};
+        const int e_hw = d.ho * d.wo;
+        const int e_t = 16 * (pw & 1) + (lane & 15);
+        const unsigned e_lo0 = (unsigned)(((4 * (lane >> 4)) * e_hw + 2 * (e_t >> 3) * d.wo + 2 * (e_t & 7)) * 4);
+        const unsigned e_lo1 = e_lo0 + (unsigned)d.wo * 4u;
+        const int e_first = g.nstage - 6;
+#define W4_PIN_EPI()                                                                                                           \
+    do {                                                                                                                       \
+        if constexpr (EPI) {                                                                                                   \
+            asm volatile("" : "+v"(pfreg[2]), "+v"(pfreg[3]), "+v"(pfreg[4]), "+v"(pfreg[5]), "+v"(pfreg[6]), "+v"(pfreg[7]) :: "memory"); \
+            asm volatile("" : "+v"(eop[0]), "+v"(eop[1]), "+v"(eop[2]), "+v"(eop[3]), "+v"(eop[4]), "+v"(eop[5]), "+v"(eop[6]),     \
+                         "+v"(eop[7]), "+v"(eop[8]), "+v"(eop[9]), "+v"(eop[10]), "+v"(eop[11]) :: "memory");                        \
+            asm volatile("" : "+v"(eop[12]), "+v"(eop[13]), "+v"(eop[14]), "+v"(eop[15]), "+v"(eop[16]), "+v"(eop[17]),            \
+                         "+v"(eop[18]), "+v"(eop[19]), "+v"(eop[20]), "+v"(eop[21]), "+v"(eop[22]), "+v"(eop[23]) :: "memory");     \
+        }                                                                                                                      \
+    } while (0)
+        // One straight-line statement per window slot K (its four loads are skipped INSIDE the asm text unless k == K): a C++
+        // switch would put the 24 destination registers through phi copies -- vector moves of registers with loads in flight.
+#define W4_EPI_SLOT(K)                                                                                                         \
+    asm volatile("s_cmp_lg_u32 %4, " #K "\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"                                           \
+                 "global_load_dwordx2 %0, %5, %7\n\tglobal_load_dwordx2 %1, %6, %7\n\t"                                        \
+                 "global_load_dwordx2 %2, %5, %8\n\tglobal_load_dwordx2 %3, %6, %8\n.Lw4epi%=:"                                 \
+                 : "+v"(eop[4 * K + 0]), "+v"(eop[4 * K + 1]), "+v"(eop[4 * K + 2]), "+v"(eop[4 * K + 3])                      \
+                 : "s"(k), "v"(e_lo0), "v"(e_lo1), "s"(b0), "s"(b1) : "memory", "scc")
+        auto epi_issue = [&](const W4Cur& t, float& dm0, float& dm1, float& dm2, float& dm3) {
+            if constexpr (EPI) {
+                const int k = t.st - e_first;              // window slot: planes 16 (k >> 1) + 2 (k & 1) and the next one
+                const int kc = k < 0 ? 0 : k;
+                const int64_t ps = (int64_t)e_hw * 4;
+                const char* b0 = reinterpret_cast<const char*>(pf_t + ((int64_t)t.n * d.cout + W4_BM * t.ct + 48 * (pw >> 1)) * e_hw +
+                                                               (8 * t.by) * d.wo + 16 * t.bx) + (16 * (kc >> 1) + 2 * (kc & 1)) * ps;
+                const char* b1 = b0 + ps;
+                W4_EPI_SLOT(0); W4_EPI_SLOT(1); W4_EPI_SLOT(2); W4_EPI_SLOT(3); W4_EPI_SLOT(4); W4_EPI_SLOT(5);
+                // outside the window: four dummy loads on the weights (the hand-counted vmcnt values are static)
+                asm volatile("s_cmp_lt_u32 %4, 6\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"
+                             "global_load_dword %0, %5, %6\n\tglobal_load_dword %1, %5, %6\n\t"
+                             "global_load_dword %2, %5, %6\n\tglobal_load_dword %3, %5, %6\n.Lw4epi%=:"
+                             : "+v"(dm0), "+v"(dm1), "+v"(dm2), "+v"(dm3)
+                             : "s"(k), "v"(lane16), "s"(reinterpret_cast<const char*>(d.w_wino4)) : "memory", "scc");
+            }
+        };
+        // the tile's operand: registers -> LDS (the U buffer of stage q + 1, free since the hand-off E_(q-1)), X1, X2
+        auto epi_store = [&](int q) {
+            if constexpr (EPI) {
+                float* rb = ubuf + ((q + 1) & 1) * W4_UBUF + (pw * 24 * 64 + lane) * 2;
+#pragma unroll
+                for (int j = 0; j < 24; ++j) *reinterpret_cast<f32x2*>(rb + j * 128) = eop[j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // X1
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // X2
+                asm volatile("" ::: "memory");
+            }
+        };
+        int cst = 0;                                       // stage-in-tile of the consumers' stage q
         const int pf_first = g.nstage > 3 ? g.nstage - 3 : 0;
         auto prefetch = [&](const W4Cur& t, float& dst) {
             const int k = t.st - pf_first;
@@ -436,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         W4_TRACE_DECL;
         constexpr int NHL = 2 * W4_NSLOT + (LN ? 2 * W4_NSLOT : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
-        constexpr int NUL = 12, NPF = 1;                   // loads per U slab quarter / per prefetch
+        constexpr int NUL = 12, NPF = EPI ? 4 : 1;         // loads per U slab quarter / per prefetch (EPI: operand loads)
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;
@@ -458,7 +529,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         commit(c2, h1);
         step2();
         step_issue();
-        prefetch(ci, pfreg[1]);
+        if constexpr (EPI) epi_issue(ci, pfreg[4], pfreg[5], pfreg[6], pfreg[7]);
+        else prefetch(ci, pfreg[1]);
         issue(ci, h0); tag(h0);
         handoff();
         // One helper iteration, while the consumers multiply stage q.  The fp32 MFMA stream owns the SIMD's vector ALU: a
@@ -472,9 +544,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         //        under the MFMAs of step 7 -- no LDS round trip between stages.
         // Before M_q the helper runs what needs no VALU: U registers -> LDS, the U loads of stage q + 2, the patch reads of
         // stage q + 1; between M_q and E_q the halo loads of stage q + 5.
-        auto iteration = [&](int q, Halo& hcommit, Halo& hissue, float& pfdst) {
+        auto iteration = [&](int q, Halo& hcommit, Halo& hissue, auto PAR_) {
+            constexpr int PAR = decltype(PAR_)::value;
             float* ub = ubuf + ((q + 1) & 1) * W4_UBUF;
             float* vb = vbuf + ((q + 1) & 1) * W4_VBUF;
+            if constexpr (EPI) {
+                if (cst == 0 && q > 0) epi_store(q);       // the consumers are in the epilogue of the tile that just ended
+                const int wrap = w4_eq(cst + 1, g.nstage);
+                cst = (cst + 1) * (1 - wrap);
+            }
             W4_T0();
             // the U registers were loaded one iteration ago, before that iteration's halo loads
             W4_WAIT_U(NHL + NPF);
@@ -517,7 +595,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
             W4_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
-            prefetch(ci, pfdst);
+            if constexpr (EPI) epi_issue(ci, pfreg[4 * PAR], pfreg[4 * PAR + 1], pfreg[4 * PAR + 2], pfreg[4 * PAR + 3]);
+            else prefetch(ci, pfreg[PAR]);
             if (!W4_DBG(256)) issue(ci, hissue);
             __builtin_amdgcn_sched_barrier(0);
             W4_STAMP(4);                                       // halo loads
@@ -525,12 +604,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_STAMP(5);
         };
         for (int q = 0; q < Q; q += 4) {
-            iteration(q, h2, h1, pfreg[0]);
-            if (q + 1 < Q) iteration(q + 1, h3, h2, pfreg[1]);
-            if (q + 2 < Q) iteration(q + 2, h0, h3, pfreg[0]);
-            if (q + 3 < Q) iteration(q + 3, h1, h0, pfreg[1]);
+            iteration(q, h2, h1, std::integral_constant<int, 0>{});
+            if (q + 1 < Q) iteration(q + 1, h3, h2, std::integral_constant<int, 1>{});
+            if (q + 2 < Q) iteration(q + 2, h0, h3, std::integral_constant<int, 0>{});
+            if (q + 3 < Q) iteration(q + 3, h1, h0, std::integral_constant<int, 1>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (EPI) { W4_PIN_EPI(); epi_store(Q); }     // the last tile's operand
         W4_TRACE_OUT();
         return;
     }
@@ -666,9 +746,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             //      and a scalar offset per cout -- no 64-bit vector address arithmetic.
             const W4Cur& tt = c0;
             const int hw_o = d.ho * d.wo;
-            const int t = 16 * wn + li;
+            // (EPI: the per-lane addresses are rebuilt from a lane id the compiler cannot hoist out of the tile loop -- kept
+            // live across the multiply they are spilled, and a scratch reload here queues behind the helpers' loads)
+            int lane_e = lane;
+            if constexpr (EPI) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            const int li_e = EPI ? (lane_e & 15) : li, kq_e = EPI ? (lane_e >> 4) : kq;
+            const int t = 16 * wn + li_e;
             const int oy = 8 * tt.by + 2 * (t >> 3), ox = 16 * tt.bx + 2 * (t & 7);
-            const int lo0 = ((4 * kq) * hw_o + oy * d.wo + ox) * 4, lo1 = lo0 + d.wo * 4;
+            const int lo0 = ((4 * kq_e) * hw_o + oy * d.wo + ox) * 4, lo1 = lo0 + d.wo * 4;
             const int64_t sbase = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 48 * wm) * hw_o;
             const int plane_bytes = 48 * hw_o * 4;
             auto rsrc_of = [&](const float* p) {
@@ -679,8 +764,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const auto r_out = rsrc_of(d.out);
                 const auto r_z = rsrc_of(DACT ? d.dact_z : d.out);
                 const auto r_res = rsrc_of(RES ? d.res : d.out);
+                // EPI: the operand pairs of this lane in the U buffer the last stage released: [wave][pair 24][lane]
+                const float* el = ubuf + ((q + 1) & 1) * W4_UBUF + (wave * 24 * 64 + lane_e) * 2;
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
+                    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);            // (one fragment at a time: register pressure)
                     // rows (xi): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 for each nu;  columns (nu): the same combination
                     f32x4 s0[4], s1[4];
 #pragma unroll
@@ -690,13 +778,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     }
                     const f32x4 y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
                     const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+                    if constexpr (EPI) {
+                        if (m == 0) {                                                // X1: the helpers have stored the operand
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int so = (16 * m + r) * hw_o * 4;                      // scalar byte offset of the cout plane
                         f32x2 y0 = {y00[r], y01[r]}, y1 = {y10[r], y11[r]};
+                        f32x2 e0, e1;
+                        if constexpr (EPI) {
+                            e0 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 0) * 128);
+                            e1 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 1) * 128);
+                            if (m == 2 && r == 3) {                                  // X2: all of it is in registers
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                __builtin_amdgcn_s_barrier();
+                                asm volatile("" ::: "memory");
+                            }
+                        }
                         if constexpr (DACT) {
-                            const f32x2 q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo0, so, 0));
-                            const f32x2 q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo1, so, 0));
+                            f32x2 q0, q1;
+                            if constexpr (EPI) { q0 = e0; q1 = e1; }
+                            else {
+                                q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo0, so, 0));
+                                q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo1, so, 0));
+                            }
                             if (d.act_d == SDA_ACT_SILU) {
                                 y0[0] *= sda_dact(SDA_ACT_SILU, q0[0]); y0[1] *= sda_dact(SDA_ACT_SILU, q0[1]);
                                 y1[0] *= sda_dact(SDA_ACT_SILU, q1[0]); y1[1] *= sda_dact(SDA_ACT_SILU, q1[1]);
@@ -706,8 +815,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                             }
                         }
                         if constexpr (RES) {
-                            y0 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo0, so, 0));
-                            y1 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo1, so, 0));
+                            if constexpr (EPI) { y0 += e0; y1 += e1; }
+                            else {
+                                y0 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo0, so, 0));
+                                y1 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo1, so, 0));
+                            }
                         }
                         if (!(g.debug & 8)) {
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w4_u32x2, y0), r_out, lo0, so, 0);
@@ -716,7 +828,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     }
                 }
             };
-            if (d.dact_z) {
+            if constexpr (EPI) {                           // (exactly one of the two operands: the launch condition)
+                if (d.dact_z) run(std::true_type{}, std::false_type{});
+                else run(std::false_type{}, std::true_type{});
+            } else if (d.dact_z) {
                 if (d.res) run(std::true_type{}, std::true_type{});
                 else run(std::true_type{}, std::false_type{});
             } else {
@@ -747,13 +862,13 @@ extern "C" int sda_w4_trace_read(double* out) {
 }
 #endif
 
-template <bool MOD, bool LN, bool SILU, int VAR>
+template <bool MOD, bool LN, bool SILU, bool EPI, int VAR>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
     static_assert(W4_LDS_BYTES <= 160 * 1024, "LDS");
     static bool attr_set[SDA_MAX_DEVICES];
-    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, VAR>), W4_LDS_BYTES, attr_set);
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR>), W4_LDS_BYTES, attr_set);
     if (rc != SDA_OK) return rc;
-    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, VAR>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
+    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
     return sda_launch_status();
 }
 
@@ -773,6 +888,10 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
     const int need = (g.grid + 7) / 8 * 8;
     if (grid > need) grid = need;
     if (grid < 8) grid = 8;
+    // the epilogue operand through the helpers (EPI): one operand, tiles of at least twelve stages (the six-stage load window
+    // of a tile must open after the previous tile's operand has left the registers)
+    static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
+    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12;
     switch (wino4_config(d)) {
         case 0: {
 #ifdef SDA_W4_VARIANTS
@@ -783,16 +902,19 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
                     if (!tbuf && hipMalloc(&tbuf, 256 * 64 * sizeof(long long)) != hipSuccess) return SDA_E_BADARG;
                     (void)hipMemsetAsync(tbuf, 0, 256 * 64 * sizeof(long long), stream);
                     Wino4Geom gt = g; gt.trace = tbuf; w4_trace_buf = tbuf; w4_trace_grid = grid;
-                    return wino4_launch_t<false, false, false, 11>(d, gt, grid, stream);
+                    return epi ? wino4_launch_t<false, false, false, true, 11>(d, gt, grid, stream)
+                               : wino4_launch_t<false, false, false, false, 11>(d, gt, grid, stream);
                 }
                 default: break;
             }
 #endif
-            return wino4_launch_t<false, false, false, 0>(d, g, grid, stream);
+            return epi ? wino4_launch_t<false, false, false, true, 0>(d, g, grid, stream)
+                       : wino4_launch_t<false, false, false, false, 0>(d, g, grid, stream);
         }
-        case 1: return wino4_launch_t<false, false, true, 0>(d, g, grid, stream);
-        case 2: return wino4_launch_t<false, true, false, 0>(d, g, grid, stream);
-        case 6: return wino4_launch_t<true, true, false, 0>(d, g, grid, stream);
+        case 1: return epi ? wino4_launch_t<false, false, true, true, 0>(d, g, grid, stream)
+                           : wino4_launch_t<false, false, true, false, 0>(d, g, grid, stream);
+        case 2: return wino4_launch_t<false, true, false, false, 0>(d, g, grid, stream);
+        case 6: return wino4_launch_t<true, true, false, false, 0>(d, g, grid, stream);
         default: return SDA_E_UNSUPPORTED;
     }
 }
