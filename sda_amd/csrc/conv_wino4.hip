@@ -780,6 +780,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     const f32x4 y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
                     if constexpr (EPI) {
                         if (m == 0) {                                                // X1: the helpers have stored the operand
+                            // (behind the first fragment's inverse transform: the helpers' stores take as long)
+                            asm volatile("" :: "v"(y00), "v"(y01), "v"(y10), "v"(y11));
                             __builtin_amdgcn_sched_barrier(0);
                             __builtin_amdgcn_s_barrier();
                             asm volatile("" ::: "memory");

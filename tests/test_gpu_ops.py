@@ -421,3 +421,35 @@ def test_winograd4_window_view_and_context_channel(dev, circular):
             torch.cuda.synchronize()
             assert ops.conv_path(desc) == 2, 'expected the second-generation Winograd kernel'
             assert_close(out.cpu(), ref[lo:], 1e-4, what=f'window view + context (ctx_sn={ctx_sn}, lo={lo})')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(40, 96, 96, 32, 32, True), (9, 104, 96, 32, 64, False), (5, 192, 192, 32, 32, True),
+                                   (3, 88, 96, 16, 32, True)])
+def test_winograd4_epilogue_operand_through_the_helpers(dev, shape):
+    """The residual add (sda/nn.py:28) and the multiply by act'(z) (backward of sda/nn.py:139) of conv_wino4 when the operand
+    is staged by the helper waves (tiles of >= 12 K-stages): workgroups with several tiles (40 x 8 = 320 tiles on 256 CUs),
+    a partial last stage (cin 104), two cout tiles per block (192), in-place residual (out aliases res) -- and a tile of
+    11 stages (cin 88), which keeps the consumer-side loads."""
+    from sda_amd import ops
+    from sda_amd._lib import ACT_IDS
+    from sda_amd.engine import launch_conv, planar_source
+    n, cin, cout, h, w_, circular = shape
+    torch.manual_seed(n + cin)
+    x = torch.randn(n, cin, h, w_)
+    wgt, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout)
+    conv = ref_conv(x, wgt, b, 1, circular)
+    res = torch.randn(n, cout, h, w_)
+    z = torch.randn(n, cout, h, w_, requires_grad=True)
+    dz, = torch.autograd.grad(F.silu(z).sum(), z)
+    out = hip_conv(x, wgt, b, h, w_, dev, circular=circular, act_in=ACT_IDS['SiLU'], res=res)
+    assert_close(out, ref_conv(F.silu(x), wgt, b, 1, circular) + res, TOL, what='silu + residual')
+    out = hip_conv(x, wgt, b, h, w_, dev, circular=circular, dact_z=z.detach(), act_d=ACT_IDS['SiLU'])
+    assert_close(out, conv * dz, TOL, what="x act'(z)")
+    # in place: the output buffer is the residual
+    pk = ops.PackedConv(wgt.to(dev), b.to(dev))
+    xd, buf = x.to(dev), res.to(dev).clone()
+    desc = launch_conv(pk, planar_source(xd), buf, h, w_, bias=pk.bias, circular=circular, res=buf)
+    torch.cuda.synchronize()
+    assert ops.conv_path(desc) == 2
+    assert_close(buf.cpu(), conv + res, TOL, what='in-place residual')

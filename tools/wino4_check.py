@@ -302,7 +302,7 @@ def trace():
 def bench():
     print('--- layer bench (algorithmic TFLOP/s; issued = /2.25)')
     for S, n in ((64, 896), (256, 60)):
-        layers = [('blk0 96->96 plain', 96, 96, S, {}), ('blk0 96->96 mod+LN', 96, 96, S, dict(ln=True, mod=True)),
+        layers = [('blk0 96->96 plain', 96, 96, S, {}), ('blk0 96->96 no bias', 96, 96, S, dict(nobias=True)), ('blk0 96->96 mod+LN', 96, 96, S, dict(ln=True, mod=True)),
                   ('blk0 96->96 silu+res', 96, 96, S, dict(silu=True, res=True)), ('blk0^T 96->96 dact', 96, 96, S, dict(dact=True)),
                   ('blk1 192->192 mod+LN', 192, 192, S // 2, dict(ln=True, mod=True)),
                   ('blk2 384->384 mod+LN', 384, 384, S // 4, dict(ln=True, mod=True)),
@@ -312,7 +312,7 @@ def bench():
             x = torch.randn(n, cin, hs, hs, device=dev)
             w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
             b = torch.randn(cout, device=dev)
-            pk = ops.PackedConv(w, b)
+            pk = ops.PackedConv(w, None if fz.get('nobias') else b)
             out = torch.empty(n, cout, h, h, device=dev)
             kw = dict(circular=True, bias=pk.bias)
             if fz.get('up'):
