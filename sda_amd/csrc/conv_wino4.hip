@@ -728,11 +728,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     };
     for (int tl = 0; tl < my_tiles; ++tl) {
         // bias of this lane's couts: 96 ct + 48 wm + 16 m + 4 kq + (0..3)
+        // (per-lane addresses are rebuilt from a lane id the compiler cannot hoist out of the tile loop: kept live across the
+        // multiply they are spilled, and a consumer's scratch reload queues behind everything the helpers have in flight)
         f32x4 binit[3];
+        int lane_b;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             binit[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 48 * wm + 16 * m + 4 * kq);
+            if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 48 * wm + 16 * m + 4 * (lane_b >> 4));
         }
         stage(std::true_type{}, binit);
         for (int st = 1; st < g.nstage; ++st) {
@@ -746,11 +750,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             //      and a scalar offset per cout -- no 64-bit vector address arithmetic.
             const W4Cur& tt = c0;
             const int hw_o = d.ho * d.wo;
-            // (EPI: the per-lane addresses are rebuilt from a lane id the compiler cannot hoist out of the tile loop -- kept
-            // live across the multiply they are spilled, and a scratch reload here queues behind the helpers' loads)
-            int lane_e = lane;
-            if constexpr (EPI) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-            const int li_e = EPI ? (lane_e & 15) : li, kq_e = EPI ? (lane_e >> 4) : kq;
+            int lane_e;                                    // (rebuilt, as for the bias)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            const int li_e = lane_e & 15, kq_e = lane_e >> 4;
             const int t = 16 * wn + li_e;
             const int oy = 8 * tt.by + 2 * (t >> 3), ox = 16 * tt.bx + 2 * (t & 7);
             const int lo0 = ((4 * kq_e) * hw_o + oy * d.wo + ox) * 4, lo1 = lo0 + d.wo * 4;
@@ -915,7 +917,8 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
         }
         case 1: return epi ? wino4_launch_t<false, false, true, true, 0>(d, g, grid, stream)
                            : wino4_launch_t<false, false, true, false, 0>(d, g, grid, stream);
-        case 2: return wino4_launch_t<false, true, false, false, 0>(d, g, grid, stream);
+        case 2: return epi ? wino4_launch_t<false, true, false, true, 0>(d, g, grid, stream)      // (up-sampling tails + skip)
+                           : wino4_launch_t<false, true, false, false, 0>(d, g, grid, stream);
         case 6: return wino4_launch_t<true, true, false, false, 0>(d, g, grid, stream);
         default: return SDA_E_UNSUPPORTED;
     }

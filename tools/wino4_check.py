@@ -306,7 +306,7 @@ def bench():
                   ('blk0 96->96 silu+res', 96, 96, S, dict(silu=True, res=True)), ('blk0^T 96->96 dact', 96, 96, S, dict(dact=True)),
                   ('blk1 192->192 mod+LN', 192, 192, S // 2, dict(ln=True, mod=True)),
                   ('blk2 384->384 mod+LN', 384, 384, S // 4, dict(ln=True, mod=True)),
-                  ('tail1 192->96 up+LN', 192, 96, S, dict(ln=True, up=True)), ('tail2 384->192 up+LN', 384, 192, S // 2, dict(ln=True, up=True))]
+                  ('tail1 192->96 up+LN', 192, 96, S, dict(ln=True, up=True)), ('tail1 192->96 up+LN+res', 192, 96, S, dict(ln=True, up=True, res=True)), ('tail2 384->192 up+LN', 384, 192, S // 2, dict(ln=True, up=True))]
         for name, cin, cout, h, fz in layers:
             hs = h // 2 if fz.get('up') else h
             x = torch.randn(n, cin, hs, hs, device=dev)
