@@ -768,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const auto r_res = rsrc_of(RES ? d.res : d.out);
                 // EPI: the operand pairs of this lane in the U buffer the last stage released: [wave][pair 24][lane]
                 const float* el = ubuf + ((q + 1) & 1) * W4_UBUF + (wave * 24 * 64 + lane_e) * 2;
+                f32x2 el0[8], el1[8];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);            // (one fragment at a time: register pressure)
@@ -789,18 +790,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                             asm volatile("" ::: "memory");
                         }
                     }
+                    // the operands of the second and third fragment are read at once (the first fragment's accumulators are free
+                    // by now): X2 releases the helpers after a third of the epilogue
+                    if constexpr (EPI) {
+                        if (m == 1) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                el0[r] = *reinterpret_cast<const f32x2*>(el + ((4 + r) * 2 + 0) * 128);
+                                el1[r] = *reinterpret_cast<const f32x2*>(el + ((4 + r) * 2 + 1) * 128);
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // X2: all of it is in registers
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int so = (16 * m + r) * hw_o * 4;                      // scalar byte offset of the cout plane
                         f32x2 y0 = {y00[r], y01[r]}, y1 = {y10[r], y11[r]};
                         f32x2 e0, e1;
                         if constexpr (EPI) {
-                            e0 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 0) * 128);
-                            e1 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 1) * 128);
-                            if (m == 2 && r == 3) {                                  // X2: all of it is in registers
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                __builtin_amdgcn_s_barrier();
-                                asm volatile("" ::: "memory");
+                            if (m >= 1) { e0 = el0[4 * (m - 1) + r]; e1 = el1[4 * (m - 1) + r]; }
+                            else {
+                                e0 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 0) * 128);
+                                e1 = *reinterpret_cast<const f32x2*>(el + ((4 * m + r) * 2 + 1) * 128);
                             }
                         }
                         if constexpr (DACT) {
