@@ -8,22 +8,29 @@
 //
 // What the design is built around (tools/mfma_shadow_gen.py, profiles/r02_mfma_shadow.txt): the fp32 MFMA runs on the
 // vector datapath, so an instruction of the SAME wave issued between two MFMAs is not hidden -- a VALU costs 4 cycles plus
-// ~10 for the switch, a global load ~18, an LDS read ~0.3-5, scalar instructions nothing -- while the instructions of a
-// SIBLING wave on the same SIMD cost the MFMA wave nothing at all.  Hence:
-//   * waves 0-3 (one per SIMD) are pure multiply streams: MFMA + ds_read + scalar bookkeeping, nothing else in the loop.
-//     BOTH operands come from LDS.  Each owns ALL 16 transform-domain positions of a 48-cout x 16-tile fragment (3 x 1
-//     MFMA fragments x 16 positions = 192 accumulators, the AGPR half of its 256 registers), so the inverse transform
-//     A^T M A is lane-local: no LDS exchange, no epilogue barriers.
-//   * waves 4-7 (their siblings) do everything else for the NEXT K-stage while the current one is multiplied: LDS-DMA of the
-//     stage's U slab (global_load_lds_dwordx4: 48 KiB, no registers), the input halo (row-contiguous loads, every pixel
-//     once, loader fusions -- modulation, LayerNorm, SiLU, nearest upsample, circular / zero padding -- applied once per
-//     pixel), the B^T d B transform and the V writes; and they issue the halo loads of the stage after that.
+// ~10 for the switch, a global load ~18, an LDS read ~0.3-5, scalar instructions nothing; the LDS / scalar / vector-memory
+// instructions of a SIBLING wave on the same SIMD cost the MFMA wave nothing, but its VALU instructions do not issue at all
+// while the stream runs.  Hence:
+//   * waves 0-3 (one per SIMD, "consumers") are pure multiply streams: MFMA + ds_read + scalar bookkeeping, nothing else in
+//     the loop.  BOTH operands come from LDS.  Each owns ALL 16 transform-domain positions of a 48-cout x 16-tile fragment
+//     (3 x 1 MFMA fragments x 16 positions = 192 accumulators of its 256 registers), so the inverse transform A^T M A is
+//     lane-local: no LDS exchange between consumers.
+//   * waves 4-7 (their siblings, "helpers") do everything else for the NEXT K-stages while the current one is multiplied:
+//     the stage's U slab L2 -> registers -> LDS, the input halo (every pixel once; loader fusions -- modulation, LayerNorm,
+//     SiLU, nearest upsample, circular / zero padding -- applied once per pixel), the B^T d B transform and the V writes;
+//     their global loads are issued stages ahead from inline asm with hand-counted s_waitcnt vmcnt(N).  Their vector-ALU work
+//     runs in a deliberate pause of the consumers (barrier M_q after step 3 of a stage); a second barrier E_q after step 6
+//     hands the next stage's buffers over early.
+//   * the epilogue operand (residual / skip tensor, or z of x act'(z)) reaches the consumers through the helpers' registers
+//     and the U buffer the tile's last hand-off released (EPI kernels): a consumer-side global load queues behind everything
+//     the helpers have in flight on the CU's vector-memory path.
 //   * workgroup tile = 96 couts x (8 x 4 Winograd tiles = 16 x 8 output pixels of one image); K-stage = 8 input channels;
-//     two (U 48 KiB + V 24 KiB) stage buffers; one workgroup barrier per stage.  The stage pipeline runs across tiles (the
-//     producers are stateless: a stage's halo addresses / liveness / LayerNorm statistics are derived when its loads are
-//     issued and travel with them in registers), so only the epilogue itself is not covered by MFMAs.
-//   * LDS layouts are conflict free: U [p][cout fragment][lane][k4] (lane-linear: what the DMA writes and what ds_read_b64
-//     reads), V [p][kq][tile][k4] with a 32-bank skew between the kq planes.
+//     two (U 48 KiB + V 16 KiB) stage buffers + wave-private halo planes = 135.5 KiB of LDS; persistent over an XCD-contiguous
+//     tile range.  The stage pipeline runs across tiles (a stage's halo addresses / liveness / LayerNorm statistics are
+//     derived when its loads are issued and travel with them in registers), so only the epilogue itself is not covered by MFMAs.
+//   * LDS layouts are conflict free: U [pair][cout fragment][lane][h][k4] (one ds_read_b128 per fragment and position pair),
+//     V [pair][kq][k4][tile][h] (8-byte lane-linear writes, ds_read_b64).
+// DESIGN.md 5.1c has the measurements behind each choice.
 // Roofline: fp32 matrix pipe, 157.3 TFLOP/s; issued flops = algorithmic (direct-convolution) flops / 2.25.
 #include "sda_common.hpp"
 #include <stdlib.h>
