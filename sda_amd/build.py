@@ -7,6 +7,7 @@ The objects are compiled with hipcc and linked WITHOUT an rpath to /opt/rocm: at
 to the HIP runtime that PyTorch-ROCm already loaded (same soname libamdhip64.so.7), so that torch's streams and
 device pointers are valid inside these kernels.  `import torch` therefore always precedes loading (sda_amd/_lib.py).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,11 +23,29 @@ EXTRA_FLAGS = os.environ.get('SDA_EXTRA_HIPCC_FLAGS', '').split()
 CONV_PARTS = 4                                       # see SDA_CONV_PART in csrc/conv_igemm.hip
 
 
-def _newer(target, deps):
-    if not os.path.exists(target):
+def _digest(deps, flags=()):
+    h = hashlib.sha256()
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(flags).encode())
+    return h.hexdigest()
+
+
+def _newer(target, deps, flags=()):
+    """Is `target` out of date?  By CONTENT (a digest of the inputs kept beside the target), not by mtime: file times are not
+    trustworthy everywhere this runs (snapshot copies, containers with a coarse or non-monotonic clock)."""
+    stamp = target + '.stamp'
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != _digest(deps, flags)
+
+
+def _stamp(target, deps, flags=()):
+    with open(target + '.stamp', 'w') as f:
+        f.write(_digest(deps, flags))
 
 
 def _headers():
@@ -52,21 +71,24 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(LIBDIR, src.replace('.hip', suffix + '.o'))
         objs.append(obj)
-        if force or _newer(obj, [sp] + hdrs):
-            cmd = [HIPCC, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off'] + flags + EXTRA_FLAGS + ['-c', sp, '-o', obj]
+        cflags = ['-O3', '-std=c++17', '-fPIC', '-ffp-contract=off'] + flags + EXTRA_FLAGS
+        if force or _newer(obj, [sp] + hdrs, cflags):
+            cmd = [HIPCC, f'--offload-arch={ARCH}'] + cflags + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
-            procs.append((src + suffix, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+            procs.append((src + suffix, obj, [sp] + hdrs, cflags, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, obj, deps, cflags, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out.decode()}')
+        _stamp(obj, deps, cflags)
     lib = os.path.join(LIBDIR, 'libsda_hip.so')
-    if force or _newer(lib, objs):
+    if force or procs or _newer(lib, objs):
         cmd = [HIPCC, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', lib] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+        _stamp(lib, objs)
     return lib
 
 
@@ -77,6 +99,7 @@ def build_emu(force=False):
     if force or _newer(lib, [src] + _headers()):
         subprocess.check_call([HIPCC, '--offload-host-only', '-DSDA_HOST_EMU', '-O2', '-std=c++17', '-fPIC',
                                '-ffp-contract=off', '-shared', src, '-o', lib])
+        _stamp(lib, [src] + _headers())
     return lib
 
 

@@ -131,7 +131,7 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
                       (g->tn == 1 || d->n_inner == 1 || d->x_sn_outer >= d->x_sn_inner * (int64_t)(d->n_inner - 1));
         g->fast32 = (span < (1LL << 30)) && nonneg;
     }
-    { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+    { static const int dbg = sda_debug_env(); g->debug = dbg; }            // (0 in the product build)
     g->lds_bytes = ((int64_t)g->ntaps * SDA_CONV_CK * g->bm + (int64_t)SDA_CONV_CK * g->S) * 4;
     if (g->lds_bytes > 160 * 1024) return SDA_E_LDS;
     return SDA_OK;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
     for (int st = 0; st < g.nstage; ++st) {
         const int c0 = st * CK;
         // ---- stage the weight slab: [tap][ck][BM] <- w[tap][c0+ck][co0 .. co0+BM)
-        if (!((g.debug & 2) && st > 0)) {
+        if (!(SDA_DBG(g, 2) && st > 0)) {
             constexpr int ROW4 = BM / 4;
             const int total4 = g.ntaps * CK * ROW4;
             for (int f = tid; f < total4; f += SDA_CONV_THREADS) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
             }
         }
         // ---- stage the input halo tile with every loader-side fusion applied
-        if (!((g.debug & 2) && st > 0)) {
+        if (!(SDA_DBG(g, 2) && st > 0)) {
             float v[NPOS][CK];
 #pragma unroll
             for (int i = 0; i < NPOS; ++i)
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SDA_CONV_THREADS) void conv_igemm_kernel(const sda_
         }
         __syncthreads();
         // ---- MFMA over all taps of this channel slab
-        if (!(g.debug & 4)) {
+        if (!SDA_DBG(g, 4)) {
             int dy = 0, dx = 0;
             for (int tap = 0; tap < g.ntaps; ++tap) {
                 const int toff = dy * g.in_cols + dx + pixbase;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512, ((CK == SDA_CONV_CK && NT == 1 && MT <= 3 && S
         };
 
         for (int st = 0; st < g.nstage; ++st, ++gs) {
-            if (!((g.debug & 2) && gs > 0)) produce(st, smem + (gs & 1) * BUF);
+            if (!(SDA_DBG(g, 2) && gs > 0)) produce(st, smem + (gs & 1) * BUF);
             __syncthreads();
         }
         }   // tiles
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, ((CK == SDA_CONV_CK && NT == 1 && MT <= 3 && S
 
         for (int st = 0; st < g.nstage; ++st, ++gs) {
             const float* buf = smem + (gs & 1) * BUF;
-            if (g.debug & 4) { __syncthreads(); continue; }
+            if SDA_DBG(g, 4) { __syncthreads(); continue; }
             const float* bw = buf + khalf * BM + l31;
             const float* bin = buf + WSZ + khalf * SPAD;
             // operands of one tap live in registers; the next tap's are fetched while this tap's MFMAs run
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512, ((CK == SDA_CONV_CK && NT == 1 && MT <= 3 && S
         int ct, n0, oy0, ox0;
         conv_decode_block(g, tile, ct, n0, oy0, ox0);
         const int co0 = ct * BM;
-        if (g.debug & 8) {                              // ablation: no epilogue memory traffic at all
+        if SDA_DBG(g, 8) {                              // ablation: no epilogue memory traffic at all
             float keep = 0.f;
 #pragma unroll
             for (int q = 0; q < NT; ++q)

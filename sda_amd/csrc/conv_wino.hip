@@ -84,7 +84,7 @@ int sda_wino_plan(const sda_conv_desc* d, WinoGeom* g) {
     g->hcols = 2 * g->ttx + 2;
     g->sh = g->ttn * g->hrows * g->hcols;
     if (g->sh > 288) return SDA_E_UNSUPPORTED;       // (degenerate 2x2-pixel images)
-    { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+    { static const int dbg = sda_debug_env(); g->debug = dbg; }            // (0 in the product build)
     return SDA_OK;
 }
 
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                 }
                 float* buf = smem + (gs & 1) * BUF;
                 const int c0 = st * CK;
-                if (!((g.debug & 2) && gs > 0)) {
-                    if (g.debug & 32) continue;
+                if (!(SDA_DBG(g, 2) && gs > 0)) {
+                    if SDA_DBG(g, 32) continue;
                     const int ca = c0 + 2 * pw, cb = ca + 1;                 // this wave's two channels
                     // channel offsets relative to the tile base (padded channels >= cin read channel 0 and are zeroed)
                     const unsigned offa = ca < g.cin ? (unsigned)((int64_t)ca * d.x_sc) : 0u;
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
 #pragma unroll
                 for (int m = 0; m < MT; ++m) av[s_][m] = *reinterpret_cast<const f32x4*>(u + m * 32 * 4);
             };
-            if (!(g.debug & 4)) fetch_a(0, 0, 0);
+            if (!SDA_DBG(g, 4)) fetch_a(0, 0, 0);
             for (int st = 0; st < g.nstage; ++st, ++gs) {
                 const float* buf = smem + (gs & 1) * BUF;
-                if (g.debug & 4) { __syncthreads(); continue; }
+                if SDA_DBG(g, 4) { __syncthreads(); continue; }
                 const float* vst = buf + ((wave * 4 * 2 + khalf) * WINO_T + l31) * 4;
                 bv[0] = *reinterpret_cast<const f32x4*>(vst);
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
             const int64_t pix = tv ? ((int64_t)n * d.cout * d.ho + 2 * ty) * d.wo + 2 * tx : 0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                if (!(g.debug & 8)) {
+                if (!SDA_DBG(g, 8)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const sda_conv_desc d
                     }
                 }
                 __syncthreads();
-                if (!(g.debug & 8)) {
+                if (!SDA_DBG(g, 8)) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = wave * 8 + it * 2 + khalf;

@@ -111,9 +111,9 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     g->nstage = d->cin_pad / W4_CK;
     if ((int64_t)g->nstage * total > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
 #ifdef SDA_W4_VARIANTS
-    g->debug = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0;      // (tooling build: re-read per launch)
+    g->debug = sda_debug_env();      // (tooling build: re-read per launch)
 #else
-    { static const int dbg = getenv("SDA_CONV_DEBUG") ? atoi(getenv("SDA_CONV_DEBUG")) : 0; g->debug = dbg; }
+    { static const int dbg = sda_debug_env(); g->debug = dbg; }            // (0 in the product build)
 #endif
     g->trace = nullptr;
     return SDA_OK;
@@ -150,18 +150,14 @@ __device__ __forceinline__ void w4_advance(const Wino4Geom& g, W4Cur& c) {
 }
 
 // phase stamps of the tracing variant (VAR == 11): T(k) adds the cycles since the previous stamp to phase k
-#ifdef SDA_W4_ABLATE
-#define W4_DBG(b) (g.debug & (b))      // tooling builds: runtime ablation switches (SDA_CONV_DEBUG), timing experiments only
-#else
-#define W4_DBG(b) false
-#endif
+#define W4_DBG(b) SDA_DBG(g, b)        // tooling builds only (sda_common.hpp): runtime ablation switches, timing experiments
 #define W4_TRACE_DECL long long w4tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long w4tl_ = 0, w4tb_ = 0; (void)w4tr_; (void)w4tl_; (void)w4tb_; if constexpr (VAR == 11) w4tb_ = __builtin_readcyclecounter()
 #define W4_T0() do { if constexpr (VAR == 11) w4tl_ = __builtin_readcyclecounter(); } while (0)
-#define W4_STAMP(k) do { if constexpr (VAR == 11) if (!(g.debug & 4096)) { const long long n_ = __builtin_readcyclecounter(); w4tr_[k] += n_ - w4tl_; w4tl_ = n_; } } while (0)
+#define W4_STAMP(k) do { if constexpr (VAR == 11) if (!SDA_DBG(g, 4096)) { const long long n_ = __builtin_readcyclecounter(); w4tr_[k] += n_ - w4tl_; w4tl_ = n_; } } while (0)
 // deferred stamps (VAR == 11, debug bit 8192): s_memtime into SGPRs, read only after the pause they bracket -- no wait in between
-#define W4_MARK(v) do { if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0" : "=s"(v) :: "memory"); } while (0)
-#define W4_MARK_ADD(k, a, b) do { if constexpr (VAR == 11) if (g.debug & 8192) w4tr_[k] += (long long)((b) - (a)); } while (0)
-#define W4_MARK_WAIT() do { if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define W4_MARK(v) do { if constexpr (VAR == 11) if SDA_DBG(g, 8192) asm volatile("s_memtime %0" : "=s"(v) :: "memory"); } while (0)
+#define W4_MARK_ADD(k, a, b) do { if constexpr (VAR == 11) if SDA_DBG(g, 8192) w4tr_[k] += (long long)((b) - (a)); } while (0)
+#define W4_MARK_WAIT() do { if constexpr (VAR == 11) if SDA_DBG(g, 8192) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #define W4_TRACE_OUT() do { if constexpr (VAR == 11) { w4tr_[7] = __builtin_readcyclecounter() - w4tb_; if (g.trace && lane == 0) for (int k_ = 0; k_ < 8; ++k_) g.trace[(blockIdx.x * 8 + wave) * 8 + k_] = w4tr_[k_]; } } while (0)
 
 // Helper-wave global loads, hidden from the compiler's s_waitcnt bookkeeping.  The helpers keep loads in flight for several
@@ -186,8 +182,12 @@ __device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned of
 // EPI: the epilogue operand (residual or activation-derivative input) reaches the consumers through the helpers' registers and
 //      LDS instead of their own global loads (see "epilogue operand" in the helpers)
 // VAR: ablation variant (0 = shipped; others exist only under -DSDA_W4_VARIANTS for tools/wino4_check.py --variants)
-template <bool MOD, bool LN, bool SILU, bool EPI, int VAR = 0>
+// EPM: how the epilogue operand travels.  0 = the launch has none (plain / modulation + LayerNorm launches: the epilogue is the
+//      inverse transform and the stores, nothing else is compiled in); 1 = through the helpers (EPI, above); 2 = consumer-side
+//      buffer loads (any operand combination; tiles shorter than twelve stages).
+template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
+    constexpr bool EPI = EPM == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             __builtin_amdgcn_sched_barrier(0);
             if (!W4_DBG(512)) __builtin_amdgcn_s_barrier();                  // M_q
             asm volatile("" ::: "memory");
-            if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mk3), "+s"(mk0), "+s"(mk1), "+s"(mk2) :: "memory");
+            if constexpr (VAR == 11) if SDA_DBG(g, 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mk3), "+s"(mk0), "+s"(mk1), "+s"(mk2) :: "memory");
             W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
             W4_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
@@ -629,8 +629,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     // positions 2 s, 2 s + 1 and both K quads;  B fragments: V[s][kq][k4][16 wn + li][h], two 8-byte reads (one ds_read2_b64).  (ds_read_b128 moves 256 B per LDS
     // clock, ds_read2_b64 half of that: tools/w4_feed_gen.py -- the cheaper read is also worth ~5 % of shader clock here,
     // the kernel runs at the power limit.)
-    const int ard = (3 * wm * 64 + lane) * 4;
-    const int brd = kq * W4_VKQ + (16 * wn + li) * 2;
+    int ard = (3 * wm * 64 + lane) * 4;
+    int brd = kq * W4_VKQ + (16 * wn + li) * 2;
     f32x4 acc[16][3];
     W4_TRACE_DECL;
     __syncthreads();                                       // stage 0 is in buffer 0
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 W4_MARK(mc0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr (VAR == 11) if (g.debug & 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mc1), "+s"(mc0) :: "memory");
+                if constexpr (VAR == 11) if SDA_DBG(g, 8192) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(mc1), "+s"(mc0) :: "memory");
                 W4_MARK_ADD(1, mc0, mc1);
                 W4_STAMP(1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -740,6 +740,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         f32x4 binit[3];
         int lane_b;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
+        if constexpr (EPM == 2) {
+            // (the generic epilogue is the register-hungriest: the two LDS read offsets are rebuilt per tile as well, instead of
+            // being spilled around it -- the next tile's first operands were fetched before the epilogue, from the old copies)
+            ard = (3 * wm * 64 + lane_b) * 4;
+            brd = (lane_b >> 4) * W4_VKQ + (16 * wn + (lane_b & 15)) * 2;
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             binit[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 f32x2 el0[8], el1[8];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);            // (one fragment at a time: register pressure)
+                    if constexpr (EPM != 0) __builtin_amdgcn_sched_barrier(0);       // (one fragment at a time: register pressure)
                     // rows (xi): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 for each nu;  columns (nu): the same combination
                     f32x4 s0[4], s1[4];
 #pragma unroll
@@ -845,14 +851,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                                 y1 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo1, so, 0));
                             }
                         }
-                        if (!(g.debug & 8)) {
+                        if (!SDA_DBG(g, 8)) {
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w4_u32x2, y0), r_out, lo0, so, 0);
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(w4_u32x2, y1), r_out, lo1, so, 0);
                         }
                     }
                 }
             };
-            if constexpr (EPI) {                           // (exactly one of the two operands: the launch condition)
+            if constexpr (EPM == 0) {
+                run(std::false_type{}, std::false_type{});
+            } else if constexpr (EPI) {                    // (exactly one of the two operands: the launch condition)
                 if (d.dact_z) run(std::true_type{}, std::false_type{});
                 else run(std::false_type{}, std::true_type{});
             } else if (d.dact_z) {
@@ -886,7 +894,7 @@ extern "C" int sda_w4_trace_read(double* out) {
 }
 #endif
 
-template <bool MOD, bool LN, bool SILU, bool EPI, int VAR>
+template <bool MOD, bool LN, bool SILU, int EPI, int VAR>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
     static_assert(W4_LDS_BYTES <= 160 * 1024, "LDS");
     static bool attr_set[SDA_MAX_DEVICES];
@@ -916,6 +924,11 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
     // of a tile must open after the previous tile's operand has left the registers)
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
     const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12;
+    const int epm = epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
+#define W4_LAUNCH3(MOD, LN, SILU)                                                                                              \
+    (epm == 1 ? wino4_launch_t<MOD, LN, SILU, 1, 0>(d, g, grid, stream)                                                        \
+              : epm == 2 ? wino4_launch_t<MOD, LN, SILU, 2, 0>(d, g, grid, stream)                                             \
+                         : wino4_launch_t<MOD, LN, SILU, 0, 0>(d, g, grid, stream))
     switch (wino4_config(d)) {
         case 0: {
 #ifdef SDA_W4_VARIANTS
@@ -926,22 +939,22 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g, hipStream_t str
                     if (!tbuf && hipMalloc(&tbuf, 256 * 64 * sizeof(long long)) != hipSuccess) return SDA_E_BADARG;
                     (void)hipMemsetAsync(tbuf, 0, 256 * 64 * sizeof(long long), stream);
                     Wino4Geom gt = g; gt.trace = tbuf; w4_trace_buf = tbuf; w4_trace_grid = grid;
-                    return epi ? wino4_launch_t<false, false, false, true, 11>(d, gt, grid, stream)
-                               : wino4_launch_t<false, false, false, false, 11>(d, gt, grid, stream);
+                    return epm == 1 ? wino4_launch_t<false, false, false, 1, 11>(d, gt, grid, stream)
+                         : epm == 2 ? wino4_launch_t<false, false, false, 2, 11>(d, gt, grid, stream)
+                                    : wino4_launch_t<false, false, false, 0, 11>(d, gt, grid, stream);
                 }
                 default: break;
             }
 #endif
-            return epi ? wino4_launch_t<false, false, false, true, 0>(d, g, grid, stream)
-                       : wino4_launch_t<false, false, false, false, 0>(d, g, grid, stream);
+            return W4_LAUNCH3(false, false, false);
         }
-        case 1: return epi ? wino4_launch_t<false, false, true, true, 0>(d, g, grid, stream)
-                           : wino4_launch_t<false, false, true, false, 0>(d, g, grid, stream);
-        case 2: return epi ? wino4_launch_t<false, true, false, true, 0>(d, g, grid, stream)      // (up-sampling tails + skip)
-                           : wino4_launch_t<false, true, false, false, 0>(d, g, grid, stream);
-        case 6: return wino4_launch_t<true, true, false, false, 0>(d, g, grid, stream);
+        case 1: return W4_LAUNCH3(false, false, true);
+        case 2: return W4_LAUNCH3(false, true, false);                                             // (up-sampling tails + skip)
+        case 6: return epm == 0 ? wino4_launch_t<true, true, false, 0, 0>(d, g, grid, stream)
+                                : wino4_launch_t<true, true, false, 2, 0>(d, g, grid, stream);
         default: return SDA_E_UNSUPPORTED;
     }
+#undef W4_LAUNCH3
 }
 
 static bool wino4_disabled() {

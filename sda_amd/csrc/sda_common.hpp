@@ -6,6 +6,21 @@
 
 #define SDA_WAVE 64
 
+// ---- timing-ablation switches ($SDA_CONV_DEBUG bits: skip the loaders / the multiply / the epilogue stores ...).  They make
+// results WRONG, so the product library does not contain them: SDA_DBG() is a compile-time `false` and the environment
+// variable is never read unless the library is a tooling build (SDA_EXTRA_HIPCC_FLAGS=-DSDA_ABLATE python -m sda_amd.build
+// --force; tools/conv_bench.py and tools/wino4_check.py say when they need one).  tests/test_abi_and_host.py checks that the
+// shipped .so does not carry the variable's name.
+#if defined(SDA_ABLATE) || defined(SDA_W4_ABLATE) || defined(SDA_W4_VARIANTS)
+#include <stdlib.h>
+#define SDA_ABLATE_BUILD 1
+#define SDA_DBG(g, bits) ((g).debug & (bits))
+static inline int sda_debug_env() { const char* e = getenv("SDA_CONV_" "DEBUG"); return e ? atoi(e) : 0; }
+#else
+#define SDA_DBG(g, bits) (false)
+static inline int sda_debug_env() { return 0; }
+#endif
+
 static inline int sda_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SDA_OK : (int)e;

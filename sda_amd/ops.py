@@ -4,9 +4,8 @@ Every function launches a hand-written gfx950 kernel on the CURRENT torch stream
 tensors must live on a HIP device (`_dev()` raises otherwise).
 """
 import ctypes
-from typing import Optional
-
 import os
+from typing import Optional
 
 import torch
 from torch import Tensor
@@ -15,9 +14,8 @@ from . import _lib
 from ._lib import ACT_IDS, ConvDesc
 
 CONV_CK = 8          # K-stage depth of conv_igemm (SDA_CONV_CK)
-import os as _os
-WINOGRAD = _os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3) for eligible 3x3 layers
-WINOGRAD4 = _os.environ.get('SDA_CONV_WINO4', '1') != '0'    # ... its one-wave-per-SIMD kernel where images are multiples of 16
+WINOGRAD = os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3) for eligible 3x3 layers
+WINOGRAD4 = os.environ.get('SDA_CONV_WINO4', '1') != '0'    # ... its one-wave-per-SIMD kernel where images are multiples of 16
 
 
 def _dev(*tensors):
@@ -229,7 +227,6 @@ def block1d_fwd(a: Tensor, mod, mod_sn: int, pk1: 'PackedConv', pk2: 'PackedConv
     _dev(a, mod, y, z, mean, rstd)
     d = _block1d_desc(a, mod, mod_sn, pk1, pk2, circular, act, eps, unbiased)
     d.y, d.z, d.mean, d.rstd = y.data_ptr(), _ptr(z), _ptr(mean), _ptr(rstd)
-    import ctypes
     _lib.check(_lib.load().sda_block1d_fwd(ctypes.byref(d), _stream()), 'sda_block1d_fwd')
 
 
@@ -239,7 +236,6 @@ def block1d_bwd(g: Tensor, a: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, mod
     _dev(g, a, z, mean, rstd, mod, gx)
     d = _block1d_desc(a, mod, mod_sn, pk1b, pk2b, circular, act, 0.0, unbiased)
     d.z, d.mean, d.rstd, d.g, d.gx = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), gx.data_ptr()
-    import ctypes
     _lib.check(_lib.load().sda_block1d_bwd(ctypes.byref(d), _stream()), 'sda_block1d_bwd')
 
 
@@ -401,6 +397,8 @@ def randn_rows(out: Tensor, seed: int, row0: int, draw: int = 0, draw_dev: Optio
     if draw_dev is not None and (not draw_dev.is_cuda or draw_dev.dtype != torch.int64):
         raise _lib.SdaHipError('draw_dev must be a device int64 scalar')
     rows = out.shape[0]
+    if out.numel() == 0:                    # an empty shard (batch < world size): nothing to draw
+        return out
     _lib.check(_lib.load().sda_randn_rows(out.data_ptr(), rows, out.numel() // max(rows, 1), seed & 0xffffffffffffffff, row0,
                                           draw, _ptr(draw_dev), draw_mul, draw_add, _stream()), 'sda_randn_rows')
     return out
@@ -490,7 +488,6 @@ def transport_cost(cost: Tensor) -> float:
     """Host optimal-transport solve with uniform marginals of an (m, n) fp32 host cost matrix: min_P <P, cost>."""
     if cost.is_cuda or cost.dtype != torch.float32 or cost.dim() != 2:
         raise _lib.SdaHipError('transport_cost expects an fp32 host matrix')
-    import ctypes
     cost = cost.contiguous()
     total = ctypes.c_double(0.0)
     _lib.check(_lib.load().sda_transport_cost(cost.data_ptr(), cost.shape[0], cost.shape[1], ctypes.addressof(total)),
@@ -502,7 +499,6 @@ def assignment_cost(cost: Tensor):
     """Host linear-assignment solve of a square cost matrix (CPU tensor): (minimum total cost, column of each row)."""
     if cost.is_cuda or cost.dtype != torch.float32 or cost.dim() != 2 or cost.shape[0] != cost.shape[1]:
         raise _lib.SdaHipError('assignment_cost expects a square fp32 host matrix')
-    import ctypes
     cost = cost.contiguous()
     n = cost.shape[0]
     total = ctypes.c_double(0.0)

@@ -513,10 +513,23 @@ class GaussianScore(nn.Module):
         self.A = A
         self.sde = sde
         self.detach = detach
-        # scalar std / gamma (every experiment of the reference): the likelihood cotangent is one fused launch
-        self._scalars = None
-        if torch.as_tensor(std).numel() == 1 and torch.as_tensor(gamma).numel() == 1:
-            self._scalars = (float(torch.as_tensor(std)), float(torch.as_tensor(gamma)))
+        self._scalar_cache = None
+
+    @property
+    def _scalars(self):
+        """(std, gamma) as python floats when both buffers are scalars (every experiment of the reference): the likelihood
+        cotangent is then one fused launch.  Read from the LIVE buffers -- ``load_state_dict``, ``gs.std = ...`` and in-place
+        writes all change what the fused paths use, as they do for the general path -- and cached on the buffers' identity and
+        version counter, so that a sampling loop pays the device read-back once (and none inside a graph capture)."""
+        std, gamma = self.std, self.gamma
+        if std.numel() != 1 or gamma.numel() != 1:
+            return None
+        key = (std.data_ptr(), std._version, std.device, gamma.data_ptr(), gamma._version, gamma.device)
+        hit = self._scalar_cache
+        if hit is None or hit[0] != key:
+            hit = (key, (float(std), float(gamma)))
+            self._scalar_cache = hit
+        return hit[1]
 
     #: samples per streamed group: None = decide from free HBM, 0 = never split, n = force groups of n (tests)
     group_size: Optional[int] = None
@@ -580,12 +593,13 @@ class GaussianScore(nn.Module):
 
         ghat = None
         fused = getattr(self.A, 'gaussian_guidance', None)
-        if fused is not None and self._scalars is not None:
+        sc = self._scalars
+        if fused is not None and sc is not None:
             # subsampling observation, scalar std / gamma: denoise + A + cotangent + A^T in one launch
             yq = self.y
             if rows is not None and yq.dim() == x.dim() and yq.shape[0] == rows[2]:
                 yq = yq[rows[0]:rows[1]]
-            ghat = fused(x.contiguous(), eps_d, yq, self._scalars[0], self._scalars[1], mu, sigma)
+            ghat = fused(x.contiguous(), eps_d, yq, sc[0], sc[1], mu, sigma)
         if ghat is not None:
             return self._finish(eps_d, ghat, vjp, mu, sigma, out, grad_only)
         xhat = torch.empty_like(eps_d)
@@ -601,11 +615,11 @@ class GaussianScore(nn.Module):
             # linear operator with a hand-written adjoint (sda_amd.observe): d log p / d x_hat = A^T((y - A x_hat)/var)
             ax = self.A(xhat)
             yo = observed(ax)
-            if (self._scalars is not None and ax.dtype == torch.float32 and yo.dtype == torch.float32 and
+            if (sc is not None and ax.dtype == torch.float32 and yo.dtype == torch.float32 and
                     (yo.shape == ax.shape or yo.shape == ax.shape[1:] or
                      (yo.dim() == ax.dim() and yo.shape[0] == 1 and yo.shape[1:] == ax.shape[1:]))):
                 # (the same path for every batch size: sharded and single-rank runs stay bit-identical)
-                cot = ops.gauss_cotangent(yo, ax, self._scalars[0], self._scalars[1], mu, sigma)
+                cot = ops.gauss_cotangent(yo, ax, sc[0], sc[1], mu, sigma)
             else:
                 var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
                 cot = ((yo - ax) / var).contiguous()

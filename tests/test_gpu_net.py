@@ -439,6 +439,17 @@ def test_fused_observation_operators_match_autograd(dev):
     a = GaussianScore(y, A=A_ref, std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
     b = GaussianScore(y, A=Ob.Subsample.space(4), std=0.3, sde=VPSDE(net, shape=())).to(dev)(xg, t)
     assert_close(b.cpu(), a.cpu(), 1e-5)
+    # std / gamma are live buffers: the one-launch guidance follows in-place writes and load_state_dict
+    want = GaussianScore(y, A=A_ref, std=0.7, sde=VPSDE(net, shape=()), gamma=4e-2).to(dev)(xg, t)
+    gs = GaussianScore(y, A=Ob.Subsample.space(4), std=0.3, sde=VPSDE(net, shape=())).to(dev)
+    gs(xg, t)
+    gs.std.fill_(0.7)
+    gs.gamma.fill_(4e-2)
+    assert_close(gs(xg, t).cpu(), want.cpu(), 1e-5, what='in-place std/gamma')
+    gs2 = GaussianScore(y, A=Ob.Subsample.space(4), std=0.3, sde=VPSDE(net, shape=())).to(dev)
+    gs2(xg, t)
+    gs2.load_state_dict(gs.state_dict())
+    assert_close(gs2(xg, t).cpu(), want.cpu(), 1e-5, what='load_state_dict std/gamma')
 
 
 def test_random_architectures_forward_and_vjp():

@@ -207,3 +207,50 @@ def test_stride2_vjp_parity_split_equals_zero_insertion(monkeypatch):
             else:
                 assert any(zh > 1 or zw > 1 for ep, kh, kw, zh, zw, sx in seen) and not any(ep for ep, *_ in seen)
         assert_close(grads[True], grads[False], 1e-6)
+
+
+class _SubAdj:
+    """test-local linear observation with a hand-written adjoint (takes GaussianScore's gauss_cotangent fast path)."""
+
+    def __call__(self, x):
+        return _A(x)
+
+    def adjoint(self, r, x_shape):
+        g = torch.zeros(x_shape)
+        g[..., ::2, :, ::2, ::2] = r
+        return g
+
+
+def test_gaussian_score_reads_live_std_gamma():
+    """std / gamma are buffers (state_dict entries); the fused paths must follow load_state_dict, assignment and
+    in-place writes exactly as the general path does (reference score.py:387 reads self.std / self.gamma at call time)."""
+    from sda_amd.score import GaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    inner = VPSDE(net, shape=())
+    x, t = g['x'], g['t_guided']
+
+    def fresh(std, gamma, A):
+        return GaussianScore(g['y_obs'], A=A, std=std, sde=inner, gamma=gamma)(x, t)
+
+    for A in (_A, _SubAdj()):
+        want = fresh(0.2, 5e-2, A)
+        gs = GaussianScore(g['y_obs'], A=A, std=0.5, sde=inner, gamma=1e-2)
+        base = gs(x, t)                                              # (fills the scalar cache with the constructor values)
+        assert (base - want).abs().max() > 1e-4 * want.abs().max()  # the two settings do differ
+        gs.std.fill_(0.2); gs.gamma.fill_(5e-2)                      # in place
+        assert gs._scalars == pytest.approx((0.2, 5e-2))
+        assert_close(gs(x, t), want, 1e-6)
+        gs2 = GaussianScore(g['y_obs'], A=A, std=0.5, sde=inner, gamma=1e-2)
+        gs2(x, t)
+        gs2.load_state_dict(gs.state_dict())                         # checkpoint round trip
+        assert_close(gs2(x, t), want, 1e-6)
+        gs3 = GaussianScore(g['y_obs'], A=A, std=0.5, sde=inner, gamma=1e-2)
+        gs3(x, t)
+        gs3.std = torch.tensor(0.2); gs3.gamma = torch.tensor(5e-2)  # buffer reassignment
+        assert_close(gs3(x, t), want, 1e-6)
+    # non-scalar std: no scalar fast path, general path as before
+    gv = GaussianScore(g['y_obs'], A=_A, std=torch.full(g['y_obs'].shape[-3:], 0.2), sde=inner, gamma=5e-2)
+    assert gv._scalars is None
+    assert_close(gv(x, t), fresh(0.2, 5e-2, _A), 1e-5)

@@ -1,0 +1,103 @@
+"""CPU build-time guard for the hand-scheduled gfx950 kernels (VERDICT r2 item 3 / "what's missing" 5).
+
+conv_wino4's helper waves keep global loads in flight across loop iterations and wait for them with HAND-COUNTED
+`s_waitcnt vmcnt(N)` (conv_wino4.hip: W4_WAIT_U / W4_WAIT_HALO): the scheme is only correct while
+  * the compiler adds no vector-memory instruction of its own between those waits (a spill reload -- `scratch_load` -- is
+    one, and it would also queue behind everything the helpers have in flight), and
+  * the number of loads in the program text between two waits is exactly what the counts were derived from.
+Nothing on the GPU side fails when that breaks (results stay right if the count errs on the strict side, the kernel just
+serialises; on the loose side a register is read before its load landed).  So the device code object hipcc produced for
+THIS build is unbundled here (tools/isa_guard.py: clang-offload-bundler + llvm-readelf --notes + llvm-objdump) and checked.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import isa_guard as G  # noqa: E402
+
+LIB = os.path.join(ROOT, 'sda_amd', 'lib')
+
+
+@pytest.fixture(scope='module')
+def built():
+    from sda_amd import build as b
+    b.build()                                            # incremental: a no-op when the objects are current
+    return LIB
+
+
+def _w4_params(name):
+    m = re.search(r'conv_wino4_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)E', name)
+    assert m, name
+    mod, ln, silu, epm, var = (int(v) for v in m.groups())
+    return bool(mod), bool(ln), bool(silu), epm, var
+
+
+def test_conv_wino4_no_spills_and_exact_load_counts(built):
+    obj = os.path.join(built, 'conv_wino4.o')
+    md = G.kernel_metadata(obj)
+    dis = G.disassemble(obj)
+    kernels = [n for n in md if 'conv_wino4_kernel' in n]
+    # the shipped variants: {plain, SiLU, LN} x {no operand, through the helpers, consumer loads} + mod+LN x {none, consumer}
+    assert len(kernels) == 11, kernels
+    seen = set()
+    for name in kernels:
+        mod, ln, silu, epm, var = _w4_params(name)
+        assert var == 0, f'tooling variant in the product library: {name}'
+        seen.add((mod, ln, silu, epm))
+        k, ins = md[name], dis[name]
+        h = G.histogram(ins)
+        scratch_ops = sum(v for o, v in h.items() if o.startswith('scratch_'))
+        assert sum(v for o, v in h.items() if 'mfma' in o) == 192, name          # 8 steps x 12 MFMAs x (first | later stage)
+        assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, (name, k)
+        if epm in (0, 1):
+            # the hot kernels (every launch of the reference nets): nothing spilled, no scratch segment at all
+            assert k['vgpr_spill_count'] == 0 and k['sgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0 and \
+                scratch_ops == 0, (name, k, scratch_ops)
+        else:
+            # the generic consumer-side epilogue (short tiles / two operands; no launch of the reference nets): at most the
+            # two entry-time spills the helpers reload once, outside every loop
+            assert k['vgpr_spill_count'] <= 2 and scratch_ops <= 4, (name, k, scratch_ops)
+        # ---- the hand-counted waits.  Loads per halo set / U slab quarter / prefetch as in the kernel source:
+        nhl = 6 + (6 if ln else 0) + (2 if mod else 0)
+        nul = 12
+        npf = 4 if epm == 1 else 1
+        npf_text = 28 if epm == 1 else 2                # EPI: 6 window slots x 4 + 4 dummies; else: the two arms of one branch
+        wait_u, wait_halo = nhl + npf, min(63, 2 * (nhl + npf + nul) + nul)
+        seq = G.vmem_between_waits(ins)
+        if epm == 2:
+            continue                                     # (compiler-visible consumer loads interleave their own waits)
+        # consumer bias loads, then the helper prologue, then 4 unrolled iterations, then the drain
+        assert seq[0] == (0, 3), (name, seq[:3])
+        body = seq[4:-1]
+        assert len(body) == 8, (name, seq)
+        for j in range(4):
+            assert body[2 * j] == (wait_u, nhl + npf_text), (name, j, body)       # before W4_WAIT_U: prefetch + halo issue
+            assert body[2 * j + 1] == (wait_halo, nul), (name, j, body)           # before W4_WAIT_HALO: the 12 U loads
+        assert seq[-1][0] == 0                                                    # final drain
+        # no compiler-inserted full drain anywhere else
+        assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) == 3, name
+    assert seen == {(False, False, False, 0), (False, False, False, 1), (False, False, False, 2),
+                    (False, False, True, 0), (False, False, True, 1), (False, False, True, 2),
+                    (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
+                    (True, True, False, 0), (True, True, False, 2)}
+
+
+def test_fused_1d_kernels_have_no_scratch(built):
+    for obj, pat in (('block1d.o', 'block1d_'), ('conv_small1d.o', 'conv_small1d_kernel')):
+        md = G.kernel_metadata(os.path.join(built, obj))
+        names = [n for n in md if pat in n]
+        assert names, obj
+        for n in names:
+            k = md[n]
+            assert k['vgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0, (n, k)
+
+
+def test_product_library_has_no_ablation_switches(built):
+    """SDA_CONV_DEBUG makes results wrong (it skips loaders / stores for timing experiments): the product build must not
+    read it.  The tooling build (-DSDA_ABLATE) does."""
+    blob = open(os.path.join(built, 'libsda_hip.so'), 'rb').read()
+    assert b'SDA_CONV_DEBUG' not in blob
