@@ -132,25 +132,6 @@ def cpu_baseline(wl, args, guided, corrections):
     from oracle import sda_oracle as O
     torch.manual_seed(0)
     ncpu = os.cpu_count() or 1
-    if args.cpu_threads:
-        cores = min(ncpu, int(args.cpu_threads))
-    else:
-        # torch's CPU convolutions stop scaling (and then collapse) long before 256 SMT threads on this class of host:
-        # pick the fastest of a few thread counts on one representative 3x3 conv, so the baseline is the CPU at its best
-        import torch.nn.functional as F
-        probe_x, probe_w = torch.randn(4, 96, 64, 64), torch.randn(96, 96, 3, 3)
-        best = None
-        for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} or {ncpu}):
-            torch.set_num_threads(th)
-            F.conv2d(probe_x, probe_w, padding=1)
-            t0 = time.perf_counter()
-            for _ in range(5):
-                F.conv2d(probe_x, probe_w, padding=1)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[0]:
-                best = (dt, th)
-        cores = best[1]
-    torch.set_num_threads(cores)
     sched = O.Schedule()
     if wl['kind'] == 'kolmogorov':
         size, state = wl['size'], wl['state']
@@ -191,10 +172,6 @@ def cpu_baseline(wl, args, guided, corrections):
         def score(xx, tt):
             with torch.no_grad():
                 return eps(xx, tt)
-    event_ndim = x.dim() - 1
-    # one warm step then timed steps until ~args.cpu_seconds
-    steps_done, t_spent = 0, 0.0
-    xx = x
     time_grid = torch.linspace(1, 0, 1001)
     dt = 1 / 1000
 
@@ -209,13 +186,27 @@ def cpu_baseline(wl, args, guided, corrections):
             xx = xx - (delta * e + torch.sqrt(2 * delta) * z) * sched.sigma(t - dt)
         return xx
 
-    t0 = time.perf_counter()
-    xx = one_step(xx, 0)                       # warm-up (thread pool, allocator); also bounds the timed sample
-    t_warm = time.perf_counter() - t0
-    i = 1
-    if t_warm > args.cpu_seconds:              # one step already exceeds the budget: report the warm-up step itself
-        steps_done, t_spent = 1, t_warm
-    while t_spent < args.cpu_seconds and steps_done < 50:
+    # thread count: the fastest of a few candidates ON THE WORKLOAD ITSELF (one score evaluation of the sample; torch's CPU
+    # convolutions stop scaling long before the SMT thread count of this class of host, and a small probe convolution does
+    # not predict where) -- the baseline is the CPU at its best.  The probe evaluations double as the thread-pool warm-up.
+    if args.cpu_threads:
+        cores, probe = min(ncpu, int(args.cpu_threads)), 'given'
+    else:
+        cands = sorted({t for t in (16, 32, 64, 128) if t <= ncpu} or {ncpu})
+        best = None
+        for th in cands:
+            torch.set_num_threads(th)
+            t0 = time.perf_counter()
+            score(x, time_grid[0])
+            dtp = time.perf_counter() - t0
+            if best is None or dtp < best[0]:
+                best = (dtp, th)
+        cores, probe = best[1], 'fastest of ' + '/'.join(map(str, cands)) + ' on one score evaluation of the sample'
+    torch.set_num_threads(cores)
+    # >= 1 untimed warm-up step, then >= 3 timed steps, more while the budget lasts
+    xx = one_step(x, 0)
+    steps_done, t_spent, i = 0, 0.0, 1
+    while steps_done < 3 or (t_spent < args.cpu_seconds and steps_done < 50):
         t0 = time.perf_counter()
         xx = one_step(xx, i)
         t_spent += time.perf_counter() - t0
@@ -224,9 +215,19 @@ def cpu_baseline(wl, args, guided, corrections):
     sample_steps_per_s = steps_done / t_spent
     value = sample_steps_per_s * nwin / total_windows        # cost is linear in windows / trajectories
     return dict(value=value, unit='diffusion-steps/s (same per-GPU shard, extrapolated linearly from the sample)',
-                cores=cores, kind='port',
-                sample=f'{steps_done} timed steps ({t_spent:.1f} s) of {unit}; guided={int(guided)}, corrections={corrections}; '
-                       f'scaled by {nwin}/{total_windows}')
+                cores=cores, kind='port', cpu_model=_cpu_model(), host_logical_cpus=ncpu, threads_chosen_by=probe,
+                sample=f'{steps_done} timed steps after 1 warm-up step ({t_spent:.1f} s, {t_spent / steps_done:.2f} s/step) of {unit}; '
+                       f'guided={int(guided)}, corrections={corrections}; scaled by {nwin}/{total_windows}')
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 PEAK_MFMA_F32 = 157.3      # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md)
@@ -253,15 +254,34 @@ def roofline_report(prof, prof_steps, step_s, args, root):
                      'algorithmic_GBps': gbs, 'frac_of_8TBps': gbs / PEAK_HBM}
     conv = {k: v for k, v in fam.items() if 'issued_mfma_tflops' in v}
     dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
-    traffic = None
-    tfile = os.path.join(root, 'profiles', f'r02_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
-    if os.path.exists(tfile):              # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-        traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+    traffic, tfile = None, None
+    for rnd in ('r03', 'r02'):             # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            break
     kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
               'wino': 'conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)',
-              'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)'}.get(dom, dom)
+              'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)',
+              'small1d': 'conv_small1d_kernel (single-round-trip 1-D convolution, v_mfma_f32_16x16x4_f32)',
+              'block1d_fwd': 'block1d_fwd_kernel (fused 1-D residual block, v_mfma_f32_16x16x4_f32)',
+              'block1d_bwd': 'block1d_bwd_kernel (fused 1-D residual block VJP, v_mfma_f32_16x16x4_f32)'}.get(dom, dom)
     d = conv.get(dom, {})
-    return {'bound': 'mfma', 'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+    latency = None
+    if dom in ('small1d', 'block1d_fwd', 'block1d_bwd'):
+        # the 1-D nets are LATENCY-bound (a launch is a few hundred kFLOP per image): the model that prices them is launches per
+        # step x time per launch against the floor of a dependent launch in a graph chain (1.7 us measured), not a
+        # fraction of the matrix peak.  HIP-event brackets add their own few us per launch: `event_us_per_launch` is an upper
+        # bound, `graph_us_per_launch_all_kernels` = the graph-replayed step / every launch of the step is the clean figure.
+        n_launch = sum(v['launches_per_step'] for v in fam.values())
+        latency = {'model': 'launches/step x us/launch vs the 1.7 us dependent-launch floor',
+                   'bracketed_launches_per_step': n_launch,
+                   'per_family': {k: {'launches_per_step': v['launches_per_step'], 'event_us_per_launch': 1e3 * v['avg_launch_ms']}
+                                  for k, v in fam.items()},
+                   'step_us': step_s * 1e6, 'launch_floor_us': 1.7,
+                   'floor_us_per_step_bracketed_kernels': 1.7 * n_launch}
+    return {'bound': 'latency' if latency else 'mfma', 'latency': latency,
+            'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': d.get('mfma_util'), 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
             'direct_equivalent_tflops': d.get('algorithmic_tflops'), 'avg_launch_ms': d.get('avg_launch_ms'),
@@ -283,9 +303,9 @@ def main():
     ap.add_argument('--corrections', type=int, default=1)
     ap.add_argument('--tau', type=float, default=0.5)
     ap.add_argument('--per-gpu', type=int, default=0, help='override trajectories per GPU')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    ap.add_argument('--cpu-windows', type=int, default=2)
-    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = calibrate: fastest of 8..128 threads on a probe conv')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='timed CPU steps continue past the minimum of 3 while under this budget')
+    ap.add_argument('--cpu-windows', type=int, default=1, help='trajectory windows of the CPU sample (Kolmogorov workloads)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = calibrate: fastest of 16..128 threads on one score evaluation of the sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay each step from a captured hipGraph')

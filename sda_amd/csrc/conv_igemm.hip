@@ -842,14 +842,17 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     }
 }
 
-// which kernel family sda_conv_igemm would serve this launch with: 2 one-wave-per-SIMD Winograd, 1 Winograd, 0 direct
+// which kernel family sda_conv_igemm would serve this launch with: 2 one-wave-per-SIMD Winograd, 1 Winograd, 3 the small 1-D
+// kernel (conv_small1d.hip), 0 the direct implicit-GEMM kernels
 struct Wino4Geom;
 int sda_wino4_path(const sda_conv_desc* d);
 int sda_wino_path(const sda_conv_desc* d);
+int sda_small1d_path(const sda_conv_desc* d);
 extern "C" int sda_conv_igemm_path(const sda_conv_desc* d) {
     if (!d) return SDA_E_BADARG;
     if (d->w_wino4 && sda_wino4_path(d)) return 2;
     if (d->w_wino && sda_wino_path(d)) return 1;
+    if (d->kh == 1 && d->kw == 3 && sda_small1d_path(d)) return 3;
     return 0;
 }
 

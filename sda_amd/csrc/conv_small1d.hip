@@ -162,23 +162,34 @@ __global__ __launch_bounds__(256) void conv_small1d_kernel(const sda_conv_desc d
     }
 }
 
-// SDA_E_UNSUPPORTED -> the launch is served by the general kernels
-int sda_small1d_try(const sda_conv_desc* d, hipStream_t stream) {
+// eligibility + tile length (16 / 32 / 64 positions); 0 -> the launch is served by the general kernels, < 0 -> bad descriptor
+static int small1d_plan(const sda_conv_desc* d) {
     static const bool off = getenv("SDA_CONV_SMALL1D") && atoi(getenv("SDA_CONV_SMALL1D")) == 0;
-    if (off || !d) return SDA_E_UNSUPPORTED;
+    if (off || !d) return 0;
     if (d->kh != 1 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->hs != 1 || d->ho != 1 || d->up_h != 1 || d->up_w != 1 ||
         d->zins_h != 1 || d->zins_w != 1 || d->cctx != 0 || d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx)
-        return SDA_E_UNSUPPORTED;
+        return 0;
     if (d->cin_pad > S1_MAXC || d->cin_pad % 4 || d->cout_pad > 64 || d->cout_pad % 16 || d->cout > d->cout_pad || d->cx > d->cin_pad ||
         d->wo != d->ws || d->wo < 1 || d->n < 1 || d->n_inner < 1 || !d->x || !d->w || !d->out)
-        return SDA_E_UNSUPPORTED;
+        return 0;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return SDA_E_BADARG;
     // 64-position tiles for batches that fill the chip, smaller ones otherwise (see block1d.hip)
     const int tp = (int64_t)d->n * ((d->wo + 15) / 16) <= 1024 ? 16 : ((int64_t)d->n * ((d->wo + 31) / 32) <= 1024 ? 32 : 64);
+    // this kernel is for launches that cannot fill the chip with the staged kernel's tiles; big batches stay there
+    if ((int64_t)d->n * ((d->wo + tp - 1) / tp) > 4096) return 0;
+    return tp;
+}
+
+// would sda_conv_igemm serve this launch with conv_small1d_kernel?  (sda_conv_igemm_path)
+int sda_small1d_path(const sda_conv_desc* d) { return small1d_plan(d) > 0; }
+
+// SDA_E_UNSUPPORTED -> the launch is served by the general kernels
+int sda_small1d_try(const sda_conv_desc* d, hipStream_t stream) {
+    const int tp = small1d_plan(d);
+    if (tp == 0) return SDA_E_UNSUPPORTED;
+    if (tp < 0) return tp;
     const int ptiles = (d->wo + tp - 1) / tp;
     const int64_t grid = (int64_t)d->n * ptiles;
-    // this kernel is for launches that cannot fill the chip with the staged kernel's tiles; big batches stay there
-    if (grid > 4096) return SDA_E_UNSUPPORTED;
     if (tp == 16) hipLaunchKernelGGL(conv_small1d_kernel<16>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
     else if (tp == 32) hipLaunchKernelGGL(conv_small1d_kernel<32>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);
     else hipLaunchKernelGGL(conv_small1d_kernel<64>, dim3((unsigned)grid), dim3(256), 0, stream, *d, ptiles);

@@ -142,13 +142,17 @@ def conv_igemm(desc: ConvDesc):
         e0.record()
         _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
         e1.record()
-        prof.records.append((e0, e1, prof.flops(desc), ('direct', 'wino', 'wino4')[max(0, conv_path(desc))]))
+        prof.records.append((e0, e1, prof.flops(desc), CONV_FAMILIES[max(0, conv_path(desc))]))
         return
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 
+CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d')     # indexed by sda_conv_igemm_path
+
+
 def conv_path(desc: ConvDesc) -> int:
-    """Kernel family that would serve the launch: 2 one-wave-per-SIMD Winograd, 1 Winograd, 0 direct implicit GEMM."""
+    """Kernel family that would serve the launch: 2 one-wave-per-SIMD Winograd, 1 Winograd, 3 small 1-D kernel, 0 direct
+    implicit GEMM."""
     return _lib.load().sda_conv_igemm_path(ctypes.byref(desc))
 
 
@@ -207,6 +211,18 @@ def block1d_eligible(c: int, h: int, pk1: 'PackedConv', pk2: 'PackedConv') -> bo
             pk1.k_real == c and pk1.m_real == c and pk2.k_real == c and pk2.m_real == c)
 
 
+def _bracket_block1d(family: str, d, launch):
+    """bench.py's roofline leg: a fused 1-D residual block is two k = 3 convolutions c -> c over n x len positions."""
+    prof = conv_profile
+    if prof is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    prof.records.append((e0, e1, 2 * (2.0 * d.n * d.len * d.c * d.c * 3), family))
+
+
 def _block1d_desc(a, mod, mod_sn, pk1, pk2, circular, act, eps, unbiased):
     d = _lib.Block1dDesc()
     d.n, d.c, d.len = a.shape[0], a.shape[1], a.shape[-1]
@@ -227,7 +243,7 @@ def block1d_fwd(a: Tensor, mod, mod_sn: int, pk1: 'PackedConv', pk2: 'PackedConv
     _dev(a, mod, y, z, mean, rstd)
     d = _block1d_desc(a, mod, mod_sn, pk1, pk2, circular, act, eps, unbiased)
     d.y, d.z, d.mean, d.rstd = y.data_ptr(), _ptr(z), _ptr(mean), _ptr(rstd)
-    _lib.check(_lib.load().sda_block1d_fwd(ctypes.byref(d), _stream()), 'sda_block1d_fwd')
+    _bracket_block1d('block1d_fwd', d, lambda: _lib.check(_lib.load().sda_block1d_fwd(ctypes.byref(d), _stream()), 'sda_block1d_fwd'))
 
 
 def block1d_bwd(g: Tensor, a: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, mod, mod_sn: int, pk1b: 'PackedConv',
@@ -236,7 +252,7 @@ def block1d_bwd(g: Tensor, a: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, mod
     _dev(g, a, z, mean, rstd, mod, gx)
     d = _block1d_desc(a, mod, mod_sn, pk1b, pk2b, circular, act, 0.0, unbiased)
     d.z, d.mean, d.rstd, d.g, d.gx = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), gx.data_ptr()
-    _lib.check(_lib.load().sda_block1d_bwd(ctypes.byref(d), _stream()), 'sda_block1d_bwd')
+    _bracket_block1d('block1d_bwd', d, lambda: _lib.check(_lib.load().sda_block1d_bwd(ctypes.byref(d), _stream()), 'sda_block1d_bwd'))
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm pieces
