@@ -440,7 +440,9 @@ def main():
                        'score_evals_per_step': 1 + args.corrections, 'hipgraph_step': bool(args.graph), 'hipgraph_note': graph_note,
                        'observation': 'fused Subsample (hand-written adjoint; no autograd through A)',
                        'corrector_noise': 'row-keyed Philox (sda_randn_rows)',
-                       'parallelism': f'dp{world} (batch-sharded, no in-loop collective)'},
+                       'parallelism': f'dp{world} (batch-sharded, no in-loop collective)',
+                       'ranks_seen': dist.get_world_size() if world > 1 else 1,
+                       'backend': (args.backend + (' (RCCL)' if args.backend == 'nccl' else '')) if world > 1 else None},
             'wallclock_per_1000_steps_s': elapsed / args.steps * 1000,
             'samples_finite': finite, 'final_allgather_ms': gather_ms,
         }

@@ -56,8 +56,8 @@ struct Wino4Geom {
     int cin, hv, wv;                   // real input channels, virtual (= output) image size
     int bx_n, by_n;                    // 16 x 8-pixel blocks per image
     int n_ct, grid, nstage, debug, mtiles;
-    int walk;                          // 1: the workgroups of an XCD walk its block range interleaved (block = slot + j * per_xcd), 0: each a contiguous sub-range
-    int sx, sy, sn;                    // a workgroup's step from one block to its next, as (columns, rows, images) with sx < bx_n, sy < by_n
+    int walk;                          // 1: the workgroups of an XCD walk its tile range interleaved (tile = slot + j * per_xcd), 0: each a contiguous sub-range
+    int sc, sx, sy, sn;                // a workgroup's step from one tile to its next, as (cout tiles, columns, rows, images): mixed-radix digits
     long long* trace;                  // (tooling builds only) per-wave phase cycle sums
 };
 
@@ -118,7 +118,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     { static const int dbg = sda_debug_env(); g->debug = dbg; }            // (0 in the product build)
 #endif
     g->trace = nullptr;
-    g->walk = 1; g->sx = 1; g->sy = 0; g->sn = 0;          // (set per launch: sda_wino4_launch)
+    g->walk = 1; g->sc = 1; g->sx = 0; g->sy = 0; g->sn = 0;   // (set per launch: sda_wino4_launch)
     return SDA_OK;
 }
 
@@ -135,8 +135,8 @@ __device__ __forceinline__ W4Tile w4_decode(const Wino4Geom& g, int tile) {
 }
 
 // stage cursor (all scalar): stage in tile + the decoded tile.  Stepping to the next stage / tile is an increment with
-// carries: consecutive tiles of a workgroup are the cout tiles of one block (16 x 8 pixels of one image), then the
-// workgroup's next block -- (sx, sy, sn) further on in (column, row, image) order, see the tile walk in the kernel.
+// carries; a workgroup's next tile is (sc, sx, sy, sn) further on in (cout tile, column, row, image) order -- see the tile walk
+// in the kernel.
 struct W4Cur { int st, ct, bx, by, n; };
 // 1 if a == n else 0, for a <= n: pure integer arithmetic.  (A bool conjunction of uniform compares is lowered through lane
 // masks and a v_cndmask / v_readfirstlane pair -- vector instructions in a wave that must issue none.)
@@ -146,15 +146,17 @@ __device__ __forceinline__ int w4_ge(int a, int n) { return (int)((unsigned)(n -
 __device__ __forceinline__ void w4_advance(const Wino4Geom& g, W4Cur& c) {
     const int t_next = w4_eq(c.st + 1, g.nstage);
     c.st = (c.st + 1) * (1 - t_next);
-    const int b_next = t_next * w4_eq(c.ct + 1, g.n_ct);
-    c.ct = (c.ct + t_next) * (1 - b_next);
-    const int bx = c.bx + b_next * g.sx;                   // mixed-radix add of the block step: one carry per digit suffices
+    // mixed-radix add of the tile step: every digit of the step is below its radix, so one carry per digit suffices
+    const int ct = c.ct + t_next * g.sc;
+    const int cc = w4_ge(ct, g.n_ct);
+    c.ct = ct - cc * g.n_ct;
+    const int bx = c.bx + t_next * g.sx + cc;
     const int cx = w4_ge(bx, g.bx_n);
     c.bx = bx - cx * g.bx_n;
-    const int by = c.by + b_next * g.sy + cx;
+    const int by = c.by + t_next * g.sy + cx;
     const int cy = w4_ge(by, g.by_n);
     c.by = by - cy * g.by_n;
-    c.n += b_next * g.sn + cy;
+    c.n += t_next * g.sn + cy;
 }
 
 // phase stamps of the tracing variant (VAR == 11): T(k) adds the cycles since the previous stamp to phase k
@@ -202,34 +204,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     float* const ubuf = smem;                              // [2][W4_UBUF]
     float* const vbuf = smem + 2 * W4_UBUF;                // [2][W4_VBUF]
 
-    // persistent, XCD-aware tile walk over BLOCKS (16 x 8 output pixels of one image; a workgroup runs all cout tiles of a block
-    // back to back).  XCD (blockIdx & 7) owns a contiguous range of the (image, row, column)-ordered block list, and its
-    // per_xcd workgroups walk that range INTERLEAVED: at any moment they work on ~per_xcd consecutive blocks -- whole block rows
-    // of one image -- so the three 64-byte segments a halo row touches (the block's own and one of each horizontal neighbour),
-    // and the rows shared with the blocks above / below, are fetched into this XCD's L2 once and hit there for the neighbours
-    // within microseconds.  (Round 2 gave each workgroup a contiguous sub-range: a block's neighbour then ran on the same CU
-    // one tile later, after the XCD's 32 CUs had pulled twice the L2's size through it -- 3.5x the algorithmic reads reached
-    // the fabric, profiles/r02_*traffic.json.)  g.walk == 0 keeps the contiguous walk for A/B measurements.
+    // persistent, XCD-aware tile walk.  The tile list is ordered (image, block row, block column, cout tile), a block being
+    // 16 x 8 output pixels.  XCD (blockIdx & 7) owns a contiguous eighth of it, and its per_xcd workgroups walk that range
+    // INTERLEAVED (tile = begin + slot + j * per_xcd): at any moment the XCD works on ~per_xcd consecutive tiles, i.e. on ALL
+    // cout tiles of a few consecutive blocks -- whole block rows of one image.  Everything the tiles share is then fetched into
+    // this XCD's L2 once and hit there by the other readers within microseconds: the input of a block by its n_ct cout tiles,
+    // the three 128-byte lines a halo row touches by the horizontal neighbours, the rows shared with the blocks above / below,
+    // and a K-stage's U slab by the workgroups on the same cout tile (they run in near lockstep).  Round 2 gave each workgroup
+    // a contiguous sub-range: a block's neighbour (and its next cout tile) then ran on the same CU one tile later, after the
+    // XCD's 32 CUs had pulled twice the L2's size through it -- 5 to 16 times the algorithmic reads reached the fabric
+    // (profiles/r03_w4_traffic.txt).  g.walk == 0 keeps that walk for A/B measurements.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int nblk = g.grid / g.n_ct;
-    const int bq = nblk >> 3, br = nblk & 7;
-    const int b_begin = xcd * bq + (xcd < br ? xcd : br);
-    const int b_cnt = bq + (xcd < br ? 1 : 0);
-    int first_blk, my_blocks;
+    const int tq = g.grid >> 3, tr_ = g.grid & 7;
+    const int t_begin = xcd * tq + (xcd < tr_ ? xcd : tr_);
+    const int t_cnt = tq + (xcd < tr_ ? 1 : 0);
+    int first, my_tiles;
     if (g.walk) {
-        first_blk = b_begin + slot;
-        my_blocks = slot < b_cnt ? (b_cnt - slot + per_xcd - 1) / per_xcd : 0;
+        first = t_begin + slot;
+        my_tiles = slot < t_cnt ? (t_cnt - slot + per_xcd - 1) / per_xcd : 0;
     } else {
-        const int sq = b_cnt / per_xcd, sr = b_cnt % per_xcd;
-        first_blk = b_begin + slot * sq + (slot < sr ? slot : sr);
-        my_blocks = sq + (slot < sr ? 1 : 0);
+        const int sq = t_cnt / per_xcd, sr = t_cnt % per_xcd;
+        first = t_begin + slot * sq + (slot < sr ? slot : sr);
+        my_tiles = sq + (slot < sr ? 1 : 0);
     }
-    const int my_tiles = my_blocks * g.n_ct;
     if (my_tiles <= 0) return;
     const int Q = my_tiles * g.nstage;                     // stages this workgroup runs, across all of its tiles
     W4Cur c0;
     {
-        const W4Tile t0 = w4_decode(g, first_blk * g.n_ct);
+        const W4Tile t0 = w4_decode(g, first);
         c0.st = 0; c0.ct = t0.ct; c0.bx = t0.bx; c0.by = t0.by; c0.n = t0.n;
     }
 
@@ -928,8 +930,7 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
     const int cus = sda_cu_count();
     if (!cus) return SDA_E_BADARG;
     int grid = cus - cus % 8;
-    const int nblk = g_in.grid / g_in.n_ct;                // blocks: a workgroup runs all cout tiles of a block
-    const int need = (nblk + 7) / 8 * 8;
+    const int need = (g_in.grid + 7) / 8 * 8;
     if (grid > need) grid = need;
     if (grid < 8) grid = 8;
     // the tile walk (see the kernel): interleaved within an XCD by default; SDA_W4_WALK=0 = contiguous sub-ranges (A/B runs)
@@ -937,10 +938,11 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
     Wino4Geom g = g_in;
     g.walk = walk_on ? 1 : 0;
     {
-        const int step = walk_on ? grid / 8 : 1;           // blocks between a workgroup's consecutive blocks
-        g.sx = step % g.bx_n;
-        g.sy = (step / g.bx_n) % g.by_n;
-        g.sn = step / g.bx_n / g.by_n;
+        int step = walk_on ? grid / 8 : 1;                 // tiles between a workgroup's consecutive tiles
+        g.sc = step % g.n_ct; step /= g.n_ct;
+        g.sx = step % g.bx_n; step /= g.bx_n;
+        g.sy = step % g.by_n;
+        g.sn = step / g.by_n;
     }
     // the epilogue operand through the helpers (EPI): one operand, tiles of at least twelve stages (the six-stage load window
     // of a tile must open after the previous tile's operand has left the registers)

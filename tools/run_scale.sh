@@ -2,7 +2,9 @@
 # Scaling curve of bench.py on ONE node: N = 1, 2, 4, 8 ranks (one per GPU, RCCL), weak and strong.
 #   weak:   every rank owns a configuration shard (16 trajectories of 64x2x256x256); N = 8 is BASELINE configs[3] itself
 #   strong: the configuration's global batch (128 trajectories) is split over the ranks; N = 1 streams it in groups
-# usage: tools/run_scale.sh [outdir] [extra bench.py args...]      (no curve has been measured yet: no 8-GPU node was available)
+# usage: tools/run_scale.sh [outdir] [extra bench.py args...]      (no curve has been measured by the builder: 1-GPU boxes only)
+# NOTE strong scaling at N = 1 streams all 128 trajectories through one GPU: ~63 s per step (8 x the 7.9 s shard step) -- budget
+# ~3.5 min for its 2 steps + warm-up + capture.
 set -u
 OUT=${1:-gpurun_out/scale}; shift || true
 mkdir -p "$OUT"
@@ -29,4 +31,11 @@ for mode in ('weak', 'strong'):
             pass
     if 1 in rows:
         print(mode, {n: f'{v:.4f} steps/s ({v / rows[1]:.2f}x)' for n, v in sorted(rows.items())})
+for f in sorted(glob.glob(f'{sys.argv[1]}/*_n*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f"{f}: ranks seen (dist.get_world_size) {d['config'].get('ranks_seen')}, backend {d['config'].get('backend')}, "
+              f"final_allgather_ms {d.get('final_allgather_ms'):.2f}, ms_per_step {d['ms_per_step']:.1f}")
+    except Exception as e:
+        print(f, 'unreadable:', e)
 PY

@@ -39,8 +39,8 @@ if os.path.exists(log):
         for _, k, c, v in counter_rows(os.path.join(out, d), r'stream16|stream4|halo_read|store8'):
             if c != cname:
                 continue
-            key = 'halo_iso' if 'halo_readILi0' in k else 'halo_dense' if 'halo_readILi1' in k else re.sub(r'\(.*', '', k).replace('_Z', '').strip('0123456789')
-            key = [n for n in ('stream16', 'stream4', 'halo_iso', 'halo_dense', 'store8') if n in key][0]
+            key = 'halo_iso' if 'halo_read<0>' in k else 'halo_dense' if 'halo_read<1>' in k else \
+                [n for n in ('stream16', 'stream4', 'store8') if k.startswith(n)][0]
             per.setdefault(key, []).append(v * 1024)
         cal[cname] = {k: sum(v) / len(v) for k, v in per.items()}
     res['calibration_bytes_reported'] = cal
