@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 4
+#define SDA_ABI_VERSION 5
 
 enum {
     SDA_OK = 0,
@@ -151,6 +151,42 @@ typedef struct sda_block1d_desc {
 } sda_block1d_desc;
 int sda_block1d_fwd(const sda_block1d_desc* d, void* stream);
 int sda_block1d_bwd(const sda_block1d_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A whole SINGLE-LEVEL 1-D U-Net in ONE launch (the Lorenz score networks, experiments/lorenz/utils.py:26-42;
+ * sda/nn.py:184-206 with one level: head convolution cin -> c, `nblocks` modulated residual blocks (descent then ascent,
+ * sda/nn.py:18-28), tail convolution c -> cout; every convolution kernel 3, stride 1, one padding mode), and its input VJP
+ * in one more.  A workgroup owns a run of positions of one sequence and recomputes a halo of one position per convolution
+ * and side (csrc/net1d.hip), so no layer ever waits for another workgroup.
+ *   x / out: addressed as base + image * sn + channel * sc + position * sx (elements): (B, C, L) and (B, L, C) tensors alike.
+ *   weights: sda_pack_conv_weight packings [3][k][m], FORWARD form for sda_net1d_fwd; for sda_net1d_bwd the BACKWARD-DATA
+ *   forms in reverse role: w_head = tail^T (cout -> c), w1[k] / w2[k] = conv1^T / conv2^T of block k, w_tail = head^T
+ *   (c -> cin), x = the incoming cotangent (cin = its channels), out = the input gradient (cout = its channels).
+ *   k_pad_head x m_pad: head packing; k_pad x m_pad: block packings (c -> c); k_pad x m_pad_tail: tail packing.
+ *   a_save / z_save [nblocks][n][c][len], mean_save / rstd_save [nblocks][n][len] (block strides save_stride / stat_stride):
+ *   written by the forward when non-NULL (all four or none), read by the VJP.
+ * SDA_E_UNSUPPORTED outside the kernel's range (callers fall back to the per-block kernels). */
+#define SDA_NET1D_MAXB 8
+typedef struct sda_net1d_desc {
+    int32_t n, len;
+    int32_t cin, c, cout;
+    int32_t nblocks;
+    int32_t circular, act, unbiased;
+    float eps;
+    int32_t k_pad_head, k_pad, m_pad, m_pad_tail;
+    const float* x; int64_t x_sn, x_sc, x_sx;
+    float* out; int64_t out_sn, out_sc, out_sx;
+    const float* w_head; const float* b_head;
+    const float* w_tail; const float* b_tail;
+    const float* w1[SDA_NET1D_MAXB]; const float* b1[SDA_NET1D_MAXB];
+    const float* w2[SDA_NET1D_MAXB]; const float* b2[SDA_NET1D_MAXB];
+    const float* mod[SDA_NET1D_MAXB];  /* [*][c] additive modulation of block k (NULL = none) */
+    int64_t mod_sn;                    /* per-image stride of every mod (0 = shared) */
+    float* a_save; float* z_save; int64_t save_stride;
+    float* mean_save; float* rstd_save; int64_t stat_stride;
+} sda_net1d_desc;
+int sda_net1d_fwd(const sda_net1d_desc* d, void* stream);
+int sda_net1d_bwd(const sda_net1d_desc* d, void* stream);
 
 /* Repack torch-layout conv weights [cout][cin][kh][kw] for sda_conv_igemm.
  *   transpose = 0: forward          dst[tap][ci][co]        = w[co][ci][dy][dx]

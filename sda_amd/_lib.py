@@ -76,12 +76,39 @@ class Block1dDesc(Structure):
     ]
 
 
+NET1D_MAXB = 8
+
+
+class Net1dDesc(Structure):
+    """Mirror of `struct sda_net1d_desc` (include/sda_hip.h)."""
+    _fields_ = [
+        ('n', c_int32), ('len', c_int32),
+        ('cin', c_int32), ('c', c_int32), ('cout', c_int32),
+        ('nblocks', c_int32),
+        ('circular', c_int32), ('act', c_int32), ('unbiased', c_int32),
+        ('eps', c_float),
+        ('k_pad_head', c_int32), ('k_pad', c_int32), ('m_pad', c_int32), ('m_pad_tail', c_int32),
+        ('x', c_fp), ('x_sn', c_int64), ('x_sc', c_int64), ('x_sx', c_int64),
+        ('out', c_fp), ('out_sn', c_int64), ('out_sc', c_int64), ('out_sx', c_int64),
+        ('w_head', c_fp), ('b_head', c_fp),
+        ('w_tail', c_fp), ('b_tail', c_fp),
+        ('w1', c_fp * NET1D_MAXB), ('b1', c_fp * NET1D_MAXB),
+        ('w2', c_fp * NET1D_MAXB), ('b2', c_fp * NET1D_MAXB),
+        ('mod', c_fp * NET1D_MAXB),
+        ('mod_sn', c_int64),
+        ('a_save', c_fp), ('z_save', c_fp), ('save_stride', c_int64),
+        ('mean_save', c_fp), ('rstd_save', c_fp), ('stat_stride', c_int64),
+    ]
+
+
 SIGNATURES = {
     'sda_abi_version': (c_int, []),
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
     'sda_gauss_cotangent': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     'sda_block1d_fwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_block1d_bwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
+    'sda_net1d_fwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
+    'sda_net1d_bwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
     'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),

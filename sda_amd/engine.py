@@ -32,6 +32,11 @@ from . import ops
 from ._lib import SdaHipError
 from .ops import PackedConv, conv_out_size, make_conv_desc
 
+
+def _lib_net1d_maxb() -> int:
+    from ._lib import NET1D_MAXB
+    return NET1D_MAXB
+
 # fraction of currently-unallocated HBM one chunk's activations may occupy
 CHUNK_HBM_FRACTION = 0.45
 # fraction of unallocated HBM that activations kept from the forward for the VJP may occupy
@@ -324,6 +329,97 @@ class UNetEngine:
             del saved
             lo = hi
 
+    # -------------------------------------------------------------------------------- whole-net kernel (1-D, one level)
+    def net1d_plan(self, src: Source) -> Optional[dict]:
+        """The single-launch path (csrc/net1d.hip) serves single-level 1-D nets of <= 64 channels whose convolutions are all
+        k = 3, stride 1 with one padding mode -- the Lorenz score networks.  None: the per-layer / per-block kernels run."""
+        if not ops.NET1D or self.depth != 1 or self.unet.spatial != 1 or src.hs != 1 or src.cctx or src.n_inner != 1:
+            return None
+        lev = self.levels[0]
+        blocks = lev.descent + lev.ascent
+        convs = [lev.head, lev.tail] + [c for b in blocks for c in (b.conv1, b.conv2)]
+        if any((c.kh, c.kw, c.sh, c.sw) != (1, 3, 1, 1) or c.circular != lev.head.circular for c in convs):
+            return None
+        if len(blocks) > _lib_net1d_maxb() or lev.C < 2 or lev.C > 64 or src.cx > 64 or lev.tail.cout > 64:
+            return None
+        if any(b.act != blocks[0].act or b.ln.eps != blocks[0].ln.eps for b in blocks):
+            return None
+        if 64 - 2 * (2 * len(blocks) + 2) < 4:
+            return None
+        hf, tf = lev.head.fwd(), lev.tail.fwd()
+        pk = [(b.conv1.fwd(), b.conv2.fwd()) for b in blocks]
+        k_pad, m_pad = tf.k_pad, hf.m_pad
+        if any(p.k_pad != k_pad or p.m_pad != m_pad for pair in pk for p in pair):
+            return None
+        if max(k_pad, m_pad, hf.k_pad, tf.m_pad) > 64 or m_pad % 16 or tf.m_pad % 16 or k_pad % 4 or hf.k_pad % 4:
+            return None
+        return dict(lev=lev, blocks=blocks)
+
+    def _net1d_desc(self, plan, n: int, length: int, mod_all, lo: int, per_image: bool, backward: bool, cin_keep: int = 0):
+        from ._lib import Net1dDesc
+        lev, blocks = plan['lev'], plan['blocks']
+        d = Net1dDesc()
+        d.n, d.len, d.c, d.nblocks = n, length, lev.C, len(blocks)
+        d.circular, d.unbiased = int(lev.head.circular), int(self.unbiased)
+        d.act = blocks[0].act if blocks else 0
+        d.eps = blocks[0].ln.eps if blocks else 1e-5
+        keep = []                                        # (packed tensors referenced by raw pointer stay alive via the caches)
+        if not backward:
+            hp, tp = lev.head.fwd(), lev.tail.fwd()
+            d.cin, d.cout = lev.head.cin, lev.tail.cout
+            d.b_head = None if hp.bias is None else hp.bias.data_ptr()
+            d.b_tail = None if tp.bias is None else tp.bias.data_ptr()
+        else:
+            hp, tp = lev.tail.bwd(), lev.head.bwd(cin_keep=cin_keep)      # reverse roles: tail^T runs first, head^T last
+            d.cin, d.cout = lev.tail.cout, cin_keep
+            d.b_head = d.b_tail = None
+        d.w_head, d.w_tail = hp.packed.data_ptr(), tp.packed.data_ptr()
+        d.k_pad_head, d.m_pad, d.k_pad, d.m_pad_tail = hp.k_pad, hp.m_pad, tp.k_pad, tp.m_pad
+        for k, blk in enumerate(blocks):
+            p1 = blk.conv1.bwd() if backward else blk.conv1.fwd()
+            p2 = blk.conv2.bwd() if backward else blk.conv2.fwd()
+            d.w1[k], d.w2[k] = p1.packed.data_ptr(), p2.packed.data_ptr()
+            d.b1[k] = None if (backward or p1.bias is None) else p1.bias.data_ptr()
+            d.b2[k] = None if (backward or p2.bias is None) else p2.bias.data_ptr()
+            mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
+            d.mod[k] = None if mod is None else mod.data_ptr()
+            d.mod_sn = mod_sn
+            keep += [p1, p2, mod]
+        return d, keep
+
+    def _net1d_forward(self, plan, src: Source, lo: int, hi: int, mod_all, per_image: bool, out: Tensor, save: bool):
+        n, length = hi - lo, src.ws
+        d, keep = self._net1d_desc(plan, n, length, mod_all, lo, per_image, False)
+        d.x = src.x.data_ptr() + 4 * lo * src.sn_outer
+        d.x_sn, d.x_sc, d.x_sx = src.sn_outer, src.sc, src.sx
+        d.out = out.data_ptr()
+        d.out_sn, d.out_sc, d.out_sx = out.stride(0), out.stride(1), out.stride(3)
+        saved = None
+        if save:
+            nb, C, dev = len(plan['blocks']), plan['lev'].C, out.device
+            a_s = torch.empty(max(nb, 1), n, C, length, device=dev, dtype=torch.float32)
+            z_s = torch.empty_like(a_s)
+            m_s = torch.empty(max(nb, 1), n, length, device=dev, dtype=torch.float32)
+            r_s = torch.empty_like(m_s)
+            d.a_save, d.z_save, d.save_stride = a_s.data_ptr(), z_s.data_ptr(), n * C * length
+            d.mean_save, d.rstd_save, d.stat_stride = m_s.data_ptr(), r_s.data_ptr(), n * length
+            saved = dict(net1d=(plan, a_s, z_s, m_s, r_s), dims=[(1, length)])
+        ops.net1d_launch(d, False)
+        return saved
+
+    def _net1d_backward(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
+        plan, a_s, z_s, m_s, r_s = saved['net1d']
+        n, length = g_out.shape[0], src.ws
+        d, keep = self._net1d_desc(plan, n, length, mod_all, lo, per_image, True, cin_keep=src.cx)
+        d.x = g_out.data_ptr()
+        d.x_sn, d.x_sc, d.x_sx = g_out.stride(0), g_out.stride(1), g_out.stride(3)
+        d.out = g_in.data_ptr()
+        d.out_sn, d.out_sc, d.out_sx = g_in.stride(0), g_in.stride(1), g_in.stride(3)
+        C = plan['lev'].C
+        d.a_save, d.z_save, d.save_stride = a_s.data_ptr(), z_s.data_ptr(), n * C * length
+        d.mean_save, d.rstd_save, d.stat_stride = m_s.data_ptr(), r_s.data_ptr(), n * length
+        ops.net1d_launch(d, True)
+
     # -------------------------------------------------------------------------------- forward
     def _mod_for(self, blk: _Block, mod_all: Optional[Tensor], lo: int, per_image: bool):
         if mod_all is None:
@@ -367,6 +463,9 @@ class UNetEngine:
     def forward_chunk(self, src: Source, lo: int, hi: int, mod_all: Optional[Tensor], per_image: bool, out: Tensor,
                       save: bool):
         """Images [lo, hi) of ``src`` -> ``out`` (n, out_channels, h, w).  Returns what the VJP needs (or None)."""
+        plan = self.net1d_plan(src)
+        if plan is not None:
+            return self._net1d_forward(plan, src, lo, hi, mod_all, per_image, out, save)
         n = hi - lo
         dev = out.device
         L, D = self.levels, self.depth
@@ -453,6 +552,9 @@ class UNetEngine:
 
     def backward_chunk(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
         """g_out: (n, out_channels, h, w) -> g_in: (n, src.cx, hs, ws)   (context-channel gradients are not formed)."""
+        if 'net1d' in saved:
+            return self._net1d_backward(saved, g_out, src, lo, mod_all, per_image, g_in)
+        g_out = g_out.contiguous()
         L, D = self.levels, self.depth
         dims = saved['dims']
         n = g_out.shape[0]
@@ -522,7 +624,14 @@ class _UNetFunction(torch.autograd.Function):
         # output spatial size of level 0
         hd = engine.levels[0].head
         ho, wo = conv_out_size(src.hs, hd.kh, hd.sh), conv_out_size(src.ws, hd.kw, hd.sw)
-        out = torch.empty(n, out_channels, ho, wo, device=dev, dtype=torch.float32)
+        # a channel-last trajectory (MCScoreWrapper's transposed view of a (B, L, C) tensor) through the whole-net 1-D kernel:
+        # the output is laid out channel-last too, so that the wrapper's transpose back is a contiguous tensor -- the kernel
+        # writes through strides, no copy kernel on either side (and likewise for the cotangent / input gradient below)
+        ctx.channel_last = bool(src.hs == 1 and src.sc == 1 and src.sx == src.cx and src.cx > 1 and engine.net1d_plan(src) is not None)
+        if ctx.channel_last:
+            out = torch.empty(n, ho, wo, out_channels, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
+        else:
+            out = torch.empty(n, out_channels, ho, wo, device=dev, dtype=torch.float32)
         ctx.engine, ctx.src, ctx.mod_all, ctx.per_image = engine, src, mod_all, per_image
         ctx.x_shape = x.shape
         ctx.vjp_state = engine.forward_all(src, mod_all, per_image, out, need)
@@ -531,8 +640,11 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out: Tensor):
         engine, src = ctx.engine, ctx.src
-        g_out = g_out.contiguous()
-        g_in = torch.empty(src.n, src.cx, src.hs, src.ws, device=g_out.device, dtype=torch.float32)
+        if ctx.channel_last:                             # (strided cotangent in, channel-last gradient out: see forward)
+            g_in = torch.empty(src.n, src.hs, src.ws, src.cx, device=g_out.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        else:
+            g_out = g_out.contiguous()
+            g_in = torch.empty(src.n, src.cx, src.hs, src.ws, device=g_out.device, dtype=torch.float32)
         engine.backward_all(ctx.vjp_state, g_out, src, ctx.mod_all, ctx.per_image, g_in)
         return g_in.reshape(ctx.x_shape), None, None, None, None, None
 

@@ -255,6 +255,27 @@ def block1d_bwd(g: Tensor, a: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, mod
     _bracket_block1d('block1d_bwd', d, lambda: _lib.check(_lib.load().sda_block1d_bwd(ctypes.byref(d), _stream()), 'sda_block1d_bwd'))
 
 
+# ------------------------------------------------------------------------------------------ whole single-level 1-D net
+
+NET1D = os.environ.get('SDA_NET1D', '1') != '0'
+
+
+def net1d_launch(d: '_lib.Net1dDesc', backward: bool):
+    """One launch for a whole single-level 1-D U-Net (csrc/net1d.hip), forward or input VJP; see include/sda_hip.h."""
+    lib = _lib.load()
+    fn, name = (lib.sda_net1d_bwd, 'sda_net1d_bwd') if backward else (lib.sda_net1d_fwd, 'sda_net1d_fwd')
+    prof = conv_profile
+    if prof is None:
+        _lib.check(fn(ctypes.byref(d), _stream()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(fn(ctypes.byref(d), _stream()), name)
+    e1.record()
+    flops = 2.0 * d.n * d.len * 3 * (d.cin * d.c + 2 * d.nblocks * d.c * d.c + d.c * d.cout)
+    prof.records.append((e0, e1, flops, 'net1d_bwd' if backward else 'net1d_fwd'))
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm pieces
 
 def ln_stats(x: Tensor, mod: Optional[Tensor], mod_sn: int, eps: float, unbiased: bool, mean: Tensor, rstd: Tensor):

@@ -521,6 +521,7 @@ def test_fused_1d_block_equals_per_layer_path_and_oracle(dev, monkeypatch, chann
         return y.detach(), gx
 
     assert ops.BLOCK1D
+    monkeypatch.setattr(ops, 'NET1D', False)             # (the whole-net kernel has its own test below)
     y_f, gx_f = run()
     monkeypatch.setattr(ops, 'BLOCK1D', False)
     y_l, gx_l = run()
@@ -534,6 +535,65 @@ def test_fused_1d_block_equals_per_layer_path_and_oracle(dev, monkeypatch, chann
     gxo, = torch.autograd.grad(yo, xo, g.cpu().double())
     assert_close(y_f, yo.detach().float(), 1e-4, what='fused forward vs oracle')
     assert_close(gx_f, gxo.float(), 1e-4, what='fused VJP vs oracle')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('channels,hidden,blocks,length,batch,padding,act,layout', [
+    (3, 64, 3, 64, 1, 'zeros', 'SiLU', 'BLC'),           # Lorenz-63 global net (experiments/lorenz/utils.py:26-42), config [0]
+    (40, 64, 3, 128, 64, 'zeros', 'SiLU', 'BLC'),        # Lorenz-96, config [1]: 64-column tiles, four per sequence
+    (5, 48, 2, 37, 2, 'circular', 'SiLU', 'BCL'),        # circular wrap inside a tile, odd length
+    (7, 24, 1, 200, 3, 'zeros', 'GELU', 'BLC'),          # many tiles per sequence, partial last tile
+    (4, 64, 4, 130, 2, 'circular', 'ELU', 'BCL'),        # eight blocks (the kernel's maximum), halo 18
+    (6, 10, 1, 5, 3, 'zeros', 'SiLU', 'BLC'),            # a sequence shorter than the halo
+    (2, 64, 3, 20, 70, 'circular', 'SiLU', 'BLC'),       # a tile wraps a short circular sequence more than once
+])
+def test_whole_net_1d_kernel_equals_block_path_and_oracle(dev, monkeypatch, channels, hidden, blocks, length, batch, padding, act, layout):
+    """The single-launch 1-D U-Net (csrc/net1d.hip: halo-recompute tiles, weights double-buffered in registers, strided
+    input / output) against the per-block kernels and the float64 oracle: forward and input VJP, shared and per-sample time
+    embedding, (B, L, C) trajectories read / written through strides (MCScoreWrapper, sda/score.py:104-110)."""
+    import torch.nn as nn
+    from sda_amd import ops
+    from sda_amd.nn import UNet
+    from oracle import sda_oracle as O
+    torch.manual_seed(hash((channels, hidden, length, blocks)) % 1000)
+    net = UNet(channels, channels, 16, hidden_channels=(hidden,), hidden_blocks=(blocks,), kernel_size=3, activation=getattr(nn, act),
+               spatial=1, padding_mode=padding).to(dev)
+    assert net.engine().depth == 1
+    if layout == 'BLC':                                   # channel-last memory viewed as (B, C, L)
+        x = torch.randn(batch, length, channels, device=dev).transpose(1, 2)
+        g = torch.randn(batch, length, channels, device=dev).transpose(1, 2)
+    else:
+        x = torch.randn(batch, channels, length, device=dev)
+        g = torch.randn(batch, channels, length, device=dev)
+    for per_sample in (False, True):
+        emb = torch.randn(batch if per_sample else 1, 16, device=dev)
+
+        def run():
+            xx = x.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            y = net(xx, emb)
+            gx, = torch.autograd.grad(y, xx, g)
+            return y.detach(), gx
+
+        monkeypatch.setattr(ops, 'NET1D', True)
+        launches = []
+        real = ops.net1d_launch
+        monkeypatch.setattr(ops, 'net1d_launch', lambda d, bwd: (launches.append(bwd), real(d, bwd))[1])
+        y_n, gx_n = run()
+        assert launches == [False, True], 'the whole-net kernel did not serve this net'
+        if layout == 'BLC':                               # no transposing copies: results come back channel-last
+            assert y_n.transpose(1, 2).is_contiguous() and gx_n.transpose(1, 2).is_contiguous()
+        monkeypatch.setattr(ops, 'net1d_launch', real)
+        monkeypatch.setattr(ops, 'NET1D', False)
+        y_b, gx_b = run()
+        assert_close(y_n, y_b, 1e-5, what='whole-net vs per-block forward')
+        assert_close(gx_n, gx_b, 1e-5, what='whole-net vs per-block VJP')
+        sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+        cfg = O.UNetConfig(channels, channels, 16, (hidden,), (blocks,), 3, 2, act, 1, padding)
+        xo = x.detach().cpu().double().contiguous().requires_grad_(True)
+        yo = O.unet_forward(sd, "", cfg, xo, emb.cpu().double())
+        gxo, = torch.autograd.grad(yo, xo, g.cpu().double())
+        assert_close(y_n.cpu(), yo.detach().float(), 1e-4, what='whole-net forward vs oracle')
+        assert_close(gx_n.cpu(), gxo.float(), 1e-4, what='whole-net VJP vs oracle')
 
 
 @pytest.mark.gpu
