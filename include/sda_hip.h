@@ -159,10 +159,12 @@ int sda_block1d_bwd(const sda_block1d_desc* d, void* stream);
  * in one more.  A workgroup owns a run of positions of one sequence and recomputes a halo of one position per convolution
  * and side (csrc/net1d.hip), so no layer ever waits for another workgroup.
  *   x / out: addressed as base + image * sn + channel * sc + position * sx (elements): (B, C, L) and (B, L, C) tensors alike.
- *   weights: sda_pack_conv_weight packings [3][k][m], FORWARD form for sda_net1d_fwd; for sda_net1d_bwd the BACKWARD-DATA
- *   forms in reverse role: w_head = tail^T (cout -> c), w1[k] / w2[k] = conv1^T / conv2^T of block k, w_tail = head^T
- *   (c -> cin), x = the incoming cotangent (cin = its channels), out = the input gradient (cout = its channels).
- *   k_pad_head x m_pad: head packing; k_pad x m_pad: block packings (c -> c); k_pad x m_pad_tail: tail packing.
+ *   w: every convolution as an sda_pack_conv_weight packing [3][64][64] (k_pad = m_pad = 64: zero padded), 2 + 2 nblocks of them
+ *   back to back in EXECUTION order; bias: [2 + 2 nblocks][64] zero padded, same order (NULL = none).
+ *     sda_net1d_fwd: FORWARD packings: head, (conv1, conv2) of block 0 .. nblocks - 1, tail.
+ *     sda_net1d_bwd: BACKWARD-DATA packings (transpose = 1): tail^T (cout -> c), (conv2^T, conv1^T) of block nblocks - 1 .. 0,
+ *                    head^T (c -> cin); x = the incoming cotangent (cin = its channels), out = the input gradient (cout = its
+ *                    channels); mod[k] is still the modulation of forward block k.
  *   a_save / z_save [nblocks][n][c][len], mean_save / rstd_save [nblocks][n][len] (block strides save_stride / stat_stride):
  *   written by the forward when non-NULL (all four or none), read by the VJP.
  * SDA_E_UNSUPPORTED outside the kernel's range (callers fall back to the per-block kernels). */
@@ -173,13 +175,10 @@ typedef struct sda_net1d_desc {
     int32_t nblocks;
     int32_t circular, act, unbiased;
     float eps;
-    int32_t k_pad_head, k_pad, m_pad, m_pad_tail;
     const float* x; int64_t x_sn, x_sc, x_sx;
     float* out; int64_t out_sn, out_sc, out_sx;
-    const float* w_head; const float* b_head;
-    const float* w_tail; const float* b_tail;
-    const float* w1[SDA_NET1D_MAXB]; const float* b1[SDA_NET1D_MAXB];
-    const float* w2[SDA_NET1D_MAXB]; const float* b2[SDA_NET1D_MAXB];
+    const float* w;
+    const float* bias;
     const float* mod[SDA_NET1D_MAXB];  /* [*][c] additive modulation of block k (NULL = none) */
     int64_t mod_sn;                    /* per-image stride of every mod (0 = shared) */
     float* a_save; float* z_save; int64_t save_stride;

@@ -87,13 +87,10 @@ class Net1dDesc(Structure):
         ('nblocks', c_int32),
         ('circular', c_int32), ('act', c_int32), ('unbiased', c_int32),
         ('eps', c_float),
-        ('k_pad_head', c_int32), ('k_pad', c_int32), ('m_pad', c_int32), ('m_pad_tail', c_int32),
         ('x', c_fp), ('x_sn', c_int64), ('x_sc', c_int64), ('x_sx', c_int64),
         ('out', c_fp), ('out_sn', c_int64), ('out_sc', c_int64), ('out_sx', c_int64),
-        ('w_head', c_fp), ('b_head', c_fp),
-        ('w_tail', c_fp), ('b_tail', c_fp),
-        ('w1', c_fp * NET1D_MAXB), ('b1', c_fp * NET1D_MAXB),
-        ('w2', c_fp * NET1D_MAXB), ('b2', c_fp * NET1D_MAXB),
+        ('w', c_fp),
+        ('bias', c_fp),
         ('mod', c_fp * NET1D_MAXB),
         ('mod_sn', c_int64),
         ('a_save', c_fp), ('z_save', c_fp), ('save_stride', c_int64),

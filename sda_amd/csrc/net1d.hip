@@ -9,8 +9,10 @@
 //     the neighbouring workgroups (1.8x redundant multiplies at NF = 4 -- the nets are latency-bound, not MFMA-bound).
 //     Positions outside the sequence are forced to zero at every convolution input (zero padding) or wrap (circular).
 //   * wave w owns output channels 16 w .. 16 w + 15 of every convolution (v_mfma_f32_16x16x4_f32; A = weight fragments held
-//     in registers, straight from the packed [tap][k_pad][m_pad] layout, B from LDS).  The weights of convolution i + 1 are
-//     loaded (L2 -> registers, 48 dwords per lane) while convolution i multiplies: two register sets, alternating.
+//     in registers, B from LDS).  Every convolution's weights are packed [tap][64][64] (zero padded) in EXECUTION order in one
+//     buffer, so a fragment load is one lane offset + a scalar offset; the weights of convolution i + 1 are loaded (L2 ->
+//     registers, 48 dwords per lane) while convolution i multiplies: two register sets, alternating.  Biases and modulation
+//     vectors are staged in LDS once per launch.
 //   * the residual stream lives in registers in MFMA D layout (channel 16 w + 4 kq + r, column 16 nf + li) between layers;
 //     LayerNorm statistics are reduced lane-locally, across the four lane groups (shuffles), across the four waves (LDS).
 //   * what the VJP needs (block inputs a, pre-activations z, mean / rstd per position) is written for the own columns only;
@@ -19,14 +21,36 @@
 //     MCScoreWrapper (sda/score.py:104-110) cost nothing on either side.
 #include "sda_common.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
-#define N1_LD 80                       // LDS row stride: 80 mod 32 = 16 -> the two k rows of a 32-lane access group hit disjoint banks
+// LDS tiles are [column][channel] (68-float rows: 16-byte accesses of consecutive columns land 4 banks apart -> conflict free).
+// The K index of an MFMA fragment is a free permutation as long as both operands agree: fragment cb holds channels
+// { 16 kq + cb }, so a lane's 16 B values of one (column, tap) are CONSECUTIVE channels -- four ds_read_b128 feed sixteen MFMAs
+// (the [channel][column] layout of block1d.hip needs one ds_read_b32 per MFMA: +15-28 % on the stream, profiles/r02_w4_feed.txt)
+// -- and a lane's four D values of a column are consecutive channels too: one ds_write_b128 per column on the way back.
+#define N1_LD 68
 #define N1_MAXC 64
+#define N1_MAXCOL 66                   // 64 conv columns + one edge column per side
 
 typedef float n1_f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef SDA_N1_TRACE                    // tooling (tools/net1d_trace.py): per-phase cycle sums of workgroup 0 / wave 0
+__device__ long long n1_trace[16];
+#define N1_T0() long long n1_tl = __builtin_readcyclecounter()
+#define N1_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); n1_trace[k] += n_ - n1_tl; n1_tl = n_; } } while (0)
+extern "C" int sda_n1_trace_read(long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(n1_trace), sizeof(long long) * 16) != hipSuccess) return SDA_E_BADARG;
+    if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(n1_trace), z, sizeof(z)); }
+    return SDA_OK;
+}
+#else
+#define N1_T0() do {} while (0)
+#define N1_STAMP(k) do {} while (0)
+#endif
+
 struct N1Ctx {
     int tid, lane, wave, kq, li, co0, n, p0, H, len;
+    unsigned wlane;                    // this lane's element offset inside a [tap][64][64] weight slab: row 16 kq, column co0 + li
     bool circular;
 };
 
@@ -41,51 +65,45 @@ __device__ __forceinline__ int n1_pos(const N1Ctx& c, int j, bool& inside) {
     return inside ? p : 0;
 }
 
-// all A fragments of one convolution for this wave: one batch of unconditional loads from clamped addresses
-__device__ __forceinline__ void n1_load_w(const float* w, int k_pad, int m_pad, const N1Ctx& c, float (&wreg)[3][16]) {
-    const bool on = c.co0 < m_pad;
-    const float* wl = w + c.kq * m_pad + (on ? c.co0 : 0) + c.li;
-    const int frag = 4 * m_pad, tapstride = k_pad * m_pad, last = ((k_pad >> 2) - 1) * frag;
+// all A fragments of convolution `conv` for this wave: wreg[tap][cb] = W[conv][tap][k = 16 kq + cb][m = co0 + li]
+// (one batch of loads: a per-lane offset against wave-uniform bases)
+__device__ __forceinline__ void n1_load_w(const float* w, int conv, const N1Ctx& c, float (&wreg)[3][16]) {
+    const float* wb = w + (size_t)conv * (3 * 64 * 64);
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-        for (int cb = 0; cb < 16; ++cb) {
-            const int off = cb * frag < last ? cb * frag : last;           // (clamped: rows beyond k_pad multiply zero tile rows)
-            wreg[tap][cb] = wl[tap * tapstride + off];
-        }
+        for (int cb = 0; cb < 16; ++cb) wreg[tap][cb] = (wb + tap * 4096 + cb * 64)[c.wlane];
 }
 
-// acc[nf] = sum_{tap, cb} A(tap, cb) B[4 cb + k][16 nf + li + tap]   (tile rows of N1_LD floats; tile column jj <-> conv
-// column jj - 1).  All 16 K fragments, unconditionally (see block1d.hip: a runtime trip count costs more than the surplus MFMAs).
+// acc[nf] = sum_{tap, cb} A(tap, cb) B[channel 16 kq + cb][column 16 nf + li + tap]   (tile column jj <-> conv column jj - 1).
+// All 16 K fragments, unconditionally (see block1d.hip: a runtime trip count costs more than the surplus MFMAs).  Per tap the
+// wave reads its 16 x NF operand values as 4 x NF ds_read_b128; consecutive MFMAs rotate over the NF accumulators.
 template <int NF>
 __device__ __forceinline__ void n1_mm(const float (&wreg)[3][16], const float* tile, const N1Ctx& c, n1_f32x4 (&acc)[NF]) {
-    const float* brow = tile + c.kq * N1_LD + c.li;
-    float bv[2][NF][3];
+    const float* brow = tile + c.li * N1_LD + 16 * c.kq;
+    n1_f32x4 bv[NF][4];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        acc[nf] = n1_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NF; ++nf) acc[nf] = n1_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) bv[0][nf][tap] = brow[16 * nf + tap];
-    }
-#pragma unroll
-    for (int cb = 0; cb < 16; ++cb) {
-        const int cn = cb + 1 < 16 ? cb + 1 : cb;
+    for (int tap = 0; tap < 3; ++tap) {
+        // (one operand set: the ~100 cycles until a tap's reads return are exposed three times per 6000-cycle convolution)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) bv[(cb + 1) & 1][nf][tap] = brow[4 * cn * N1_LD + 16 * nf + tap];
+            for (int q = 0; q < 4; ++q)
+                bv[nf][q] = *reinterpret_cast<const n1_f32x4*>(brow + (16 * nf + tap) * N1_LD + 4 * q);
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+        for (int cb = 0; cb < 16; ++cb)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[cb & 1][nf][tap], acc[nf], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NF, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);
+                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[nf][cb >> 2][cb & 3], acc[nf], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // (or the scheduler hoists all three taps' reads: 192 live registers)
     }
 }
 
-// a strided (image, channel, position) tensor -> tile rows [0, 64) x conv columns [0, NC): thread (column j = tid & 63,
-// channel group tid >> 6): channels sub + 4 i.  Rows >= channels and columns outside the sequence are zero.
+// a strided (image, channel, position) tensor -> tile columns 1 .. NC (conv columns 0 .. NC-1), channels [0, 64): thread
+// (column j = lane, channel group = wave): channels 16 sub .. 16 sub + 15.  Channels >= `channels` and columns outside the
+// sequence are zero.  Offsets inside one image are 32-bit (checked by the launcher).
 template <int NF>
 __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64_t sc, int64_t sx, int channels, const N1Ctx& c,
                                              float* tile) {
@@ -94,29 +112,36 @@ __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64
     if (j < NC) {
         bool inside;
         const int ps = n1_pos(c, j, inside);
-        const float* base = src + (int64_t)c.n * sn + (int64_t)ps * sx;
-        float v[16];
+        const float* base = src + (int64_t)c.n * sn;
+        const unsigned lo = (unsigned)(ps * (int)sx);
+        n1_f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ci = sub + 4 * i, cic = ci < channels ? ci : channels - 1;
-            v[i] = base[(int64_t)cic * sc];
+            const int ci = 16 * sub + i, cic = ci < channels ? ci : channels - 1;
+            v[i >> 2][i & 3] = base[lo + (unsigned)(cic * (int)sc)];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ci = sub + 4 * i;
-            tile[ci * N1_LD + 1 + j] = (inside && ci < channels) ? v[i] : 0.f;
+            const int ci = 16 * sub + i;
+            if (!(inside && ci < channels)) v[i >> 2][i & 3] = 0.f;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<n1_f32x4*>(tile + (1 + j) * N1_LD + 16 * sub + 4 * q) = v[q];
     }
 }
 
-// registers in D layout -> tile rows of this wave (masked: columns outside the sequence and channels >= c are zero)
+// registers in D layout -> the tile channels of this wave (masked: columns outside the sequence and channels >= c are zero):
+// a lane's four values of a column are consecutive channels -> one 16-byte store per column
 template <int NF>
-__device__ __forceinline__ void n1_store_tile(const n1_f32x4 (&v)[NF], const bool (&inside)[NF], int c_real, const N1Ctx& c, float* tile) {
+__device__ __forceinline__ void n1_store_tile(const n1_f32x4 (&v)[NF], const bool (&inside)[NF], const bool (&rok)[4], const N1Ctx& c,
+                                              float* tile) {
+    const int cb = c.co0 + 4 * c.kq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int co = c.co0 + 4 * c.kq + r;
+    for (int nf = 0; nf < NF; ++nf) {
+        n1_f32x4 o;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) tile[co * N1_LD + 1 + 16 * nf + c.li] = (inside[nf] && co < c_real) ? v[nf][r] : 0.f;
+        for (int r = 0; r < 4; ++r) o[r] = (inside[nf] && rok[r]) ? v[nf][r] : 0.f;
+        *reinterpret_cast<n1_f32x4*>(tile + (1 + 16 * nf + c.li) * N1_LD + cb) = o;
     }
 }
 
@@ -139,80 +164,109 @@ __device__ __forceinline__ void n1_colsum(float (&s)[NF], float* red, const N1Ct
 }
 
 __device__ __forceinline__ void n1_ctx(N1Ctx& c, const sda_net1d_desc& d, int ptiles, int tp) {
-    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.kq = c.lane >> 4; c.li = c.lane & 15;
+    c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.kq = c.lane >> 4; c.li = c.lane & 15;
     c.co0 = 16 * c.wave; c.n = blockIdx.x / ptiles; c.p0 = (blockIdx.x - c.n * ptiles) * tp;
     c.H = 2 * d.nblocks + 2; c.len = d.len; c.circular = d.circular != 0;
+    c.wlane = (unsigned)(16 * c.kq * 64 + c.co0 + c.li);
+}
+
+// biases of every convolution and the modulation vectors of every block -> LDS (once per launch; read per block as one 16-byte
+// LDS read per lane instead of dependent global round trips).  All loads are issued before the first LDS store: one round trip.
+__device__ __forceinline__ void n1_stage_vectors(const sda_net1d_desc& d, const N1Ctx& c, float* sb, float* smod) {
+    constexpr int NB = ((2 + 2 * SDA_NET1D_MAXB) * 64 + 255) / 256, NM = (SDA_NET1D_MAXB * 64 + 255) / 256;
+    const int nconv = 2 + 2 * d.nblocks;
+    float vb[NB], vm[NM];
+    if (sb) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = c.tid + 256 * i;
+            vb[i] = (d.bias && e < nconv * 64) ? d.bias[e] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const int e = c.tid + 256 * i, k = e >> 6, ch = e & 63;
+        const float* mp = k < d.nblocks ? d.mod[k] : nullptr;
+        vm[i] = (mp && ch < d.c) ? mp[(int64_t)c.n * d.mod_sn + ch] : 0.f;
+    }
+    if (sb) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = c.tid + 256 * i;
+            if (e < (2 + 2 * SDA_NET1D_MAXB) * 64) sb[e] = vb[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) smod[c.tid + 256 * i] = vm[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
+// convolution order in d.w / d.bias: head, (conv1, conv2) of block 0 .. nblocks - 1, tail
 template <int NF>
 __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
-    __shared__ float tin[N1_MAXC * N1_LD];                 // input of the next convolution, tile column jj <-> conv column jj - 1
-    __shared__ float tz[N1_MAXC * N1_LD];                  // act(z) between the two convolutions of a block
+    __shared__ __attribute__((aligned(16))) float tin[N1_MAXCOL * N1_LD];     // input of the next convolution, [column jj <-> conv column jj - 1][channel]
+    __shared__ __attribute__((aligned(16))) float tz[N1_MAXCOL * N1_LD];      // act(z) between the two convolutions of a block
+    __shared__ __attribute__((aligned(16))) float sb[(2 + 2 * SDA_NET1D_MAXB) * 64];
+    __shared__ __attribute__((aligned(16))) float smod[SDA_NET1D_MAXB * 64];
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
+    N1_T0();
     float wA[3][16], wB[3][16];
-    n1_load_w(d.w_head, d.k_pad_head, d.m_pad, c, wA);
+    n1_load_w(d.w, 0, c, wA);
     // the two edge columns of both tiles are never written again: they stand for data beyond the tile (zeros: whatever they
     // were, the columns they reach are halo columns that have lost their meaning by the time they matter)
     if (c.tid < 2 * N1_MAXC) {
-        const int row = c.tid >> 1, col = (c.tid & 1) ? NC + 1 : 0;
-        tin[row * N1_LD + col] = 0.f;
-        tz[row * N1_LD + col] = 0.f;
+        const int ch = c.tid >> 1, col = (c.tid & 1) ? NC + 1 : 0;
+        tin[col * N1_LD + ch] = 0.f;
+        tz[col * N1_LD + ch] = 0.f;
     }
-    bool inside[NF], own[NF];
-    int pos[NF];
+    bool inside[NF], own[NF], rok[4];
+    unsigned soff[NF], ooff[NF];
+    const int cbase = c.co0 + 4 * c.kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rok[r] = cbase + r < d.c;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
         const int j = 16 * nf + c.li;
-        pos[nf] = n1_pos(c, j, inside[nf]);
+        const int ps = n1_pos(c, j, inside[nf]);
         own[nf] = inside[nf] && j >= c.H && j < c.H + tp && c.p0 - c.H + j < d.len;      // (the un-wrapped position is this tile's)
+        soff[nf] = (unsigned)(cbase * d.len + ps);                                       // planar [c][len] saves
+        ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
     }
     n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tin);
-    if (d.nblocks > 0) n1_load_w(d.w1[0], d.k_pad, d.m_pad, c, wB);
-    else n1_load_w(d.w_tail, d.k_pad, d.m_pad_tail, c, wB);
+    n1_stage_vectors(d, c, sb, smod);
+    n1_load_w(d.w, 1, c, wB);
+    N1_STAMP(0);                                           // address arithmetic + issue of the first loads
     __syncthreads();
+    N1_STAMP(1);                                           // the input tile's round trip
     // ---- head convolution: a = conv(x) + b
     n1_f32x4 a[NF];
     n1_mm<NF>(wA, tin, c, a);
     {
-        float bh[4];
+        const n1_f32x4 bh = *reinterpret_cast<const n1_f32x4*>(sb + cbase);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = c.co0 + 4 * c.kq + r;
-            bh[r] = (d.b_head && co < d.c) ? d.b_head[co] : 0.f;
-        }
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[nf][r] += bh[r];
+        for (int nf = 0; nf < NF; ++nf) a[nf] += bh;
     }
+    N1_STAMP(2);                                           // head convolution (waits for its weights)
     const bool silu = d.act == SDA_ACT_SILU;
     const float inv_c = 1.f / (float)d.c, inv_v = 1.f / (float)(d.unbiased ? d.c - 1 : d.c);
     const int64_t plane = (int64_t)d.c * d.len;
     for (int k = 0; k < d.nblocks; ++k) {
-        // ---- per-channel operands of the block (scalars per lane: 4 channels)
-        float mo[4], b1[4], b2[4];
-        const float* mp = d.mod[k] ? d.mod[k] + (int64_t)c.n * d.mod_sn : nullptr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = c.co0 + 4 * c.kq + r, coc = co < d.c ? co : d.c - 1;
-            mo[r] = mp ? mp[coc] : 0.f;
-            b1[r] = d.b1[k] ? d.b1[k][coc] : 0.f;
-            b2[r] = d.b2[k] ? d.b2[k][coc] : 0.f;
-        }
+        // ---- per-channel operands of the block (this lane's 4 channels)
+        const n1_f32x4 mo = *reinterpret_cast<const n1_f32x4*>(smod + k * 64 + cbase);
+        const n1_f32x4 b1 = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * k) * 64 + cbase);
+        const n1_f32x4 b2 = *reinterpret_cast<const n1_f32x4*>(sb + (2 + 2 * k) * 64 + cbase);
         // ---- the block input is what the VJP differentiates through: save the own columns
         if (d.a_save) {
             float* as = d.a_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = c.co0 + 4 * c.kq + r;
-                if (co < d.c)
+                float* asr = as + r * d.len;               // (uniform)
 #pragma unroll
-                    for (int nf = 0; nf < NF; ++nf)
-                        if (own[nf]) as[(int64_t)co * d.len + pos[nf]] = a[nf][r];
+                for (int nf = 0; nf < NF; ++nf)
+                    if (own[nf] && rok[r]) asr[soff[nf]] = a[nf][r];
             }
         }
         // ---- LayerNorm over channels of u = a + mod (two passes over registers: mean, then centred sum of squares)
@@ -223,12 +277,12 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             s[nf] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool on = (c.co0 + 4 * c.kq + r) < d.c;
-                u[nf][r] = on ? a[nf][r] + mo[r] : 0.f;
+                u[nf][r] = rok[r] ? a[nf][r] + mo[r] : 0.f;
                 s[nf] += u[nf][r];
             }
         }
         n1_colsum<NF>(s, red, c);
+        N1_STAMP(3);                                       // block operands, a_save stores, first channel reduction
         float mean[NF], rstd[NF];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
@@ -236,15 +290,14 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             s[nf] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool on = (c.co0 + 4 * c.kq + r) < d.c;
                 const float dl = u[nf][r] - mean[nf];
-                s[nf] += on ? dl * dl : 0.f;
+                s[nf] += rok[r] ? dl * dl : 0.f;
             }
         }
         n1_colsum<NF>(s, red + 4 * NC, c);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-            rstd[nf] = 1.0f / sqrtf(s[nf] * inv_v + d.eps);
+            rstd[nf] = __builtin_amdgcn_rsqf(s[nf] * inv_v + d.eps);       // (v_rsq_f32: 1 ulp)
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[nf][r] = (u[nf][r] - mean[nf]) * rstd[nf];
         }
@@ -253,111 +306,125 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             float* rs = d.rstd_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-                if (own[nf]) { ms[pos[nf]] = mean[nf]; rs[pos[nf]] = rstd[nf]; }
+                if (own[nf]) { const unsigned p = soff[nf] - (unsigned)(cbase * d.len); ms[p] = mean[nf]; rs[p] = rstd[nf]; }
         }
-        n1_store_tile<NF>(u, inside, d.c, c, tin);
-        n1_load_w(d.w2[k], d.k_pad, d.m_pad, c, wA);                       // (set A is free: the previous conv2 / the head is done)
+        n1_store_tile<NF>(u, inside, rok, c, tin);
+        n1_load_w(d.w, 2 + 2 * k, c, wA);                  // conv2 of this block (set A is free: the previous conv2 / the head is done)
         __syncthreads();
+        N1_STAMP(4);                                       // second reduction, normalised tile -> LDS, weight-load issue
         // ---- conv1: z = conv(LN) + b1 -> saved (own columns); act(z) -> LDS
         n1_f32x4 z[NF];
         n1_mm<NF>(wB, tin, c, z);
+        N1_STAMP(5);                                       // conv1 multiply
         float* zs = d.z_save ? d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane : nullptr;
         auto conv1_epilogue = [&](auto SILU_) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = c.co0 + 4 * c.kq + r;
+                float* zsr = zs + r * d.len;
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) {
                     const float zv = z[nf][r] + b1[r];
-                    if (zs && co < d.c && own[nf]) zs[(int64_t)co * d.len + pos[nf]] = zv;
+                    if (zs && own[nf] && rok[r]) zsr[soff[nf]] = zv;
                     z[nf][r] = decltype(SILU_)::value ? sda_act(SDA_ACT_SILU, zv) : sda_act(d.act, zv);
                 }
             }
         };
         if (silu) conv1_epilogue(std::true_type{});
         else conv1_epilogue(std::false_type{});
-        n1_store_tile<NF>(z, inside, d.c, c, tz);
-        if (k + 1 < d.nblocks) n1_load_w(d.w1[k + 1], d.k_pad, d.m_pad, c, wB);
-        else n1_load_w(d.w_tail, d.k_pad, d.m_pad_tail, c, wB);
+        n1_store_tile<NF>(z, inside, rok, c, tz);
+        n1_load_w(d.w, 3 + 2 * k, c, wB);                  // conv1 of the next block, or the tail
         __syncthreads();
+        N1_STAMP(6);                                       // conv1 epilogue: z stores, activation, tile -> LDS
         // ---- conv2 + b2 + residual
         n1_f32x4 y[NF];
         n1_mm<NF>(wA, tz, c, y);
+        N1_STAMP(7);                                       // conv2 multiply
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[nf][r] += y[nf][r] + b2[r];
+        for (int nf = 0; nf < NF; ++nf) a[nf] += y[nf] + b2;
+        N1_STAMP(8);                                       // residual update
     }
     // ---- tail convolution -> out (own columns, through the output strides)
-    n1_store_tile<NF>(a, inside, d.c, c, tin);
+    n1_store_tile<NF>(a, inside, rok, c, tin);
     __syncthreads();
     n1_f32x4 o[NF];
     n1_mm<NF>(wB, tin, c, o);
+    {
+        const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
+        float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int co = c.co0 + 4 * c.kq + r;
-        if (co >= d.cout) continue;
-        const float bt = d.b_tail ? d.b_tail[co] : 0.f;
-        float* op = d.out + (int64_t)c.n * d.out_sn + (int64_t)co * d.out_sc;
+        for (int r = 0; r < 4; ++r) {
+            float* obr = ob + (int64_t)r * d.out_sc;       // (uniform)
+            const bool cok = cbase + r < d.cout;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-            if (own[nf]) op[(int64_t)pos[nf] * d.out_sx] = o[nf][r] + bt;
+            for (int nf = 0; nf < NF; ++nf)
+                if (own[nf] && cok) obr[ooff[nf]] = o[nf][r] + bt[r];
+        }
     }
+    N1_STAMP(9);                                           // tail convolution + output stores
 }
 
 // ------------------------------------------------------------------------------------------------------------ input VJP
-// w_* are the BACKWARD-DATA packings here (sda_pack_conv_weight with transpose = 1): "head" = tail^T (cout -> c, runs first),
-// "tail" = head^T (c -> cin, runs last); w1 / w2 of block k are conv1^T / conv2^T.  x = incoming cotangent, out = input gradient.
+// d.w holds the BACKWARD-DATA packings (sda_pack_conv_weight with transpose = 1) in execution order: tail^T (cout -> c), then for
+// k = nblocks - 1 .. 0: conv2^T, conv1^T of block k, then head^T (c -> cin).  x = incoming cotangent (cin = its channels), out =
+// the input gradient (cout = its channels); d.bias is unused.
 template <int NF>
 __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
-    __shared__ float tg[N1_MAXC * N1_LD];
-    __shared__ float tq[N1_MAXC * N1_LD];
+    __shared__ __attribute__((aligned(16))) float tg[N1_MAXCOL * N1_LD];
+    __shared__ __attribute__((aligned(16))) float tq[N1_MAXCOL * N1_LD];
+    __shared__ __attribute__((aligned(16))) float smod[SDA_NET1D_MAXB * 64];
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
     float wA[3][16], wB[3][16];
-    n1_load_w(d.w_head, d.k_pad_head, d.m_pad, c, wA);
+    n1_load_w(d.w, 0, c, wA);
     if (c.tid < 2 * N1_MAXC) {
-        const int row = c.tid >> 1, col = (c.tid & 1) ? NC + 1 : 0;
-        tg[row * N1_LD + col] = 0.f;
-        tq[row * N1_LD + col] = 0.f;
+        const int ch = c.tid >> 1, col = (c.tid & 1) ? NC + 1 : 0;
+        tg[col * N1_LD + ch] = 0.f;
+        tq[col * N1_LD + ch] = 0.f;
     }
-    bool inside[NF], own[NF];
-    int pos[NF];
+    bool inside[NF], own[NF], rok[4];
+    unsigned poff[NF], ooff[NF];
+    const int cbase = c.co0 + 4 * c.kq;
+    // (loads of saved tensors clamp their channel row: lanes beyond c read a row that exists and are masked afterwards)
+    unsigned roff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rok[r] = cbase + r < d.c;
+        roff[r] = (unsigned)((rok[r] ? cbase + r : d.c - 1) * d.len);
+    }
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
         const int j = 16 * nf + c.li;
-        pos[nf] = n1_pos(c, j, inside[nf]);
+        const int ps = n1_pos(c, j, inside[nf]);
         own[nf] = inside[nf] && j >= c.H && j < c.H + tp && c.p0 - c.H + j < d.len;
+        poff[nf] = (unsigned)ps;
+        ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
     }
     n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tg);
-    const int kl = d.nblocks - 1;
-    if (d.nblocks > 0) n1_load_w(d.w2[kl], d.k_pad, d.m_pad, c, wB);
-    else n1_load_w(d.w_tail, d.k_pad, d.m_pad_tail, c, wB);
+    n1_stage_vectors(d, c, nullptr, smod);
+    n1_load_w(d.w, 1, c, wB);
     const int64_t plane = (int64_t)d.c * d.len;
     // what a block's VJP reads from the forward, in D layout on every column (halo columns: written by the neighbours)
     n1_f32x4 ez[NF], ea[NF];
-    float emean[NF], erstd[NF], emod[4];
+    float emean[NF], erstd[NF];
     auto fetch_saved = [&](int k) {
         const float* zs = d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
         const float* as = d.a_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
         const float* ms = d.mean_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
         const float* rs = d.rstd_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
-        const float* mp = d.mod[k] ? d.mod[k] + (int64_t)c.n * d.mod_sn : nullptr;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = c.co0 + 4 * c.kq + r, coc = co < d.c ? co : d.c - 1;
-            emod[r] = mp ? mp[coc] : 0.f;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
-                ez[nf][r] = zs[(int64_t)coc * d.len + pos[nf]];
-                ea[nf][r] = as[(int64_t)coc * d.len + pos[nf]];
+                const unsigned o = roff[r] + poff[nf];
+                ez[nf][r] = zs[o];
+                ea[nf][r] = as[o];
             }
-        }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) { emean[nf] = ms[pos[nf]]; erstd[nf] = rs[pos[nf]]; }
+        for (int nf = 0; nf < NF; ++nf) { emean[nf] = ms[poff[nf]]; erstd[nf] = rs[poff[nf]]; }
     };
+    const int kl = d.nblocks - 1;
     if (d.nblocks > 0) fetch_saved(kl);
     __syncthreads();
     // ---- tail^T: g = conv^T(cotangent)
@@ -365,9 +432,11 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
     n1_mm<NF>(wA, tg, c, g);
     const bool silu = d.act == SDA_ACT_SILU;
     const float inv_c = 1.f / (float)d.c, inv_v = 1.f / (float)(d.unbiased ? d.c - 1 : d.c);
-    for (int k = kl; k >= 0; --k) {
-        n1_store_tile<NF>(g, inside, d.c, c, tg);
-        n1_load_w(d.w1[k], d.k_pad, d.m_pad, c, wA);
+    int conv = 1;                                          // index of the convolution whose weights sit in wB
+    for (int k = kl; k >= 0; --k, conv += 2) {
+        const n1_f32x4 emod = *reinterpret_cast<const n1_f32x4*>(smod + k * 64 + cbase);
+        n1_store_tile<NF>(g, inside, rok, c, tg);
+        n1_load_w(d.w, conv + 1, c, wA);                   // conv1^T of this block
         __syncthreads();
         // ---- conv2^T, x act'(z) -> LDS
         n1_f32x4 q[NF];
@@ -381,9 +450,8 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
         };
         if (silu) dact(std::true_type{});
         else dact(std::false_type{});
-        n1_store_tile<NF>(q, inside, d.c, c, tq);
-        if (k > 0) n1_load_w(d.w2[k - 1], d.k_pad, d.m_pad, c, wB);
-        else n1_load_w(d.w_tail, d.k_pad, d.m_pad_tail, c, wB);
+        n1_store_tile<NF>(q, inside, rok, c, tq);
+        n1_load_w(d.w, conv + 2, c, wB);                   // conv2^T of the block before, or head^T
         __syncthreads();
         // ---- conv1^T -> gh; LayerNorm backward: g <- rstd (gh - mean_c(gh) - xh mean'_c(gh xh)) + g
         n1_f32x4 gh[NF], xh[NF];
@@ -394,9 +462,8 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
             s1[nf] = 0.f; s2[nf] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool on = (c.co0 + 4 * c.kq + r) < d.c;
-                xh[nf][r] = on ? (ea[nf][r] + emod[r] - emean[nf]) * erstd[nf] : 0.f;
-                const float gv = on ? gh[nf][r] : 0.f;
+                xh[nf][r] = rok[r] ? (ea[nf][r] + emod[r] - emean[nf]) * erstd[nf] : 0.f;
+                const float gv = rok[r] ? gh[nf][r] : 0.f;
                 s1[nf] += gv; s2[nf] += gv * xh[nf][r];
             }
         }
@@ -412,18 +479,18 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
         __syncthreads();                                   // (red is reused by the next block's sums)
     }
     // ---- head^T -> input gradient (own columns, through the output strides)
-    n1_store_tile<NF>(g, inside, d.c, c, tg);
+    n1_store_tile<NF>(g, inside, rok, c, tg);
     __syncthreads();
     n1_f32x4 o[NF];
     n1_mm<NF>(wB, tg, c, o);
+    float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = c.co0 + 4 * c.kq + r;
-        if (co >= d.cout) continue;
-        float* op = d.out + (int64_t)c.n * d.out_sn + (int64_t)co * d.out_sc;
+        float* obr = ob + (int64_t)r * d.out_sc;
+        const bool cok = cbase + r < d.cout;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-            if (own[nf]) op[(int64_t)pos[nf] * d.out_sx] = o[nf][r];
+            if (own[nf] && cok) obr[ooff[nf]] = o[nf][r];
     }
 }
 
@@ -431,28 +498,38 @@ static int net1d_check(const sda_net1d_desc* d, bool bwd) {
     if (!d || d->n < 1 || d->len < 1 || d->c < 2 || d->c > N1_MAXC || d->cin < 1 || d->cin > N1_MAXC || d->cout < 1 ||
         d->cout > N1_MAXC || d->nblocks < 0 || d->nblocks > SDA_NET1D_MAXB)
         return SDA_E_UNSUPPORTED;
-    if (d->k_pad > N1_MAXC || d->k_pad % 4 || d->k_pad < d->c || d->m_pad > N1_MAXC || d->m_pad % 16 || d->m_pad < d->c ||
-        d->k_pad_head > N1_MAXC || d->k_pad_head % 4 || d->k_pad_head < d->cin || d->m_pad_tail > N1_MAXC || d->m_pad_tail % 16 ||
-        d->m_pad_tail < d->cout)
+    if (!d->x || !d->out || !d->w) return SDA_E_BADARG;
+    // offsets inside one image are formed in 32 bits
+    if ((int64_t)d->len * 64 >= (1LL << 30)) return SDA_E_UNSUPPORTED;
+    auto span = [&](int64_t sc, int64_t sx, int ch) { return (sc < 0 ? -sc : sc) * ch + (sx < 0 ? -sx : sx) * (int64_t)d->len; };
+    if (d->x_sc < 0 || d->x_sx < 0 || d->out_sc < 0 || d->out_sx < 0 || span(d->x_sc, d->x_sx, d->cin) >= (1LL << 30) ||
+        span(d->out_sc, d->out_sx, d->cout) >= (1LL << 30))
         return SDA_E_UNSUPPORTED;
-    if (!d->x || !d->out || !d->w_head || !d->w_tail) return SDA_E_BADARG;
-    for (int k = 0; k < d->nblocks; ++k)
-        if (!d->w1[k] || !d->w2[k]) return SDA_E_BADARG;
     const bool saves = d->a_save && d->z_save && d->mean_save && d->rstd_save;
     if (bwd && d->nblocks > 0 && !saves) return SDA_E_BADARG;
     if (!bwd && (d->a_save || d->z_save || d->mean_save || d->rstd_save) && !saves) return SDA_E_BADARG;
     return SDA_OK;
 }
 
-// columns per tile: 64 (36 own positions with the six blocks of the Lorenz nets) when that fills the chip, else 48 (20 own)
+// columns per tile (16 NF): the fewer sequences there are, the more workgroups per sequence -- a tile's time is ~ its column
+// count, and an idle CU is worth nothing: 64 columns (36 own positions with the six blocks of the Lorenz nets) when that fills the
+// chip, else 48 (20 own), else 32 (4 own: Lorenz-63, one sequence of 64 positions = 16 workgroups)
 static int net1d_nf(const sda_net1d_desc* d) {
     static const int forced = getenv("SDA_NET1D_NF") ? atoi(getenv("SDA_NET1D_NF")) : 0;
     const int H = 2 * d->nblocks + 2;
-    if ((forced == 3 || forced == 4) && 16 * forced - 2 * H >= 4) return forced;
-    const int tp4 = 64 - 2 * H, tp3 = 48 - 2 * H;
+    if (forced >= 2 && forced <= 4 && 16 * forced - 2 * H >= 4) return forced;
+    const int tp4 = 64 - 2 * H, tp3 = 48 - 2 * H, tp2 = 32 - 2 * H;
     if (tp4 < 4) return 0;
-    if (tp3 >= 8 && (int64_t)d->n * ((d->len + tp4 - 1) / tp4) < 128) return 3;
-    return 4;
+    auto wgs = [&](int tp) { return (int64_t)d->n * ((d->len + tp - 1) / tp); };
+    if (wgs(tp4) >= 128 || tp3 < 4) return 4;
+    if (wgs(tp3) >= 128 || tp2 < 4) return 3;
+    return 2;
+}
+
+template <bool BWD, int NF>
+static void net1d_launch_nf(const sda_net1d_desc* d, dim3 grid, int ptiles, int tp, hipStream_t stream) {
+    if (BWD) hipLaunchKernelGGL(net1d_bwd_kernel<NF>, grid, dim3(256), 0, stream, *d, ptiles, tp);
+    else hipLaunchKernelGGL(net1d_fwd_kernel<NF>, grid, dim3(256), 0, stream, *d, ptiles, tp);
 }
 
 template <bool BWD>
@@ -464,13 +541,9 @@ static int net1d_launch(const sda_net1d_desc* d, hipStream_t stream) {
     const int tp = 16 * nf - 2 * (2 * d->nblocks + 2), ptiles = (d->len + tp - 1) / tp;
     if ((int64_t)d->n * ptiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     const dim3 grid((unsigned)(d->n * ptiles));
-    if (nf == 3) {
-        if (BWD) hipLaunchKernelGGL(net1d_bwd_kernel<3>, grid, dim3(256), 0, stream, *d, ptiles, tp);
-        else hipLaunchKernelGGL(net1d_fwd_kernel<3>, grid, dim3(256), 0, stream, *d, ptiles, tp);
-    } else {
-        if (BWD) hipLaunchKernelGGL(net1d_bwd_kernel<4>, grid, dim3(256), 0, stream, *d, ptiles, tp);
-        else hipLaunchKernelGGL(net1d_fwd_kernel<4>, grid, dim3(256), 0, stream, *d, ptiles, tp);
-    }
+    if (nf == 2) net1d_launch_nf<BWD, 2>(d, grid, ptiles, tp, stream);
+    else if (nf == 3) net1d_launch_nf<BWD, 3>(d, grid, ptiles, tp, stream);
+    else net1d_launch_nf<BWD, 4>(d, grid, ptiles, tp, stream);
     return sda_launch_status();
 }
 

@@ -243,6 +243,7 @@ class UNetEngine:
                 blk.conv1.invalidate()
                 blk.conv2.invalidate()
         self._proj_key = None
+        self.__dict__.pop('_net1d_cache', None)
 
     # -------------------------------------------------------------------------------- modulation vectors
     def _blocks(self):
@@ -346,14 +347,35 @@ class UNetEngine:
             return None
         if 64 - 2 * (2 * len(blocks) + 2) < 4:
             return None
-        hf, tf = lev.head.fwd(), lev.tail.fwd()
-        pk = [(b.conv1.fwd(), b.conv2.fwd()) for b in blocks]
-        k_pad, m_pad = tf.k_pad, hf.m_pad
-        if any(p.k_pad != k_pad or p.m_pad != m_pad for pair in pk for p in pair):
-            return None
-        if max(k_pad, m_pad, hf.k_pad, tf.m_pad) > 64 or m_pad % 16 or tf.m_pad % 16 or k_pad % 4 or hf.k_pad % 4:
-            return None
         return dict(lev=lev, blocks=blocks)
+
+    def _net1d_weights(self, plan, backward: bool, cin_keep: int = 0):
+        """Every convolution of the net as a [3][64][64] packing (zero padded) in the kernel's execution order, in one buffer
+        (+ the biases, [conv][64], for the forward); cached until a parameter changes."""
+        lev, blocks = plan['lev'], plan['blocks']
+        convs = [lev.head] + [c for b in blocks for c in (b.conv1, b.conv2)] + [lev.tail]
+        for cc in convs:
+            cc._sync()
+        key = (backward, cin_keep, tuple(cc._key for cc in convs))
+        cache = self.__dict__.setdefault('_net1d_cache', {})
+        hit = cache.get(backward)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        dev = lev.head.conv.weight.device
+        if backward:                                     # tail^T, (conv2^T, conv1^T) of the blocks in reverse, head^T
+            order = [(lev.tail, None)] + [(c, None) for b in reversed(blocks) for c in (b.conv2, b.conv1)] + [(lev.head, cin_keep)]
+        else:
+            order = [(cc, None) for cc in convs]
+        w = torch.empty(len(order), 3 * 64 * 64, device=dev, dtype=torch.float32)
+        bias = None if backward else torch.zeros(len(order), 64, device=dev, dtype=torch.float32)
+        for i, (cc, keep) in enumerate(order):
+            wt = cc.conv.weight.detach().contiguous()
+            cout, cin = wt.shape[0], wt.shape[1]
+            ops.pack_conv_weight(wt, cout, cin, 1, 3, backward, (cin if keep is None else keep) if backward else cin, w[i], 64, 64)
+            if bias is not None and cc.conv.bias is not None:
+                bias[i, :cout] = cc.conv.bias.detach()
+        cache[backward] = (key, w, bias)
+        return w, bias
 
     def _net1d_desc(self, plan, n: int, length: int, mod_all, lo: int, per_image: bool, backward: bool, cin_keep: int = 0):
         from ._lib import Net1dDesc
@@ -363,28 +385,18 @@ class UNetEngine:
         d.circular, d.unbiased = int(lev.head.circular), int(self.unbiased)
         d.act = blocks[0].act if blocks else 0
         d.eps = blocks[0].ln.eps if blocks else 1e-5
-        keep = []                                        # (packed tensors referenced by raw pointer stay alive via the caches)
+        w, bias = self._net1d_weights(plan, backward, cin_keep)
+        d.w, d.bias = w.data_ptr(), None if bias is None else bias.data_ptr()
         if not backward:
-            hp, tp = lev.head.fwd(), lev.tail.fwd()
             d.cin, d.cout = lev.head.cin, lev.tail.cout
-            d.b_head = None if hp.bias is None else hp.bias.data_ptr()
-            d.b_tail = None if tp.bias is None else tp.bias.data_ptr()
         else:
-            hp, tp = lev.tail.bwd(), lev.head.bwd(cin_keep=cin_keep)      # reverse roles: tail^T runs first, head^T last
             d.cin, d.cout = lev.tail.cout, cin_keep
-            d.b_head = d.b_tail = None
-        d.w_head, d.w_tail = hp.packed.data_ptr(), tp.packed.data_ptr()
-        d.k_pad_head, d.m_pad, d.k_pad, d.m_pad_tail = hp.k_pad, hp.m_pad, tp.k_pad, tp.m_pad
+        keep = [w, bias]
         for k, blk in enumerate(blocks):
-            p1 = blk.conv1.bwd() if backward else blk.conv1.fwd()
-            p2 = blk.conv2.bwd() if backward else blk.conv2.fwd()
-            d.w1[k], d.w2[k] = p1.packed.data_ptr(), p2.packed.data_ptr()
-            d.b1[k] = None if (backward or p1.bias is None) else p1.bias.data_ptr()
-            d.b2[k] = None if (backward or p2.bias is None) else p2.bias.data_ptr()
             mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
             d.mod[k] = None if mod is None else mod.data_ptr()
             d.mod_sn = mod_sn
-            keep += [p1, p2, mod]
+            keep.append(mod)
         return d, keep
 
     def _net1d_forward(self, plan, src: Source, lo: int, hi: int, mod_all, per_image: bool, out: Tensor, save: bool):

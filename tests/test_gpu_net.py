@@ -539,13 +539,14 @@ def test_fused_1d_block_equals_per_layer_path_and_oracle(dev, monkeypatch, chann
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('channels,hidden,blocks,length,batch,padding,act,layout', [
-    (3, 64, 3, 64, 1, 'zeros', 'SiLU', 'BLC'),           # Lorenz-63 global net (experiments/lorenz/utils.py:26-42), config [0]
+    (3, 64, 3, 64, 1, 'zeros', 'SiLU', 'BLC'),           # Lorenz-63 global net (experiments/lorenz/utils.py:26-42), config [0]: 32-column tiles
     (40, 64, 3, 128, 64, 'zeros', 'SiLU', 'BLC'),        # Lorenz-96, config [1]: 64-column tiles, four per sequence
     (5, 48, 2, 37, 2, 'circular', 'SiLU', 'BCL'),        # circular wrap inside a tile, odd length
     (7, 24, 1, 200, 3, 'zeros', 'GELU', 'BLC'),          # many tiles per sequence, partial last tile
     (4, 64, 4, 130, 2, 'circular', 'ELU', 'BCL'),        # eight blocks (the kernel's maximum), halo 18
     (6, 10, 1, 5, 3, 'zeros', 'SiLU', 'BLC'),            # a sequence shorter than the halo
     (2, 64, 3, 20, 70, 'circular', 'SiLU', 'BLC'),       # a tile wraps a short circular sequence more than once
+    (8, 32, 3, 128, 20, 'zeros', 'SiLU', 'BLC'),         # 48-column tiles (the middle tile size)
 ])
 def test_whole_net_1d_kernel_equals_block_path_and_oracle(dev, monkeypatch, channels, hidden, blocks, length, batch, padding, act, layout):
     """The single-launch 1-D U-Net (csrc/net1d.hip: halo-recompute tiles, weights double-buffered in registers, strided
