@@ -5,7 +5,11 @@ of the final samples.
 The reference has no distributed code at all (its only parallelism is Slurm job arrays,
 experiments/lorenz/eval.py:42); this module is what a data-parallel launch of ``VPSDE.sample`` needs:
   * a deterministic batch partition,
-  * per-rank noise that is a slice of the single-process noise stream, so 1-GPU and N-GPU runs draw the same samples,
+  * per-rank noise that is a slice of the single-process noise stream, so 1-GPU and N-GPU runs draw the same noise, bit for
+    bit, and hence the same trajectories up to fp32 round-off.  (The samples themselves are bit-identical across world sizes
+    only while every shard takes the same kernel variants: tile sizes of the 1-D kernels, the LayerNorm kernel flavour and the
+    conv_small1d / staged-kernel choice depend on the LOCAL batch, and each variant sums in its own order.  The tests' shapes
+    stay on one side of every threshold; in general expect agreement to ~1e-6 relative, not equality.)
   * the final gather.
 ``DPSGaussianScore`` couples the batch through one scalar (score.py:339-342) and is therefore replicas-only.
 """
@@ -94,7 +98,8 @@ def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64,
 
     ``rank`` / ``world_size`` override the process group (and imply ``gather=False``): a single process can then compute
     any rank's shard, which is how the one-GPU test checks that the shards of a 2-rank job concatenate to the 1-rank job
-    bit for bit."""
+    (bit for bit at the tests' sizes; up to fp32 round-off when shard and whole batch select different kernel variants, see
+    the module docstring)."""
     if rank is None or world_size is None:
         rank, world_size = world()
     else:

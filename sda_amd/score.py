@@ -618,7 +618,7 @@ class GaussianScore(nn.Module):
             if (sc is not None and ax.dtype == torch.float32 and yo.dtype == torch.float32 and
                     (yo.shape == ax.shape or yo.shape == ax.shape[1:] or
                      (yo.dim() == ax.dim() and yo.shape[0] == 1 and yo.shape[1:] == ax.shape[1:]))):
-                # (the same path for every batch size: sharded and single-rank runs stay bit-identical)
+                # (the same path for every batch size: sharded and single-rank runs take the same guidance kernels)
                 cot = ops.gauss_cotangent(yo, ax, sc[0], sc[1], mu, sigma)
             else:
                 var = self.std ** 2 + self.gamma * (sigma / mu) ** 2

@@ -97,7 +97,7 @@ def test_guided_pc_steps_golden():
     sde.initial_noise = g['pc_x_init']
     sde.noise_source = lambda i, j: zs[i * corr + j]
     x = sde.sample((2,), steps=steps, corrections=corr, tau=tau)
-    assert_close(x, g['pc_x_final'], 1e-3)
+    assert_close(x, g['pc_x_final'], 1e-4)
 
 
 def test_unguided_sampling_golden():
