@@ -93,7 +93,11 @@ static int conv_plan(const sda_conv_desc* d, ConvGeom* g, int bp = SDA_CONV_BP, 
     g->bm = 32 * d->mt;
     if (d->cout_pad % g->bm || d->cout_pad < d->cout) return SDA_E_BADARG;
     if (d->cin_pad % SDA_CONV_CK || d->cin_pad < g->cin) return SDA_E_BADARG;
-    g->tw = pick_pow2_tile(d->wo, bp < 128 ? bp : 128);
+    // (a stride-2 tile reads (2 tw + 1) x (2 tr + 1) inputs: a 2 x 128 tile costs 5.0 input pixels per output and does not fit
+    //  the 1280-position stage, a 4 x 64 one 4.5 -- the 96 -> 192 level head at 256^2 went from the 128-pixel tile family, 0.53
+    //  of the matrix peak, to the 256-pixel one its 128^2 sibling already used, 0.7)
+    const int tw_cap = (d->stride_w > 1 && d->ho > 1) ? 64 : 128;
+    g->tw = pick_pow2_tile(d->wo, bp < tw_cap ? bp : tw_cap);
     g->tr = pick_pow2_tile(d->ho, bp / g->tw);
     g->tn = bp / (g->tw * g->tr);
     // tiny images: a tile of many images can need more halo positions than the loader covers -- take fewer images per tile
@@ -821,6 +825,18 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
             g2.nstage = d->cin_pad / 32;
             if (d->mt == 1) return g2.S <= 272 ? conv_launch_ws<1, 1, 272, 1, 3, 32>(d, g2, s) : conv_launch_ws<1, 1, 392, 1, 3, 32>(d, g2, s);
             return g2.S <= 272 ? conv_launch_ws<2, 1, 272, 1, 3, 32>(d, g2, s) : conv_launch_ws<2, 1, 392, 1, 3, 32>(d, g2, s);
+        }
+        // The parity classes of a stride-2 head's VJP (1 x 1 .. 2 x 2 taps): an 8-channel stage is only 1-4 taps of MFMAs
+        // (1.5-6 k cycles) against one HBM round trip of the stage behind it (~4-5 k cycles, the pipeline is one stage deep):
+        // they take 16-channel stages -- half the barriers, twice the multiply time per round trip.
+        static const bool no_ck16 = getenv("SDA_CONV_CK16") != nullptr && atoi(getenv("SDA_CONV_CK16")) == 0;
+        if (rc2 == SDA_OK && parity_shape && !no_ck16 && d->cin_pad % 16 == 0 && g2.tn * g2.tr * g2.tw == 256 && g2.S <= 520) {
+            g2.nstage = d->cin_pad / 16;
+            const bool s400 = g2.S <= 400;
+            if (d->kh == 1 && d->kw == 1) return s400 ? conv_launch_ws<3, 2, 400, 1, 1, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 1, 1, 16>(d, g2, s);
+            if (d->kh == 1 && d->kw == 2) return s400 ? conv_launch_ws<3, 2, 400, 1, 2, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 1, 2, 16>(d, g2, s);
+            if (d->kh == 2 && d->kw == 1) return s400 ? conv_launch_ws<3, 2, 400, 2, 1, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 1, 16>(d, g2, s);
+            return s400 ? conv_launch_ws<3, 2, 400, 2, 2, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 2, 16>(d, g2, s);
         }
         if (rc2 == SDA_OK) {
             if (d->kw == 3) rc2 = d->kh == 3 ? (d->mt <= 2 ? sda_conv_ws_k33_lo(d, g2, s) : sda_conv_ws_k33_hi(d, g2, s)) : sda_conv_ws_k13(d, g2, s);
