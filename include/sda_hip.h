@@ -120,7 +120,8 @@ typedef struct sda_conv_desc {
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
 /* which kernel family would serve the launch (pure planning, nothing is launched): 2 = one-wave-per-SIMD Winograd
- * (w_wino4), 1 = Winograd (w_wino), 3 = the single-round-trip small 1-D kernel, 0 = direct implicit GEMM; <0 error */
+ * (w_wino4), 1 = Winograd (w_wino), 3 = the single-round-trip small 1-D kernel, 4 = the 3 x 3 kernel for <= 16 output
+ * channels, 0 = direct implicit GEMM; <0 error */
 int sda_conv_igemm_path(const sda_conv_desc* d);
 /* bytes of dynamic LDS the launch would use (or <0 error), for planning / tests */
 int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);

@@ -794,6 +794,7 @@ struct WinoGeom;
 int sda_wino_try(const sda_conv_desc* d, hipStream_t stream);   // SDA_E_UNSUPPORTED -> use the direct kernel
 int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream);  // one-wave-per-SIMD Winograd (conv_wino4.hip)
 int sda_small1d_try(const sda_conv_desc* d, hipStream_t stream); // small 1-D layers: one round trip per launch (conv_small1d.hip)
+int sda_few_try(const sda_conv_desc* d, hipStream_t stream);     // 3 x 3, <= 16 output channels (conv_few.hip)
 
 extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -808,6 +809,10 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
     if (d && d->kh == 1 && d->kw == 3) {
         const int rcs = sda_small1d_try(d, s);
         if (rcs != SDA_E_UNSUPPORTED) return rcs;
+    }
+    if (d && d->kh == 3 && d->kw == 3 && d->cout <= 16) {
+        const int rcf = sda_few_try(d, s);
+        if (rcf != SDA_E_UNSUPPORTED) return rcf;
     }
     static const bool force_v1 = getenv("SDA_CONV_V1") != nullptr;
     const bool parity_shape = d && d->mt == 3 && d->kh >= 1 && d->kh <= 2 && d->kw >= 1 && d->kw <= 2;
@@ -859,16 +864,18 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
 }
 
 // which kernel family sda_conv_igemm would serve this launch with: 2 one-wave-per-SIMD Winograd, 1 Winograd, 3 the small 1-D
-// kernel (conv_small1d.hip), 0 the direct implicit-GEMM kernels
+// kernel (conv_small1d.hip), 4 the few-output-channel 3 x 3 kernel (conv_few.hip), 0 the direct implicit-GEMM kernels
 struct Wino4Geom;
 int sda_wino4_path(const sda_conv_desc* d);
 int sda_wino_path(const sda_conv_desc* d);
 int sda_small1d_path(const sda_conv_desc* d);
+int sda_few_path(const sda_conv_desc* d);
 extern "C" int sda_conv_igemm_path(const sda_conv_desc* d) {
     if (!d) return SDA_E_BADARG;
     if (d->w_wino4 && sda_wino4_path(d)) return 2;
     if (d->w_wino && sda_wino_path(d)) return 1;
     if (d->kh == 1 && d->kw == 3 && sda_small1d_path(d)) return 3;
+    if (d->kh == 3 && d->kw == 3 && d->cout <= 16 && sda_few_path(d)) return 4;
     return 0;
 }
 

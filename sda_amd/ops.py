@@ -147,7 +147,7 @@ def conv_igemm(desc: ConvDesc):
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 
-CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d')     # indexed by sda_conv_igemm_path
+CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d', 'few')     # indexed by sda_conv_igemm_path
 
 
 def conv_path(desc: ConvDesc) -> int:

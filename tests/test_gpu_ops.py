@@ -453,3 +453,57 @@ def test_winograd4_epilogue_operand_through_the_helpers(dev, shape):
     torch.cuda.synchronize()
     assert ops.conv_path(desc) == 2
     assert_close(buf.cpu(), conv + res, TOL, what='in-place residual')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w_,circular', [(3, 96, 10, 64, 64, True), (2, 16, 1, 8, 32, False), (5, 32, 16, 16, 96, False),
+                                                      (1, 48, 7, 40, 32, True), (130, 96, 10, 8, 32, True)])
+def test_few_output_channel_kernel(dev, n, cin, cout, h, w_, circular):
+    """conv_few.hip (3 x 3, <= 16 output channels: the U-Net tail sda/nn.py:166-176 and the head's backward-data form) against
+    torch: both paddings, bias, residual, the backward-data packing with dropped input channels, a strided source -- and the
+    shapes it must decline (ragged tile, loader fusion) still take the general kernels."""
+    from sda_amd import ops
+    from sda_amd._lib import ACT_IDS
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(n + cin + cout)
+    x = torch.randn(n, cin, h, w_)
+    wgt, b = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout)
+    ref = ref_conv(x, wgt, b, 1, circular)
+    res = torch.randn_like(ref)
+    pk = ops.PackedConv(wgt.to(dev), b.to(dev))
+    xd = x.to(dev)
+    out = torch.full((n, cout, h, w_), float('nan'), device=dev)
+    desc = launch_conv(pk, planar_source(xd), out, h, w_, circular=circular, bias=pk.bias)
+    torch.cuda.synchronize()
+    assert ops.conv_path(desc) == 4, 'expected the few-output-channel kernel'
+    assert_close(out.cpu(), ref, TOL, what='conv + bias')
+    rd = res.to(dev)
+    desc = launch_conv(pk, planar_source(xd), out, h, w_, circular=circular, bias=pk.bias, res=rd)
+    assert ops.conv_path(desc) == 4
+    assert_close(out.cpu(), ref + res, TOL, what='conv + bias + residual')
+    # backward-data form of a (cout + 1 context channel) -> cin head, the context gradient dropped (cin_keep)
+    wh = torch.randn(cin, cout + 1, 3, 3) / (9 * cin) ** 0.5
+    pkb = ops.PackedConv(wh.to(dev), None, transpose=True, cin_keep=cout)
+    xg = x.clone().requires_grad_(False)
+    inp = torch.zeros(n, cout + 1, h, w_, requires_grad=True)
+    yy = ref_conv(inp, wh, None, 1, circular)
+    gref, = torch.autograd.grad(yy, inp, x)
+    desc = launch_conv(pkb, planar_source(xd), out, h, w_, circular=circular)
+    assert ops.conv_path(desc) == 4
+    assert_close(out.cpu(), gref[:, :cout], TOL, what='backward-data, context channel dropped')
+    # a strided source (channel-last memory)
+    xcl = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    src = dict(x_ptr=xcl.data_ptr(), n=n, cx=cin, hs=h, ws=w_, x_sn_outer=xcl.stride(0), x_sc=1, x_sy=xcl.stride(1), x_sx=xcl.stride(2))
+    desc = launch_conv(pk, src, out, h, w_, circular=circular, bias=pk.bias)
+    assert ops.conv_path(desc) == 4
+    assert_close(out.cpu(), ref, TOL, what='strided source')
+    # declined shapes: a loader fusion, a ragged width
+    desc = launch_conv(pk, planar_source(xd), out, h, w_, circular=circular, bias=pk.bias, act_in=ACT_IDS['SiLU'])
+    assert ops.conv_path(desc) != 4
+    assert_close(out.cpu(), ref_conv(F.silu(x), wgt, b, 1, circular), TOL, what='declined: activation in the loader')
+    if w_ > 16:
+        xr = xd[..., :w_ - 16].contiguous()
+        outr = torch.empty(n, cout, h, w_ - 16, device=dev)
+        desc = launch_conv(pk, planar_source(xr), outr, h, w_ - 16, circular=circular, bias=pk.bias)
+        assert ops.conv_path(desc) != 4 or (w_ - 16) % 32 == 0
+        assert_close(outr.cpu(), ref_conv(x[..., :w_ - 16], wgt, b, 1, circular), TOL, what='ragged width')
