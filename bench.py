@@ -247,6 +247,10 @@ def roofline_report(prof, prof_steps, step_s, args, root):
                      'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / PEAK_MFMA_F32,
                      'avg_launch_ms': r['ms'] / max(1, r['launches']),
                      'avg_launch_gflop_algorithmic': r['flops'] / max(1, r['launches']) / 1e9}
+        if name in prof.family_bytes:
+            rd, wr = prof.family_bytes[name]
+            fam[name]['avg_launch_algorithmic_read_GB'] = rd / max(1, r['launches']) / 1e9
+            fam[name]['avg_launch_algorithmic_write_GB'] = wr / max(1, r['launches']) / 1e9
     for name, r in prof.mem_summary().items():
         gbs = r['bytes'] / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
         fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
@@ -265,11 +269,13 @@ def roofline_report(prof, prof_steps, step_s, args, root):
               'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)',
               'few': 'conv_few_kernel (3x3, <= 16 output channels, v_mfma_f32_16x16x4_f32)',
               'small1d': 'conv_small1d_kernel (single-round-trip 1-D convolution, v_mfma_f32_16x16x4_f32)',
+              'net1d_fwd': 'net1d_fwd_kernel (whole single-level 1-D U-Net in one launch, v_mfma_f32_16x16x4_f32)',
+              'net1d_bwd': 'net1d_bwd_kernel (its input VJP in one launch, v_mfma_f32_16x16x4_f32)',
               'block1d_fwd': 'block1d_fwd_kernel (fused 1-D residual block, v_mfma_f32_16x16x4_f32)',
               'block1d_bwd': 'block1d_bwd_kernel (fused 1-D residual block VJP, v_mfma_f32_16x16x4_f32)'}.get(dom, dom)
     d = conv.get(dom, {})
     latency = None
-    if dom in ('small1d', 'block1d_fwd', 'block1d_bwd'):
+    if dom in ('small1d', 'block1d_fwd', 'block1d_bwd', 'net1d_fwd', 'net1d_bwd'):
         # the 1-D nets are LATENCY-bound (a launch is a few hundred kFLOP per image): the model that prices them is launches per
         # step x time per launch against the floor of a dependent launch in a graph chain (1.7 us measured), not a
         # fraction of the matrix peak.  HIP-event brackets add their own few us per launch: `event_us_per_launch` is an upper
@@ -285,6 +291,11 @@ def roofline_report(prof, prof_steps, step_s, args, root):
             'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': d.get('mfma_util'), 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
+            'traffic_is': 'HBM/fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE '
+                          '(calibrated on known byte counts in the kernel\'s own access shapes, tools/fetch_calib.hip); compare with '
+                          'algorithmic_bytes_per_launch',
+            'algorithmic_bytes_per_launch': None if d.get('avg_launch_algorithmic_read_GB') is None else
+            1e9 * (d['avg_launch_algorithmic_read_GB'] + d['avg_launch_algorithmic_write_GB']),
             'direct_equivalent_tflops': d.get('algorithmic_tflops'), 'avg_launch_ms': d.get('avg_launch_ms'),
             'avg_launch_gflop_algorithmic': d.get('avg_launch_gflop_algorithmic'),
             'timed_with': f'HIP events around every launch of {prof_steps} '

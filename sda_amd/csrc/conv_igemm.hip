@@ -553,31 +553,35 @@ __global__ __launch_bounds__(512, ((CK == SDA_CONV_CK && NT == 1 && MT <= 3 && S
             if SDA_DBG(g, 4) { __syncthreads(); continue; }
             const float* bw = buf + khalf * BM + l31;
             const float* bin = buf + WSZ + khalf * SPAD;
-            // operands of one tap live in registers; the next tap's are fetched while this tap's MFMAs run
-            float av[2][CK / 2][MT], bv[2][CK / 2][NT];
-            auto fetch = [&](int tap, int slot_) {
+            // operands of one (tap, 8-channel chunk) live in registers; the next one's are fetched while this one's MFMAs run
+            // (stages deeper than 8 channels walk their chunks tap by tap: the register cost does not grow with CK)
+            constexpr int KC2 = CK >= 8 ? 4 : CK / 2, NCH = (CK / 2) / KC2, NSEQ = NTAPS * NCH;
+            float av[2][KC2][MT], bv[2][KC2][NT];
+            auto fetch = [&](int u, int slot_) {
+                const int tap = u % NTAPS, kc = u / NTAPS;
                 const int dy = tap / KW, dx = tap - dy * KW;
                 const int toff = dy * g.in_cols + dx;
 #pragma unroll
-                for (int k2 = 0; k2 < CK / 2; ++k2) {
+                for (int k2 = 0; k2 < KC2; ++k2) {
+                    const int kk = kc * KC2 + k2;
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) bv[slot_][k2][q] = bin[pixbase[q] + toff + 2 * k2 * SPAD];
+                    for (int q = 0; q < NT; ++q) bv[slot_][k2][q] = bin[pixbase[q] + toff + 2 * kk * SPAD];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) av[slot_][k2][m] = bw[(tap * CK + 2 * k2) * BM + m * 32];
+                    for (int m = 0; m < MT; ++m) av[slot_][k2][m] = bw[(tap * CK + 2 * kk) * BM + m * 32];
                 }
             };
             fetch(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < NTAPS; ++tap) {
-                if (tap + 1 < NTAPS) fetch(tap + 1, (tap + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);       // keep the next tap's ds_reads ahead of this tap's MFMAs
+            for (int u = 0; u < NSEQ; ++u) {
+                if (u + 1 < NSEQ) fetch(u + 1, (u + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);       // keep the next chunk's ds_reads ahead of this chunk's MFMAs
 #pragma unroll
-                for (int k2 = 0; k2 < CK / 2; ++k2)
+                for (int k2 = 0; k2 < KC2; ++k2)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int q = 0; q < NT; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap & 1][k2][m], bv[tap & 1][k2][q], acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u & 1][k2][m], bv[u & 1][k2][q], acc[m][q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                           // producers may now refill this buffer; next stage is ready
@@ -836,12 +840,21 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         // they take 16-channel stages -- half the barriers, twice the multiply time per round trip.
         static const bool no_ck16 = getenv("SDA_CONV_CK16") != nullptr && atoi(getenv("SDA_CONV_CK16")) == 0;
         if (rc2 == SDA_OK && parity_shape && !no_ck16 && d->cin_pad % 16 == 0 && g2.tn * g2.tr * g2.tw == 256 && g2.S <= 520) {
-            g2.nstage = d->cin_pad / 16;
             const bool s400 = g2.S <= 400;
+            if (d->kh == 2 && d->kw == 2) {
+                g2.nstage = d->cin_pad / 16;
+                return s400 ? conv_launch_ws<3, 2, 400, 2, 2, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 2, 16>(d, g2, s);
+            }
+            if (d->cin_pad % 32 == 0 && s400) {              // 1 and 2 taps: 32-channel stages (6-12 k cycles of MFMAs per round trip)
+                g2.nstage = d->cin_pad / 32;
+                if (d->kh == 1 && d->kw == 1) return conv_launch_ws<3, 2, 400, 1, 1, 32>(d, g2, s);
+                if (d->kh == 1 && d->kw == 2) return conv_launch_ws<3, 2, 400, 1, 2, 32>(d, g2, s);
+                return conv_launch_ws<3, 2, 400, 2, 1, 32>(d, g2, s);
+            }
+            g2.nstage = d->cin_pad / 16;
             if (d->kh == 1 && d->kw == 1) return s400 ? conv_launch_ws<3, 2, 400, 1, 1, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 1, 1, 16>(d, g2, s);
             if (d->kh == 1 && d->kw == 2) return s400 ? conv_launch_ws<3, 2, 400, 1, 2, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 1, 2, 16>(d, g2, s);
-            if (d->kh == 2 && d->kw == 1) return s400 ? conv_launch_ws<3, 2, 400, 2, 1, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 1, 16>(d, g2, s);
-            return s400 ? conv_launch_ws<3, 2, 400, 2, 2, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 2, 16>(d, g2, s);
+            return s400 ? conv_launch_ws<3, 2, 400, 2, 1, 16>(d, g2, s) : conv_launch_ws<3, 2, 520, 2, 1, 16>(d, g2, s);
         }
         if (rc2 == SDA_OK) {
             if (d->kw == 3) rc2 = d->kh == 3 ? (d->mt <= 2 ? sda_conv_ws_k33_lo(d, g2, s) : sda_conv_ws_k33_hi(d, g2, s)) : sda_conv_ws_k13(d, g2, s);

@@ -94,11 +94,24 @@ class ConvProfile:
 
     def __init__(self):
         self.records = []          # (start_event, stop_event, flops, family)
+        self.family_bytes = {}     # family -> [algorithmic bytes read, written] over all its launches
         self.mem_records = []      # (start_event, stop_event, bytes, kernel)
 
     def flops(self, d: ConvDesc) -> float:
         pixels = d.ho * d.wo / (d.zins_h * d.zins_w)
         return 2.0 * d.n * pixels * d.cout * (d.cx + d.cctx) * d.kh * d.kw
+
+    def alg_bytes(self, d: ConvDesc):
+        """ALGORITHMIC bytes of a convolution launch: every operand read once (source, weights, LayerNorm statistics, epilogue
+        operands), the output written once -- what the PMC traffic of profiles/*_traffic.json is compared against."""
+        cin = d.cx + d.cctx
+        rd = 4.0 * d.n * d.cx * d.hs * d.ws + 4.0 * d.cctx * d.hs * d.ws * (d.n if d.ctx_sn else 1)
+        rd += 4.0 * cin * d.cout * (16 if (d.w_wino4 or d.w_wino) and conv_path(d) in (1, 2) else d.kh * d.kw)
+        if d.ln_mean:
+            rd += 8.0 * d.n * d.hs * d.ws
+        out = 4.0 * d.n * d.cout * d.ho * d.wo
+        rd += out * ((1 if d.res else 0) + (1 if d.dact_z else 0))
+        return rd, out
 
     def bracket_mem(self, kernel: str, nbytes: float, launch):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,7 +155,12 @@ def conv_igemm(desc: ConvDesc):
         e0.record()
         _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
         e1.record()
-        prof.records.append((e0, e1, prof.flops(desc), CONV_FAMILIES[max(0, conv_path(desc))]))
+        fam = CONV_FAMILIES[max(0, conv_path(desc))]
+        prof.records.append((e0, e1, prof.flops(desc), fam))
+        rd, wr = prof.alg_bytes(desc)
+        b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
+        b[0] += rd
+        b[1] += wr
         return
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 

@@ -35,6 +35,6 @@ res = {'kernel': 'conv_wino4_kernel (dominant) ; all conv kernels in *_all field
        'FETCH_SIZE_KiB_per_launch_raw_all_conv': f, 'WRITE_SIZE_KiB_per_launch_raw_all_conv': w,
        'FETCH_SIZE_KiB_per_launch_raw': fw, 'WRITE_SIZE_KiB_per_launch_raw': ww,
        'hbm_bytes_per_launch': None if fw is None or ww is None else (2 * fw + ww) * 1024,
-       'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads)'}
+       'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reports 0.500 of the true bytes for 16 B/lane and 4 B/lane streams and for conv_wino4 halo rows alike (128-B lines), WRITE_SIZE 1.00-1.10 (calibration on known byte counts: tools/fetch_calib.hip, profiles/r03_w4_traffic.json)'}
 json.dump(res, open(f'{prof}/{tag}_traffic.json', 'w'), indent=1)
 print(res)
