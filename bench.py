@@ -267,6 +267,7 @@ def roofline_report(prof, prof_steps, step_s, args, root):
     kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
               'wino': 'conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)',
               'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)',
+              'par4': 'conv_par4_kernel (stride-2 backward-data, four parity classes in one launch, v_mfma_f32_32x32x2_f32)',
               'few': 'conv_few_kernel (3x3, <= 16 output channels, v_mfma_f32_16x16x4_f32)',
               'small1d': 'conv_small1d_kernel (single-round-trip 1-D convolution, v_mfma_f32_16x16x4_f32)',
               'net1d_fwd': 'net1d_fwd_kernel (whole single-level 1-D U-Net in one launch, v_mfma_f32_16x16x4_f32)',

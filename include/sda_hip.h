@@ -119,6 +119,12 @@ typedef struct sda_conv_desc {
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
+/* Backward-data of a stride-2 3 x 3 convolution (the gradient through the level heads, sda/nn.py:152-159) as ONE launch: the four
+ * output parity classes of the split formulation above together.  d = the class-(0,0) launch (kh = kw = 2, explicit_pad with pad 0,
+ * out / res = the class-(0,0) strided views of the planar [n][cout][2 ho][2 wo] gradient / skip tensors) with d->w = the four
+ * classes' sda_pack_conv_weight packings (transpose = 1) back to back in the order (0,0), (0,1), (1,0), (1,1): [9][cin_pad][cout_pad].
+ * SDA_E_UNSUPPORTED outside the kernel's range (cout % 96, ho % 8, wo % 16, loader fusions): run the four class launches. */
+int sda_conv_parity4(const sda_conv_desc* d, void* stream);
 /* which kernel family would serve the launch (pure planning, nothing is launched): 2 = one-wave-per-SIMD Winograd
  * (w_wino4), 1 = Winograd (w_wino), 3 = the single-round-trip small 1-D kernel, 4 = the 3 x 3 kernel for <= 16 output
  * channels, 0 = direct implicit GEMM; <0 error */

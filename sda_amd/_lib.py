@@ -106,6 +106,7 @@ SIGNATURES = {
     'sda_block1d_bwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_net1d_fwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
     'sda_net1d_bwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
+    'sda_conv_parity4': (c_int, [POINTER(ConvDesc), c_void_p]),
     'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),

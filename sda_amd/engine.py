@@ -149,11 +149,24 @@ class _ConvCache:
                 self._parity = out
         return self._parity or None
 
+    def bwd_parity4(self):
+        """The four parity packings back to back, [9 taps][k_pad][m_pad] in class order (0,0), (0,1), (1,0), (1,1), for the
+        one-launch kernel (csrc/conv_par4.hip); None when the layer is not a 2-D stride-(2, 2) 3 x 3 convolution."""
+        classes = self.bwd_parity()
+        if not classes or len(classes) != 4 or [(py, px) for py, px, _, _ in classes] != [(0, 0), (0, 1), (1, 0), (1, 1)]:
+            return None
+        if getattr(self, '_parity4', None) is None or self._parity4[0] is not classes:
+            pks = [pk for _, _, pk, _ in classes]
+            if any(pk.k_pad != pks[0].k_pad or pk.m_pad != pks[0].m_pad or pk.m_pad != pk.m_real for pk in pks):
+                return None
+            self._parity4 = (classes, torch.cat([pk.packed for pk in pks]))
+        return self._parity4[1]
+
 
 def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, circular: bool, stride=(1, 1), up=(1, 1),
                 zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
                 ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
-                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None):
+                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None, parity4_w: Optional[Tensor] = None):
     out_strides = (0, 0, 0, 0)
     if not out.is_contiguous():                      # an interleaved view of the real output (parity-split VJP)
         out_strides = tuple(out.stride())
@@ -174,6 +187,11 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr(),
                        w_wino4_ptr=None if getattr(pk, 'wino4', None) is None else pk.wino4.data_ptr(),
                        pad=pad, out_strides=out_strides)
+    if parity4_w is not None:
+        # all four parity classes of a stride-2 VJP in one launch: the class-(0,0) descriptor with the concatenated packing
+        d.w = parity4_w.data_ptr()
+        d.kh = d.kw = 2                                  # (the window all four classes share)
+        return d if ops.conv_parity4(d) else None
     ops.conv_igemm(d)
     return d
 
@@ -606,7 +624,17 @@ class UNetEngine:
                 g2 = torch.empty(n, L[lvl - 1].C, hu, wu, device=dev, dtype=torch.float32)
                 skip = g_skip.pop(lvl - 1)
                 classes = hd.bwd_parity() if PARITY_SPLIT and hu % hd.sh == 0 and wu % hd.sw == 0 else None
-                if classes is not None:
+                done = False
+                if classes is not None and ops.PARITY4:
+                    w4 = hd.bwd_parity4()
+                    if w4 is not None:
+                        pk0, pad0 = classes[0][2], classes[0][3]
+                        view = g2[:, :, 0::2, 0::2]
+                        done = launch_conv(pk0, planar_source(g), view, view.shape[2], view.shape[3], circular=hd.circular, pad=pad0,
+                                           res=skip[:, :, 0::2, 0::2], parity4_w=w4) is not None
+                if done:
+                    pass
+                elif classes is not None:
                     gsrc = planar_source(g)
                     for py, px, pk, pad in classes:
                         ys = slice(None) if py is None else slice(py, None, 2)

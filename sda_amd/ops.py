@@ -165,6 +165,30 @@ def conv_igemm(desc: ConvDesc):
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 
+PARITY4 = os.environ.get('SDA_CONV_PAR4', '1') != '0'
+
+
+def conv_parity4(desc: ConvDesc) -> bool:
+    """The four parity classes of a stride-2 3 x 3 convolution's backward-data in one launch (csrc/conv_par4.hip).  False: the
+    shape is outside the kernel's range (the caller runs the four class launches)."""
+    lib = _lib.load()
+    prof = conv_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.sda_conv_parity4(ctypes.byref(desc), _stream())
+    if rc == -2:                                         # SDA_E_UNSUPPORTED
+        return False
+    _lib.check(rc, 'sda_conv_parity4')
+    if prof is not None:
+        e1.record()
+        prof.records.append((e0, e1, 2.0 * desc.n * desc.ho * desc.wo * desc.cout * desc.cx * 9, 'par4'))
+        b = prof.family_bytes.setdefault('par4', [0.0, 0.0])
+        b[0] += 4.0 * desc.n * desc.cx * desc.hs * desc.ws + 4.0 * 9 * desc.cx * desc.cout + (16.0 * desc.n * desc.cout * desc.ho * desc.wo if desc.res else 0.0)
+        b[1] += 16.0 * desc.n * desc.cout * desc.ho * desc.wo
+    return True
+
+
 CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d', 'few')     # indexed by sda_conv_igemm_path
 
 

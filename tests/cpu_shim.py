@@ -176,6 +176,7 @@ def install(monkeypatch):
                          guided_combine=guided_combine, linear=linear, row_ln=row_ln, row_ln_bwd=row_ln_bwd).items():
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, 'WINOGRAD', False)      # the Winograd form has no host replay; the direct form is emulated
+    monkeypatch.setattr(ops, 'PARITY4', False)       # (the one-launch parity kernel is a device kernel: the four class launches are emulated)
     monkeypatch.setattr(ops, 'NET1D', False)         # (likewise the whole-net 1-D kernel)
     monkeypatch.setattr(ops, 'BLOCK1D', False)       # the fused 1-D block is a device kernel: the host replay takes the per-layer path
     monkeypatch.setattr(E.UNetEngine, "chunk_size", lambda self, n, hs, ws, save, device, fraction=None: n)

@@ -507,3 +507,46 @@ def test_few_output_channel_kernel(dev, n, cin, cout, h, w_, circular):
         desc = launch_conv(pk, planar_source(xr), outr, h, w_ - 16, circular=circular, bias=pk.bias)
         assert ops.conv_path(desc) != 4 or (w_ - 16) % 32 == 0
         assert_close(outr.cpu(), ref_conv(x[..., :w_ - 16], wgt, b, 1, circular), TOL, what='ragged width')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w_,circular', [(2, 96, 192, 32, 64, True), (3, 192, 384, 16, 32, True), (1, 96, 96, 16, 32, False),
+                                                      (5, 8, 96, 48, 32, True)])
+def test_stride2_vjp_one_launch_equals_four_classes_and_autograd(dev, monkeypatch, n, cin, cout, h, w_, circular):
+    """conv_par4.hip: the backward-data of a stride-2 3 x 3 convolution (U-Net level heads, sda/nn.py:152-159) with all four
+    output parity classes in one launch, against the four class launches and torch.autograd through the forward convolution;
+    skip-gradient add fused.  (cin = the head's input channels = channels of the produced gradient; cout = its output channels.)"""
+    import torch.nn as nn
+    from sda_amd import ops
+    from sda_amd.engine import _ConvCache, launch_conv, planar_source
+    torch.manual_seed(n + cin + h)
+    conv = nn.Conv2d(cin, cout, 3, stride=2, padding=1, padding_mode='circular' if circular else 'zeros')
+    x = torch.randn(n, cin, h, w_, requires_grad=True)
+    y = conv(x)
+    g = torch.randn_like(y)
+    gref, = torch.autograd.grad(y, x, g)
+    skip = torch.randn(n, cin, h, w_)
+    cc = _ConvCache(conv.to(dev))
+    classes = cc.bwd_parity()
+    gd, sd = g.to(dev), skip.to(dev)
+    # four launches
+    out4 = torch.full((n, cin, h, w_), float('nan'), device=dev)
+    for py, px, pk, pad in classes:
+        view = out4[:, :, py::2, px::2]
+        launch_conv(pk, planar_source(gd), view, view.shape[2], view.shape[3], circular=circular, pad=pad, res=sd[:, :, py::2, px::2])
+    assert_close(out4.cpu(), gref + skip, TOL, what='four class launches vs autograd')
+    # one launch
+    w4 = cc.bwd_parity4()
+    eligible = cin % 96 == 0 and (h // 2) % 8 == 0 and (w_ // 2) % 16 == 0
+    assert (w4 is not None) or not eligible
+    out1 = torch.full((n, cin, h, w_), float('nan'), device=dev)
+    v00 = out1[:, :, 0::2, 0::2]
+    done = w4 is not None and launch_conv(classes[0][2], planar_source(gd), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3],
+                                          res=sd[:, :, 0::2, 0::2], parity4_w=w4) is not None
+    assert done == eligible, 'conv_par4 eligibility'
+    if done:
+        assert_close(out1.cpu(), gref + skip, TOL, what='one launch vs autograd')
+        assert_close(out1.cpu(), out4.cpu(), 1e-5, what='one launch vs four launches')
+        out1.fill_(float('nan'))
+        launch_conv(classes[0][2], planar_source(gd), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3], parity4_w=w4)
+        assert_close(out1.cpu(), gref, TOL, what='one launch, no skip operand')

@@ -48,7 +48,14 @@ for lvl, (cin, cout, s_in) in enumerate(((96, 192, S), (192, 384, S // 2)), star
         taps = pkp.kh * pkp.kw
         report(f'head{lvl}^T parity ({py},{px}) {pkp.kh}x{pkp.kw} {cout}->{cin}', ms, 2.0 * n * so * so * cout * cin * taps)
         tot += ms
-    report(f'head{lvl}^T all four classes', tot, fl); total_ms += tot; total_fl += fl
+    report(f'head{lvl}^T all four classes (4 launches)', tot, fl)
+    w4 = cc.bwd_parity4()
+    cls = cc.bwd_parity()
+    v00, s00 = g2[:, :, 0::2, 0::2], skip[:, :, 0::2, 0::2]
+    if w4 is not None and launch_conv(cls[0][2], planar_source(g), v00, v00.shape[2], v00.shape[3], circular=True, pad=cls[0][3], res=s00, parity4_w=w4) is not None:
+        tot = timeit(lambda: launch_conv(cls[0][2], planar_source(g), v00, v00.shape[2], v00.shape[3], circular=True, pad=cls[0][3], res=s00, parity4_w=w4))
+        report(f'head{lvl}^T one launch (conv_par4)', tot, fl)
+    total_ms += tot; total_fl += fl
 # tail0: 96 -> 10 and head0^T: 96 -> 10 (VJP of the 11 -> 96 head, forcing-channel gradient dropped)
 conv = nn.Conv2d(96, 10, 3, padding=1, padding_mode='circular').to(dev)
 cc = _ConvCache(conv)
