@@ -52,6 +52,10 @@ def _worker(rank, ws, port, ret):
         full = torch.arange(batch * 6, dtype=torch.float32).reshape(batch, *event)
         gathered = P.all_gather_samples(full[lo:hi].clone(), batch)
         assert torch.equal(gathered, full)
+        # equal shares (every BASELINE configuration): the single all_gather_into_tensor path
+        full6 = torch.arange(6 * 6, dtype=torch.float32).reshape(6, *event)
+        lo6, hi6 = P.shard_range(6, rank, ws)
+        assert torch.equal(P.all_gather_samples(full6[lo6:hi6].clone(), 6), full6)
         assert P.world() == (rank, ws)
         # the whole sharded sampler (Python orchestration on the test-only CPU shim; kernels are covered by -m gpu):
         # guided, one Langevin correction per step; the gathered result equals the single-process run of the same job
