@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint3
 import torch  # noqa: F401  -- must be imported first: the library binds to the HIP runtime torch loaded
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libsda_hip.so')
+LIB_PATH = os.environ.get('SDA_HIP_LIB') or os.path.join(HERE, 'lib', 'libsda_hip.so')     # (SDA_HIP_LIB: a tooling build, tools/ only)
 
 ACT_IDS = {None: 0, 'none': 0, 'SiLU': 1, 'ReLU': 2, 'ELU': 3, 'GELU': 4, 'SELU': 5}
 

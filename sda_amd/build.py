@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIBDIR = os.path.join(HERE, 'lib')
+LIBDIR = os.environ.get('SDA_LIBDIR') or os.path.join(HERE, 'lib')      # (SDA_LIBDIR: tooling builds beside the product one)
 ARCH = 'gfx950'
 SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_small1d.hip', 'conv_few.hip', 'conv_par4.hip', 'block1d.hip', 'net1d.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'observe.hip', 'metrics.hip', 'noise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
