@@ -634,3 +634,30 @@ def test_fused_subsample_guidance_equals_general_path(dev, monkeypatch):
             m.setattr(Ob.Subsample, 'gaussian_guidance', lambda self, *a, **k: None)
             general = gs(x, t)
         assert_close(fused, general, 1e-6, what=f'fused guidance, slices {sl}')
+
+
+@pytest.mark.gpu
+def test_whole_net_1d_kernel_chunked_and_recomputed(dev, monkeypatch):
+    """The single-launch 1-D net under the engine's chunking: image offsets into the strided trajectory and the per-sample
+    modulation rows, kept and recomputed chunks (forward_all / backward_all), against the unchunked run."""
+    from sda_amd import engine as E
+    from sda_amd.experiments.lorenz import make_global_score
+    torch.manual_seed(21)
+    net = make_global_score(channels=5).to(dev)
+    x = torch.randn(11, 50, 5, device=dev)
+    t = torch.rand(11, device=dev)                          # per-sample times: one modulation row per image
+    g = torch.randn_like(x)
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        out = net(xg, t)
+        v, = torch.autograd.grad(out, xg, g)
+        return out.detach(), v
+
+    out, vjp = run()
+    for forced in (3, 8):
+        monkeypatch.setattr(E.UNetEngine, 'chunk_size',
+                            lambda self, n, hs, ws, save, device, fraction=None, forced=forced: min(n, forced))
+        out2, vjp2 = run()
+        assert torch.equal(out, out2), f'chunk {forced}: forward differs'
+        assert torch.equal(vjp, vjp2), f'chunk {forced}: VJP differs'
