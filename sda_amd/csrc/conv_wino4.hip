@@ -685,12 +685,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             constexpr int s = decltype(S)::value;
             if constexpr (s + 1 < 8) fetch(q, s + 1, (s + 1) & 1);
             else fetch(q + 1, 0, 0);
-            // MFMA order (m, k4, h): the two MFMAs of one accumulator are two apart, and the fragments of cout block m are
-            // needed only from the (4 m)-th MFMA on
+            // MFMA order (k4, m, h): the two MFMAs of one accumulator are SIX apart.  (Round 2 ran (m, k4, h) -- two apart, so that
+            // cout block m's fragments were needed late in the step; a dependent fp32 MFMA one instruction behind its producer
+            // loses a few cycles to the accumulator hand-over: 1.0-1.7 % per layer, tools/w4_quick_bench.py.  The operands of a
+            // step are all read during the previous one, so nothing is needed "late".)
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+            for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-                for (int k4 = 0; k4 < 2; ++k4)
+                for (int m = 0; m < 3; ++m)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int p = 2 * s + h;
