@@ -77,9 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv_few_kernel(const sda_conv_desc d,
 #pragma unroll
         for (int i = 0; i < CF_WLD; ++i) vw[i] = ws[woff[i]];
     };
-    auto commit = [&](int st, float* buf) {
-        // (channels beyond the real count are zero rows of the packed weights: whatever was loaded for them multiplies zero;
-        //  the loads themselves stay inside the tensor because cin_pad - cin < 8 channels are clamped below)
+    auto commit = [&](float* buf) {
+        // (every staged channel exists: the launcher requires cx == cin_pad)
 #pragma unroll
         for (int i = 0; i < CF_NLD; ++i)
             if (loff[i] >= 0) buf[loff[i]] = ((live >> i) & 1u) ? vin[i] : 0.f;
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_few_kernel(const sda_conv_desc d,
     // fragment f of this wave: row 2 wave + (f >> 1), columns 16 (f & 1) ..
     const int brow = (2 * wave) * CF_ROW + li + kq * CF_PLANE;
     load(0);
-    commit(0, smem);
+    commit(smem);
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         const float* buf = smem + (st & 1) * CF_BUF;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_few_kernel(const sda_conv_desc d,
 #pragma unroll
                 for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks][f], acc[f], 0, 0, 0);
         }
-        if (st + 1 < nstage) commit(st + 1, smem + ((st + 1) & 1) * CF_BUF);
+        if (st + 1 < nstage) commit(smem + ((st + 1) & 1) * CF_BUF);
         __syncthreads();
     }
     // ---- epilogue: D[m = 4 kq + r][n = li] -> out[n][co][oy][ox .. ox + 15], + bias (+ residual)

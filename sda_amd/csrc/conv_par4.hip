@@ -50,8 +50,7 @@ __global__ __launch_bounds__(512, 2) void conv_par4_kernel(const sda_conv_desc d
     const int nstage = d.cin_pad / P4_CK;
     if (wave >= 4) {
         // ================================================================ producers: global -> LDS, one stage ahead
-        const int ptid = tid - 256, plane_lane = lane;
-        (void)plane_lane;
+        const int ptid = tid - 256;
         const float* gimg = d.x + (int64_t)n * d.x_sn_outer;
         // per-thread load plan (the same for every stage): element e = ptid + 256 i -> (local channel, window position)
         unsigned goff[P4_NLD];
