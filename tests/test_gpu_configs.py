@@ -213,3 +213,48 @@ def test_conv_sweep_large_images():
         if msg:
             failures.append((cfg, msg))
     assert not failures, failures[:3]
+
+
+# ------------------------------------------------------------------------------------------------ configs[0], end to end
+@pytest.mark.parametrize('guided', [False, True])
+def test_config0_lorenz63_256_steps_end_to_end(dev, guided):
+    """BASELINE configs[0] as a whole: Lorenz-63 (3 states, L = 64, batch 1), the 1-D ScoreUNet of experiments/lorenz/utils.py:26-42,
+    256 predictor steps from the same initial draw -- free-running, nothing teacher-forced -- against the oracle's sampling loop
+    (sda/score.py:225-263), unguided and with Gaussian-likelihood guidance through the strided observation of
+    experiments/lorenz/eval.py:75.  The network is random-init inside the synthetic estimator of SURVEY 8d (a raw random-init
+    net overflows under guidance in the reference itself).  Bound: the reference arithmetic's own fp32-vs-fp64 deviation on
+    this 256-evaluation chain (SURVEY 8c tier 3), floor 1e-4."""
+    import bench
+    from sda_amd.experiments.lorenz import make_global_score
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    torch.manual_seed(30)
+    net = make_global_score(channels=3)
+    eps_net = oracle_eps_from_module(net, 'wrap1d')
+    net.to(dev)
+    steps, L, S = 256, 64, 3
+    x1 = torch.randn(1, L, S)
+    y = torch.randn(1, L // 8, 1)
+    A = lambda v: v[..., ::8, :1]
+    sched = O.Schedule()
+
+    def oracle(dtype):
+        def eps(xx, tt):
+            mu, sg = sched.mu(tt), sched.sigma(tt)
+            return xx * (sg / (mu * mu + sg * sg)) + 0.1 * eps_net(xx, tt, None if dtype == torch.float32 else dtype)
+        score = (lambda xx, tt: O.gaussian_score(eps, sched, y.to(dtype), A, 0.5, 3e-2, xx, tt)) if guided else eps
+        return O.sample(score, sched, x1.to(dtype), 2, steps, 0, 1.0)
+
+    ref32, ref64 = oracle(torch.float32), oracle(torch.float64)
+    assert torch.isfinite(ref64).all()
+    score = bench.SyntheticScore(net)
+    inner = VPSDE(score, shape=())
+    mod = GaussianScore(y, A=Ob.Subsample((slice(None, None, 8), slice(0, 1))), std=0.5, sde=inner, gamma=3e-2) if guided else score
+    sde = VPSDE(mod, shape=(L, S)).to(dev)
+    sde.initial_noise = x1
+    got = sde.sample((1,), steps=steps, corrections=0)
+    own = rel_err(ref32.double(), ref64)
+    err = rel_err(got.cpu().double(), ref64)
+    print(f'configs[0] {steps}-step sample, guided={guided}: HIP vs fp64 oracle {err:.2e}, fp32 oracle vs fp64 oracle {own:.2e}')
+    assert err <= max(TOL, 3 * own), (f'{steps}-step sample (guided={guided}): HIP path vs fp64 oracle {err:.2e}; the fp32 oracle itself is '
+                                      f'{own:.2e} from the fp64 oracle (bound: max(1e-4, 3x that))')
