@@ -87,13 +87,22 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
 
 
 def test_fused_1d_kernels_have_no_scratch(built):
-    for obj, pat in (('block1d.o', 'block1d_'), ('conv_small1d.o', 'conv_small1d_kernel')):
+    for obj, pat in (('block1d.o', 'block1d_'), ('conv_small1d.o', 'conv_small1d_kernel'), ('net1d.o', 'net1d_bwd_kernel'),
+                     ('conv_par4.o', 'conv_par4_kernel'), ('conv_few.o', 'conv_few_kernel')):
         md = G.kernel_metadata(os.path.join(built, obj))
         names = [n for n in md if pat in n]
         assert names, obj
         for n in names:
             k = md[n]
             assert k['vgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0, (n, k)
+    # the four-class accumulators of conv_par4 (192 registers) must leave room for two waves per SIMD; the multiply loop of a
+    # consumer wave issues no vector-memory instruction (a wave that does gets a vmcnt(0) in front of every LDS read)
+    md = G.kernel_metadata(os.path.join(built, 'conv_par4.o'))
+    (name, k), = [(n, v) for n, v in md.items() if 'conv_par4_kernel' in n]
+    assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, k
+    ins = G.disassemble(os.path.join(built, 'conv_par4.o'))[name]
+    assert sum(1 for i in ins if 'mfma' in i) == 108                       # 4 two-channel steps x 27 MFMAs, one stage body
+    assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) <= 16, 'vmcnt(0) crept into conv_par4'
 
 
 def test_product_library_has_no_ablation_switches(built):
