@@ -550,3 +550,38 @@ def test_stride2_vjp_one_launch_equals_four_classes_and_autograd(dev, monkeypatc
         out1.fill_(float('nan'))
         launch_conv(classes[0][2], planar_source(gd), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3], parity4_w=w4)
         assert_close(out1.cpu(), gref, TOL, what='one launch, no skip operand')
+
+
+@pytest.mark.gpu
+def test_stride2_vjp_one_launch_random_shapes(dev):
+    """A bounded random sweep of conv_par4 (every eligible shape class: 1-3 cout tiles of the produced gradient, K of 8-400 channels
+    incl. partial 8-channel alignment, macro grids of 1-6 x 1-4 tiles, both paddings, with / without the skip operand) against
+    torch.autograd through the forward stride-2 convolution."""
+    import random
+    import torch.nn as nn
+    from sda_amd.engine import _ConvCache, launch_conv, planar_source
+    rng = random.Random(7)
+    for case in range(14):
+        n = rng.choice([1, 2, 3])
+        cin = rng.choice([96, 96, 192, 288])                 # channels of the produced gradient (the head's input)
+        cout = rng.choice([8, 24, 40, 96, 136, 192, 400])    # channels of the incoming gradient (the contraction)
+        h, w_ = 16 * rng.randint(1, 4), 32 * rng.randint(1, 3)
+        circular = rng.random() < 0.5
+        torch.manual_seed(100 + case)
+        conv = nn.Conv2d(cin, cout, 3, stride=2, padding=1, padding_mode='circular' if circular else 'zeros')
+        x = torch.randn(n, cin, h, w_, requires_grad=True)
+        y = conv(x)
+        g = torch.randn_like(y)
+        gref, = torch.autograd.grad(y, x, g)
+        skip = torch.randn(n, cin, h, w_) if rng.random() < 0.6 else None
+        cc = _ConvCache(conv.to(dev))
+        classes, w4 = cc.bwd_parity(), cc.bwd_parity4()
+        assert w4 is not None
+        out = torch.full((n, cin, h, w_), float('nan'), device=dev)
+        v00 = out[:, :, 0::2, 0::2]
+        res = None if skip is None else skip.to(dev)[:, :, 0::2, 0::2]
+        d = launch_conv(classes[0][2], planar_source(g.to(dev)), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3],
+                        res=res, parity4_w=w4)
+        assert d is not None, (case, n, cin, cout, h, w_)
+        want = gref if skip is None else gref + skip
+        assert_close(out.cpu(), want, TOL, what=f'case {case}: n={n} {cout}->{cin} {h}x{w_} circular={circular} skip={skip is not None}')
