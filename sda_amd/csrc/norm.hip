@@ -7,6 +7,27 @@
 // The normalisation itself is never materialised in the network path: sda_conv_igemm's loader applies
 // (x + mod - mean) * rstd while it stages the halo tile.  sda_ln_apply exists for tests / unfused callers.
 #include "sda_common.hpp"
+
+// streaming accesses of the quad kernels: every byte is touched once.  On the 96-channel level (SPLIT = 8: 128-byte runs per
+// channel plane, 3 GB tensors) the non-temporal hint is worth 7 % on ln_stats (5.9 -> 6.3 TB/s) and 2-8 % on ln_bwd (5.3-5.6 ->
+// 5.8); on the 192 / 384-channel levels (SPLIT = 16: 64-byte runs) it costs 4-6 % -- measured with tools/ln_bench.py at 120
+// windows -- so it is a per-instantiation choice.
+typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ln_ld4(const float* p) {
+    if constexpr (NT) {
+        const ln_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ln_f32x4*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void ln_st4(float* p, float4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(ln_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ln_f32x4*>(p));
+    else *reinterpret_cast<float4*>(p) = v;
+}
+
 #include <stdlib.h>
 
 #define LN_THREADS 256
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_quad_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         const int k = sub + SPLIT * j;
-        v[j] = *reinterpret_cast<const float4*>(xp + (int64_t)(k < c ? k : 0) * hw);
+        v[j] = ln_ld4<SPLIT == 8>(xp + (int64_t)(k < c ? k : 0) * hw);
         if (k >= c) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (mp) {
@@ -400,7 +421,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
         const bool on = k < c;
         const int64_t off = base + (int64_t)(on ? k : 0) * hw;
         if (POOL == 1) {
-            g[j] = *reinterpret_cast<const float4*>(gh + off);
+            g[j] = ln_ld4<SPLIT == 8>(gh + off);
         } else {
             const int py = p / w, px = p - py * w;
             const float* gp = gh + (n * (int64_t)c + (on ? k : 0)) * (4 * (int64_t)hw) + (int64_t)(2 * py) * (2 * w) + 2 * px;
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
             g[j] = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y),
                                (a1.z + a1.w) + (b1.z + b1.w));
         }
-        hh[j] = *reinterpret_cast<const float4*>(x + off);
+        hh[j] = ln_ld4<SPLIT == 8>(x + off);
         if (!on) { g[j] = make_float4(0.f, 0.f, 0.f, 0.f); hh[j] = make_float4(m4.x, m4.y, m4.z, m4.w); }
     }
     if (mp) {
@@ -445,10 +466,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
             float4 v = make_float4(r4.x * (g[j].x - a.x - hh[j].x * b.x), r4.y * (g[j].y - a.y - hh[j].y * b.y),
                                    r4.z * (g[j].z - a.z - hh[j].z * b.z), r4.w * (g[j].w - a.w - hh[j].w * b.w));
             if (res) {
-                const float4 rr = *reinterpret_cast<const float4*>(res + off);
+                const float4 rr = ln_ld4<SPLIT == 8>(res + off);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
-            *reinterpret_cast<float4*>(gx + off) = v;
+            ln_st4<SPLIT == 8>(gx + off, v);
         }
     }
 }

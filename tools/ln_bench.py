@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, '/root/repo')
 from sda_amd import ops
 dev = torch.device('cuda:0')
-for c, hw_, n in ((96, 256, 16), (192, 128, 16), (384, 64, 16), (96, 64, 128)):
+for c, hw_, n in ((96, 256, int(os.environ.get("LN_N", "16"))), (192, 128, int(os.environ.get("LN_N", "16"))), (384, 64, int(os.environ.get("LN_N", "16"))), (96, 64, 128)):
     h = w = hw_
     x = torch.randn(n, c, h, w, device=dev); gh = torch.randn_like(x); res = torch.randn_like(x)
     mod = torch.randn(1, c, device=dev)
