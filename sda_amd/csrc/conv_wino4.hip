@@ -803,7 +803,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + sbase), (short)0, plane_bytes, 0x00020000);
             };
             auto run = [&](auto DACT_, auto RES_) {
-                constexpr bool DACT = decltype(DACT_)::value, RES = decltype(RES_)::value;
+                // DACT_: 0 = none; 1 = SiLU' only (the EPI kernels: no run-time switch in the plane loop, so that the planes of a
+                // fragment are independent exp / rcp chains the scheduler interleaves -- and the other activations' erf / expm1
+                // expansions, 6 500 instructions, stay out of the hot kernels); 2 = any activation, switched at run time
+                constexpr int DACT_KIND = decltype(DACT_)::value;
+                constexpr bool DACT = DACT_KIND != 0, RES = decltype(RES_)::value;
                 const auto r_out = rsrc_of(d.out);
                 const auto r_z = rsrc_of(DACT ? d.dact_z : d.out);
                 const auto r_res = rsrc_of(RES ? d.res : d.out);
@@ -847,6 +851,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        // (two planes at a time: four independent chains; all four would spill the accumulators still live)
+                        if constexpr (DACT_KIND == 1) { if (r == 2) __builtin_amdgcn_sched_barrier(0); }
                         const int so = (16 * m + r) * hw_o * 4;                      // scalar byte offset of the cout plane
                         f32x2 y0 = {y00[r], y01[r]}, y1 = {y10[r], y11[r]};
                         f32x2 e0, e1;
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                                 q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo0, so, 0));
                                 q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo1, so, 0));
                             }
-                            if (d.act_d == SDA_ACT_SILU) {
+                            if (DACT_KIND == 1 || d.act_d == SDA_ACT_SILU) {
                                 y0 *= w4_dsilu2(q0);
                                 y1 *= w4_dsilu2(q1);
                             } else {
@@ -886,17 +892,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     }
                 }
             };
+            using K0 = std::integral_constant<int, 0>;
+            using K1 = std::integral_constant<int, 1>;
+            using K2 = std::integral_constant<int, 2>;
             if constexpr (EPM == 0) {
-                run(std::false_type{}, std::false_type{});
+                run(K0{}, std::false_type{});
             } else if constexpr (EPI) {                    // (exactly one of the two operands: the launch condition)
-                if (d.dact_z) run(std::true_type{}, std::false_type{});
-                else run(std::false_type{}, std::true_type{});
+                if (d.dact_z) run(K1{}, std::false_type{});            // (SiLU': the launch condition as well)
+                else run(K0{}, std::true_type{});
             } else if (d.dact_z) {
-                if (d.res) run(std::true_type{}, std::true_type{});
-                else run(std::true_type{}, std::false_type{});
+                if (d.res) run(K2{}, std::true_type{});
+                else run(K2{}, std::false_type{});
             } else {
-                if (d.res) run(std::false_type{}, std::true_type{});
-                else run(std::false_type{}, std::false_type{});
+                if (d.res) run(K0{}, std::true_type{});
+                else run(K0{}, std::false_type{});
             }
         }
         w4_advance(g, c0);
@@ -962,7 +971,8 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
     // the epilogue operand through the helpers (EPI): one operand, tiles of at least twelve stages (the six-stage load window
     // of a tile must open after the previous tile's operand has left the registers)
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12;
+    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12 &&
+                     (!d->dact_z || d->act_d == SDA_ACT_SILU);
     const int epm = epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
 #define W4_LAUNCH3(MOD, LN, SILU)                                                                                              \
     (epm == 1 ? wino4_launch_t<MOD, LN, SILU, 1, 0>(d, g, grid, stream)                                                        \
