@@ -241,7 +241,8 @@ def roofline_report(prof, prof_steps, step_s, args, root):
     fam = {}
     for name, r in s['families'].items():
         alg = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        issued = alg / 2.25 if name.startswith('wino') else alg
+        # (zero-position form of conv_wino4: 54 of the 96 multiplies of a Winograd stage are issued)
+        issued = alg / 4.0 if name == 'wino4zp' else alg / 2.25 if name.startswith('wino') else alg
         fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
                      'share_of_step': r['ms'] * 1e-3 / prof_steps / step_s,
                      'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / PEAK_MFMA_F32,
@@ -265,6 +266,7 @@ def roofline_report(prof, prof_steps, step_s, args, root):
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
             break
     kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
+              'wino4zp': 'conv_wino4_kernel, zero-position form (up-sampling tails and their VJP: 9 of 16 Winograd positions)',
               'wino': 'conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)',
               'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)',
               'par4': 'conv_par4_kernel (stride-2 backward-data, four parity classes in one launch, v_mfma_f32_32x32x2_f32)',

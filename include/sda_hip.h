@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 5
+#define SDA_ABI_VERSION 6
 
 enum {
     SDA_OK = 0,
@@ -116,6 +116,12 @@ typedef struct sda_conv_desc {
      * of 8 and its width of 16 (workgroup tile = 96 couts x 16 x 8 pixels of one image), and the loader fusions are one of
      * none / SiLU / LayerNorm / modulation + LayerNorm; otherwise w_wino / the direct kernel serve the launch. */
     const float* w_wino4;
+    /* optional output pooling (0 / 1 = off): out is [n][cout][ho / pool_h][wo / pool_w] and receives the SUM of each pool_h x pool_w
+     * cell of the convolution's ho x wo output -- the input VJP of `Upsample(nearest) -> conv` (the tails, sda/nn.py:161-169) in one
+     * launch, without the full-resolution gradient in between.  Served for (2, 2) by the w_wino4 kernel on plain launches (no loader
+     * fusion, no epilogue operand): 7 of the 16 Winograd positions have weight zero in the cell sum and are never multiplied.
+     * Anything else: SDA_E_UNSUPPORTED (run the plain launch and pool in the reader, sda_ln_bwd's pool arguments). */
+    int32_t pool_h, pool_w;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
@@ -127,7 +133,8 @@ int sda_conv_igemm(const sda_conv_desc* d, void* stream);
 int sda_conv_parity4(const sda_conv_desc* d, void* stream);
 /* which kernel family would serve the launch (pure planning, nothing is launched): 2 = one-wave-per-SIMD Winograd
  * (w_wino4), 1 = Winograd (w_wino), 3 = the single-round-trip small 1-D kernel, 4 = the 3 x 3 kernel for <= 16 output
- * channels, 0 = direct implicit GEMM; <0 error */
+ * channels, 5 = the w_wino4 kernel in its zero-position form (2 x 2 up-sampled source or pooled output: 54 of the 96 multiplies
+ * per stage), 0 = direct implicit GEMM; <0 error */
 int sda_conv_igemm_path(const sda_conv_desc* d);
 /* bytes of dynamic LDS the launch would use (or <0 error), for planning / tests */
 int64_t sda_conv_igemm_lds_bytes(const sda_conv_desc* d);

@@ -52,6 +52,7 @@ class ConvDesc(Structure):
         ('explicit_pad', c_int32), ('pad_h', c_int32), ('pad_w', c_int32),
         ('out_sn', c_int64), ('out_sc', c_int64), ('out_sy', c_int64), ('out_sx', c_int64),
         ('w_wino4', c_fp),
+        ('pool_h', ctypes.c_int32), ('pool_w', ctypes.c_int32),
     ]
 
 

@@ -806,6 +806,8 @@ extern "C" int sda_conv_igemm(const sda_conv_desc* d, void* stream) {
         const int rc4 = sda_wino4_try(d, s);
         if (rc4 != SDA_E_UNSUPPORTED) return rc4;
     }
+    // (pooled output exists in the w_wino4 kernel only: the caller runs the plain launch + a pooling reader instead)
+    if (d && (d->pool_h > 1 || d->pool_w > 1)) return SDA_E_UNSUPPORTED;
     if (d && d->w_wino) {
         const int rcw = sda_wino_try(d, s);
         if (rcw != SDA_E_UNSUPPORTED) return rcw;
@@ -885,7 +887,11 @@ int sda_small1d_path(const sda_conv_desc* d);
 int sda_few_path(const sda_conv_desc* d);
 extern "C" int sda_conv_igemm_path(const sda_conv_desc* d) {
     if (!d) return SDA_E_BADARG;
-    if (d->w_wino4 && sda_wino4_path(d)) return 2;
+    if (d->w_wino4) {
+        const int p4 = sda_wino4_path(d);
+        if (p4) return p4 == 2 ? 5 : 2;
+    }
+    if (d->pool_h > 1 || d->pool_w > 1) return SDA_E_UNSUPPORTED;
     if (d->w_wino && sda_wino_path(d)) return 1;
     if (d->kh == 1 && d->kw == 3 && sda_small1d_path(d)) return 3;
     if (d->kh == 3 && d->kw == 3 && d->cout <= 16 && sda_few_path(d)) return 4;

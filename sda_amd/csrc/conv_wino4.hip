@@ -84,6 +84,12 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || d->cout % W4_BM || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
     if ((d->ho & 7) || (d->wo & 15) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
+    // pooled output (2 x 2 cell sums at half resolution): plain launches without an epilogue operand only
+    if (d->pool_h > 1 || d->pool_w > 1) {
+        if (d->pool_h != 2 || d->pool_w != 2 || d->mod || d->ln_mean || d->act_in != SDA_ACT_NONE || d->res || d->dact_z || d->cctx ||
+            (reinterpret_cast<uintptr_t>(d->out) & 3))
+            return SDA_E_UNSUPPORTED;
+    }
     if (d->mod && d->mod_sn != 0) return SDA_E_UNSUPPORTED;
     if (d->act_in != SDA_ACT_NONE && d->act_in != SDA_ACT_SILU) return SDA_E_UNSUPPORTED;       // (other activations: conv_wino)
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return SDA_E_UNSUPPORTED;
@@ -208,7 +214,18 @@ __device__ __forceinline__ f32x2 w4_dsilu2(f32x2 z) {
 // EPM: how the epilogue operand travels.  0 = the launch has none (plain / modulation + LayerNorm launches: the epilogue is the
 //      inverse transform and the stores, nothing else is compiled in); 1 = through the helpers (EPI, above); 2 = consumer-side
 //      buffer loads (any operand combination; tiles shorter than twelve stages).
-template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0>
+template <int ZP>
+__host__ __device__ constexpr bool w4_dead(int p) { return ZP != 0 && ((p >> 2) == 2 || (p & 3) == 2); }
+
+// ZP:  "zero positions".  With B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] a 4 x 4 input patch whose rows 1 and 2 are EQUAL has a zero
+//      row 2 in B^T d B (columns alike), and with A^T = [1 1 1 0; 0 1 -1 -1] the SUM of a tile's 2 x 2 outputs is v^T M v with
+//      v = (1, 2, 0, -1): in both cases the seven positions (xi, nu) with xi == 2 or nu == 2 carry nothing -- 54 MFMAs per stage
+//      instead of 96, bit-identical results (the skipped products are exact zeros / have weight zero).
+//      1 = the source is nearest-upsampled by 2 x 2 (the tails: LayerNorm -> Upsample -> conv, sda/nn.py:161-169; output tiles
+//          start at even pixels, so patch rows / columns 1, 2 are the same source pixel);
+//      2 = the output is summed over its 2 x 2 cells (sda_conv_desc.pool_h / pool_w: the input VJP of such a tail, the VJP of
+//          the upsample fused into the epilogue): one value per (cout, tile), written at half resolution.
+template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
     constexpr bool EPI = EPM == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -669,6 +686,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     int ard = (3 * wm * 64 + lane) * 4;
     int brd = kq * W4_VKQ + (16 * wn + li) * 2;
     f32x4 acc[16][3];
+    constexpr bool ZPOS = ZP != 0;
+    if constexpr (ZPOS) {                                  // (never written: constants for the epilogue, no registers)
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (w4_dead<ZP>(p)) acc[p][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     W4_TRACE_DECL;
     __syncthreads();                                       // stage 0 is in buffer 0
     int q = 0;
@@ -696,7 +721,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         constexpr bool FIRST = decltype(FIRST_)::value;
         w4_static_for<0, 8>([&](auto S) {
             constexpr int s = decltype(S)::value;
-            if constexpr (s + 1 < 8) fetch(q, s + 1, (s + 1) & 1);
+            // ZP: steps 4 and 5 (positions 8 .. 11: xi == 2) do not exist, steps 1, 3, 7 run their second position only; the
+            // executed steps 0 1 2 3 6 7 still alternate between the two operand buffers
+            if constexpr (ZPOS && (s == 4 || s == 5)) return;
+            constexpr int sn = (ZPOS && s == 3) ? 6 : s + 1;
+            constexpr int nmfma = (w4_dead<ZP>(2 * s) ? 0 : 6) + (w4_dead<ZP>(2 * s + 1) ? 0 : 6);
+            if constexpr (sn < 8) fetch(q, sn, sn & 1);
             else fetch(q + 1, 0, 0);
             // MFMA order (k4, m, h): the two MFMAs of one accumulator are SIX apart.  (Round 2 ran (m, k4, h) -- two apart, so that
             // cout block m's fragments were needed late in the step; a dependent fp32 MFMA one instruction behind its producer
@@ -709,6 +739,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int p = 2 * s + h;
+                        if (w4_dead<ZP>(p)) continue;
                         f32x4 c;
                         if (FIRST && k4 == 0) c = (p == 5) ? binit[m] : f32x4{0.f, 0.f, 0.f, 0.f};
                         else c = acc[p][m];
@@ -720,6 +751,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if constexpr (s == 6) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            } else if constexpr (nmfma == 6) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -895,7 +936,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             using K0 = std::integral_constant<int, 0>;
             using K1 = std::integral_constant<int, 1>;
             using K2 = std::integral_constant<int, 2>;
-            if constexpr (EPM == 0) {
+            if constexpr (ZP == 2) {
+                // pooled output: the sum of the tile's 2 x 2 block = v^T M v, v = (1, 2, 0, -1) -- one value per (cout, tile) at
+                // half resolution: out[n][cout][ho / 2][wo / 2], tile (by, bx, t) -> pixel (4 by + (t >> 3), 8 bx + (t & 7)).
+                // (A bias seeded at position (1, 1) arrives with weight 4: once per summed pixel.)
+                const int wo_p = d.wo >> 1, hw_p = (d.ho >> 1) * wo_p;
+                const int lo_p = ((4 * kq_e) * hw_p + (4 * tt.by + (t >> 3)) * wo_p + 8 * tt.bx + (t & 7)) * 4;
+                const int64_t sbase_p = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 48 * wm) * hw_p;
+                const auto r_p = __builtin_amdgcn_make_buffer_rsrc(d.out + sbase_p, (short)0, 48 * hw_p * 4, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const f32x4 c0v = (acc[0][m] + 2.f * acc[4][m]) - acc[12][m];
+                    const f32x4 c1v = (acc[1][m] + 2.f * acc[5][m]) - acc[13][m];
+                    const f32x4 c3v = (acc[3][m] + 2.f * acc[7][m]) - acc[15][m];
+                    const f32x4 y = (c0v + 2.f * c1v) - c3v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float yr = y[r];             // (a copy: bit_cast of a vector-element lvalue reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yr), r_p, lo_p, (16 * m + r) * hw_p * 4, 0);
+                    }
+                }
+            } else if constexpr (EPM == 0) {
                 run(K0{}, std::false_type{});
             } else if constexpr (EPI) {                    // (exactly one of the two operands: the launch condition)
                 if (d.dact_z) run(K1{}, std::false_type{});            // (SiLU': the launch condition as well)
@@ -931,13 +992,13 @@ extern "C" int sda_w4_trace_read(double* out) {
 }
 #endif
 
-template <bool MOD, bool LN, bool SILU, int EPI, int VAR>
+template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
     static_assert(W4_LDS_BYTES <= 160 * 1024, "LDS");
     static bool attr_set[SDA_MAX_DEVICES];
-    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR>), W4_LDS_BYTES, attr_set);
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), W4_LDS_BYTES, attr_set);
     if (rc != SDA_OK) return rc;
-    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
+    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
     return sda_launch_status();
 }
 
@@ -948,6 +1009,23 @@ static int wino4_config(const sda_conv_desc* d) {
     const bool mod = d->mod != nullptr, ln = d->ln_mean != nullptr, silu = d->act_in == SDA_ACT_SILU;
     const int key = (mod ? 4 : 0) | (ln ? 2 : 0) | (silu ? 1 : 0);
     return (key == 0 || key == 1 || key == 2 || key == 6) ? key : -1;
+}
+
+static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
+    // the epilogue operand through the helpers (EPI, mode 1): one operand, tiles of at least twelve stages (the six-stage load
+    // window of a tile must open after the previous tile's operand has left the registers), SiLU' if it is an act' launch
+    static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
+    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12 &&
+                     (!d->dact_z || d->act_d == SDA_ACT_SILU);
+    return epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
+}
+
+// which zero-position kernel (ZP) serves the launch: 2 = pooled output, 1 = 2 x 2 up-sampled source (the reference tails'
+// configuration: LayerNorm loader + skip operand through the helpers), 0 = the full kernels
+static int wino4_zp(const sda_conv_desc* d, const Wino4Geom& g) {
+    static const bool zp_on = !(getenv("SDA_W4_ZP") && atoi(getenv("SDA_W4_ZP")) == 0);
+    if (d->pool_h > 1 || d->pool_w > 1) return 2;
+    return (zp_on && d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2 && wino4_epm(d, g) == 1) ? 1 : 0;
 }
 
 int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t stream) {
@@ -968,16 +1046,16 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
         g.sy = step % g.by_n;
         g.sn = step / g.by_n;
     }
-    // the epilogue operand through the helpers (EPI): one operand, tiles of at least twelve stages (the six-stage load window
-    // of a tile must open after the previous tile's operand has left the registers)
-    static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12 &&
-                     (!d->dact_z || d->act_d == SDA_ACT_SILU);
-    const int epm = epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
+    const int epm = wino4_epm(d, g);
 #define W4_LAUNCH3(MOD, LN, SILU)                                                                                              \
     (epm == 1 ? wino4_launch_t<MOD, LN, SILU, 1, 0>(d, g, grid, stream)                                                        \
               : epm == 2 ? wino4_launch_t<MOD, LN, SILU, 2, 0>(d, g, grid, stream)                                             \
                          : wino4_launch_t<MOD, LN, SILU, 0, 0>(d, g, grid, stream))
+    // zero-position kernels (ZP, see the kernel): the pooled-output launch, and the 2 x 2 up-sampled LayerNorm + skip launch of the
+    // reference tails; SDA_W4_ZP=0 runs the latter on the full kernels (A/B runs)
+    const int zp = wino4_zp(d, g);
+    if (zp == 2) return wino4_launch_t<false, false, false, 0, 0, 2>(d, g, grid, stream);      // (eligibility: the plan)
+    if (zp == 1) return wino4_launch_t<false, true, false, 1, 0, 1>(d, g, grid, stream);
     switch (wino4_config(d)) {
         case 0: {
 #ifdef SDA_W4_VARIANTS
@@ -1011,9 +1089,11 @@ static bool wino4_disabled() {
     return off;
 }
 
+// 0 = not served; 1 = the full kernels; 2 = a zero-position kernel (54 of 96 MFMAs per stage)
 int sda_wino4_path(const sda_conv_desc* d) {
     Wino4Geom g;
-    return !wino4_disabled() && sda_wino4_plan(d, &g) == SDA_OK;
+    if (wino4_disabled() || sda_wino4_plan(d, &g) != SDA_OK) return 0;
+    return wino4_zp(d, g) ? 2 : 1;
 }
 
 int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream) {

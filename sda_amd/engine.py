@@ -166,7 +166,10 @@ class _ConvCache:
 def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, circular: bool, stride=(1, 1), up=(1, 1),
                 zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
                 ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
-                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None, parity4_w: Optional[Tensor] = None):
+                ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None, parity4_w: Optional[Tensor] = None,
+                pool=(1, 1)):
+    """pool != (1, 1): `out` is the pooled tensor [n][cout][ho / pool_h][wo / pool_w] (cell sums; sda_conv_desc.pool_h / pool_w);
+    returns None when no kernel serves the pooled form (the caller runs the plain launch and pools in its reader)."""
     out_strides = (0, 0, 0, 0)
     if not out.is_contiguous():                      # an interleaved view of the real output (parity-split VJP)
         out_strides = tuple(out.stride())
@@ -186,7 +189,9 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        res_ptr=None if res is None else res.data_ptr(),
                        w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr(),
                        w_wino4_ptr=None if getattr(pk, 'wino4', None) is None else pk.wino4.data_ptr(),
-                       pad=pad, out_strides=out_strides)
+                       pad=pad, out_strides=out_strides, pool=pool)
+    if pool != (1, 1):
+        return d if ops.conv_pooled(d) else None
     if parity4_w is not None:
         # all four parity classes of a stride-2 VJP in one launch: the class-(0,0) descriptor with the concatenated packing
         d.w = parity4_w.data_ptr()
@@ -605,11 +610,23 @@ class UNetEngine:
                 if (uh, uw) not in ((2, 2), (1, 2)):
                     raise NotImplementedError('VJP through Upsample is implemented for scale factor 2')
                 tl = lev.tail
-                ghup = torch.empty(n, lev.C, hu, wu, device=dev, dtype=torch.float32)
-                launch_conv(tl.bwd(), planar_source(g), ghup, hu, wu, circular=tl.circular)
                 a, mean, rstd = saved['tails'][lvl]
+                # the VJP of Upsample -> conv: the transposed convolution at the fine resolution, summed over the up-sampling
+                # cells -- in ONE launch where the kernel can pool in its epilogue (2 x 2: 7 of the 16 Winograd positions drop out
+                # of the cell sum), else the fine-resolution gradient goes through memory and ln_bwd pools while reading it
+                pooled = None
+                if ops.POOLED and (uh, uw) == (2, 2) and hu == 2 * h and wu == 2 * w:
+                    pooled = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
+                    if launch_conv(tl.bwd(), planar_source(g), pooled, hu, wu, circular=tl.circular, pool=(2, 2)) is None:
+                        pooled = None
+                if pooled is None:
+                    ghup = torch.empty(n, lev.C, hu, wu, device=dev, dtype=torch.float32)
+                    launch_conv(tl.bwd(), planar_source(g), ghup, hu, wu, circular=tl.circular)
                 g = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
-                ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, (uh, uw), None, g)
+                if pooled is not None:
+                    ops.ln_bwd(pooled, a, h, w, None, 0, mean, rstd, self.unbiased, (1, 1), None, g)
+                else:
+                    ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, (uh, uw), None, g)
             for bi in reversed(range(len(lev.ascent))):
                 g = self._block_bwd(lev.ascent[bi], g, saved['blocks'][('a', lvl, bi)], mod_all, lo, per_image)
         for lvl in reversed(range(D)):

@@ -59,7 +59,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
                    stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
                    ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
                    act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None,
-                   w_wino4_ptr=None, pad=None, out_strides=(0, 0, 0, 0)) -> ConvDesc:
+                   w_wino4_ptr=None, pad=None, out_strides=(0, 0, 0, 0), pool=(1, 1)) -> ConvDesc:
     d = ConvDesc()
     d.x = x_ptr
     d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
@@ -83,6 +83,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     d.explicit_pad = 0 if pad is None else 1
     d.pad_h, d.pad_w = (0, 0) if pad is None else pad
     d.out_sn, d.out_sc, d.out_sy, d.out_sx = out_strides
+    d.pool_h, d.pool_w = pool
     return d
 
 
@@ -106,10 +107,10 @@ class ConvProfile:
         operands), the output written once -- what the PMC traffic of profiles/*_traffic.json is compared against."""
         cin = d.cx + d.cctx
         rd = 4.0 * d.n * d.cx * d.hs * d.ws + 4.0 * d.cctx * d.hs * d.ws * (d.n if d.ctx_sn else 1)
-        rd += 4.0 * cin * d.cout * (16 if (d.w_wino4 or d.w_wino) and conv_path(d) in (1, 2) else d.kh * d.kw)
+        rd += 4.0 * cin * d.cout * (16 if (d.w_wino4 or d.w_wino) and conv_path(d) in (1, 2, 5) else d.kh * d.kw)
         if d.ln_mean:
             rd += 8.0 * d.n * d.hs * d.ws
-        out = 4.0 * d.n * d.cout * d.ho * d.wo
+        out = 4.0 * d.n * d.cout * d.ho * d.wo / (max(1, d.pool_h) * max(1, d.pool_w))
         rd += out * ((1 if d.res else 0) + (1 if d.dact_z else 0))
         return rd, out
 
@@ -189,12 +190,25 @@ def conv_parity4(desc: ConvDesc) -> bool:
     return True
 
 
-CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d', 'few')     # indexed by sda_conv_igemm_path
+POOLED = os.environ.get('SDA_CONV_POOLED', '1') != '0'
+
+
+def conv_pooled(desc: ConvDesc) -> bool:
+    """A convolution whose output is summed over pool_h x pool_w cells (sda_conv_desc.pool_h / pool_w).  False: no kernel serves
+    the pooled form of this launch (the caller runs the plain launch and pools in its reader)."""
+    lib = _lib.load()
+    if lib.sda_conv_igemm_path(ctypes.byref(desc)) < 0:          # SDA_E_UNSUPPORTED: planning only, nothing launched
+        return False
+    conv_igemm(desc)
+    return True
+
+
+CONV_FAMILIES = ('direct', 'wino', 'wino4', 'small1d', 'few', 'wino4zp')     # indexed by sda_conv_igemm_path
 
 
 def conv_path(desc: ConvDesc) -> int:
-    """Kernel family that would serve the launch: 2 one-wave-per-SIMD Winograd, 1 Winograd, 3 small 1-D kernel, 0 direct
-    implicit GEMM."""
+    """Kernel family that would serve the launch: 2 one-wave-per-SIMD Winograd, 5 its zero-position form (2 x 2 up-sampled source or
+    pooled output), 1 Winograd, 3 small 1-D kernel, 4 few-output-channel kernel, 0 direct implicit GEMM."""
     return _lib.load().sda_conv_igemm_path(ctypes.byref(desc))
 
 

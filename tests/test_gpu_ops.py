@@ -585,3 +585,84 @@ def test_stride2_vjp_one_launch_random_shapes(dev):
         assert d is not None, (case, n, cin, cout, h, w_)
         want = gref if skip is None else gref + skip
         assert_close(out.cpu(), want, TOL, what=f'case {case}: n={n} {cout}->{cin} {h}x{w_} circular={circular} skip={skip is not None}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w_,circular', [(3, 96, 192, 32, 64, True), (2, 192, 384, 16, 32, False), (5, 96, 96, 8, 16, True),
+                                                      (1, 40, 96, 24, 48, False)])
+def test_pooled_output_is_the_upsample_vjp(dev, n, cin, cout, h, w_, circular):
+    """sda_conv_desc.pool_h / pool_w (conv_wino4's pooled epilogue): the input VJP of Upsample(nearest, 2) -> conv3x3 (the U-Net
+    tails, sda/nn.py:161-169) in one launch, against torch.autograd through the forward pair and against the two-step form (plain
+    launch at the fine resolution, then 2 x 2 cell sums).  (cin = channels of the incoming gradient = the tail's outputs; cout =
+    channels of the produced gradient = the tail's inputs; h, w_ = the FINE resolution.)"""
+    import torch.nn as nn
+    from sda_amd import ops
+    from sda_amd.engine import _ConvCache, launch_conv, planar_source
+    torch.manual_seed(n + cin + h)
+    conv = nn.Conv2d(cout, cin, 3, padding=1, padding_mode='circular' if circular else 'zeros')
+    a = torch.randn(n, cout, h // 2, w_ // 2, requires_grad=True)
+    y = conv(F.interpolate(a, scale_factor=2, mode='nearest'))
+    g = torch.randn_like(y)
+    gref, = torch.autograd.grad(y, a, g)
+    cc = _ConvCache(conv.to(dev))
+    gd = g.to(dev)
+    fine = torch.full((n, cout, h, w_), float('nan'), device=dev)
+    launch_conv(cc.bwd(), planar_source(gd), fine, h, w_, circular=circular)
+    two_step = 4 * F.avg_pool2d(fine, 2)
+    assert_close(two_step.cpu(), gref, TOL, what='plain launch + cell sums vs autograd')
+    pooled = torch.full((n, cout, h // 2, w_ // 2), float('nan'), device=dev)
+    d = launch_conv(cc.bwd(), planar_source(gd), pooled, h, w_, circular=circular, pool=(2, 2))
+    eligible = cout % 96 == 0 and h % 8 == 0 and w_ % 16 == 0
+    assert (d is not None) == eligible, 'pooled-output eligibility'
+    if d is not None:
+        assert ops.conv_path(d) == 5
+        assert_close(pooled.cpu(), gref, TOL, what='pooled launch vs autograd')
+        assert_close(pooled.cpu(), two_step.cpu(), 2e-6, what='pooled launch vs plain launch + cell sums')
+
+
+@pytest.mark.gpu
+def test_pooled_output_refused_with_fusions_or_other_factors(dev):
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    x = torch.randn(2, 96, 16, 32, device=dev)
+    pk = ops.PackedConv(torch.randn(96, 96, 3, 3, device=dev) * 0.05, None)
+    out = torch.empty(2, 96, 8, 16, device=dev)
+    assert launch_conv(pk, planar_source(x), out, 16, 32, circular=True, pool=(2, 2)) is not None
+    assert launch_conv(pk, planar_source(x), out, 16, 32, circular=True, pool=(2, 2), res=torch.zeros_like(out)) is None
+    assert launch_conv(pk, planar_source(x), out, 16, 32, circular=True, pool=(2, 2), act_in=1) is None
+    assert launch_conv(pk, planar_source(x), torch.empty(2, 96, 16, 16, device=dev), 16, 32, circular=True, pool=(1, 2)) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('circular', [False, True])
+def test_upsampled_tail_zero_position_kernel_is_bit_identical(dev, circular, tmp_path):
+    """The zero-position form of conv_wino4 on a 2 x 2 up-sampled source skips products that are exact zeros: same bits as the full
+    kernel (SDA_W4_ZP=0, read once per process -> a second process)."""
+    import os
+    import subprocess
+    import sys
+    script = f'''
+import torch, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from sda_amd import ops
+from sda_amd.engine import launch_conv, planar_source
+dev = torch.device('cuda:0')
+torch.manual_seed(5)
+x = (torch.randn(3, 192, 16, 24) * 2 + 0.3).to(dev)
+pk = ops.PackedConv((torch.randn(96, 192, 3, 3) * 0.03).to(dev), torch.randn(96).to(dev))
+skip = torch.randn(3, 96, 32, 48).to(dev)
+var, mean = torch.var_mean(x, dim=1, unbiased=True, keepdim=True)
+rstd = 1 / torch.sqrt(var + 1e-5)
+out = torch.empty(3, 96, 32, 48, device=dev)
+d = launch_conv(pk, planar_source(x), out, 32, 48, circular={circular}, up=(2, 2), ln=(mean.reshape(3, -1).contiguous(), rstd.reshape(3, -1).contiguous()),
+                res=skip, bias=pk.bias)
+torch.save((ops.conv_path(d), out.cpu()), sys.argv[1])
+'''
+    outs = []
+    for zp in ('1', '0'):
+        f = str(tmp_path / f'zp{zp}.pt')
+        env = dict(os.environ, SDA_W4_ZP=zp)
+        subprocess.run([sys.executable, '-c', script, f], check=True, env=env, timeout=600)
+        outs.append(torch.load(f))
+    assert outs[0][0] == 5 and outs[1][0] == 2, (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])

@@ -30,10 +30,10 @@ def built():
 
 
 def _w4_params(name):
-    m = re.search(r'conv_wino4_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)E', name)
+    m = re.search(r'conv_wino4_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
     assert m, name
-    mod, ln, silu, epm, var = (int(v) for v in m.groups())
-    return bool(mod), bool(ln), bool(silu), epm, var
+    mod, ln, silu, epm, var, zp = (int(v) for v in m.groups())
+    return bool(mod), bool(ln), bool(silu), epm, var, zp
 
 
 def test_conv_wino4_no_spills_and_exact_load_counts(built):
@@ -42,16 +42,18 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
     dis = G.disassemble(obj)
     kernels = [n for n in md if 'conv_wino4_kernel' in n]
     # the shipped variants: {plain, SiLU, LN} x {no operand, through the helpers, consumer loads} + mod+LN x {none, consumer}
-    assert len(kernels) == 11, kernels
+    # + the two zero-position kernels (up-sampled LN + skip launch of the tails, pooled-output launch of their VJP)
+    assert len(kernels) == 13, kernels
     seen = set()
     for name in kernels:
-        mod, ln, silu, epm, var = _w4_params(name)
+        mod, ln, silu, epm, var, zp = _w4_params(name)
         assert var == 0, f'tooling variant in the product library: {name}'
-        seen.add((mod, ln, silu, epm))
+        seen.add((mod, ln, silu, epm) if zp == 0 else (mod, ln, silu, epm, zp))
         k, ins = md[name], dis[name]
         h = G.histogram(ins)
         scratch_ops = sum(v for o, v in h.items() if o.startswith('scratch_'))
-        assert sum(v for o, v in h.items() if 'mfma' in o) == 192, name          # 8 steps x 12 MFMAs x (first | later stage)
+        # 8 steps x 12 MFMAs x (first | later stage); zero-position kernels: 9 of the 16 positions
+        assert sum(v for o, v in h.items() if 'mfma' in o) == (192 if zp == 0 else 108), name
         assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, (name, k)
         if epm in (0, 1):
             # the hot kernels (every launch of the reference nets): nothing spilled, no scratch segment at all
@@ -83,7 +85,8 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
     assert seen == {(False, False, False, 0), (False, False, False, 1), (False, False, False, 2),
                     (False, False, True, 0), (False, False, True, 1), (False, False, True, 2),
                     (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
-                    (True, True, False, 0), (True, True, False, 2)}
+                    (True, True, False, 0), (True, True, False, 2),
+                    (False, True, False, 1, 1), (False, False, False, 0, 2)}
 
 
 def test_fused_1d_kernels_have_no_scratch(built):

@@ -9,11 +9,16 @@ from sda_amd.engine import launch_conv, planar_source
 dev = torch.device('cuda:0')
 res = []
 for name, cin, cout, h, n, fz in (('plain96', 96, 96, 64, 896, {}), ('modLN96', 96, 96, 64, 896, dict(ln=True, mod=True)), ('silu+res96', 96, 96, 64, 896, dict(silu=True, res=True)),
-                                  ('dact96', 96, 96, 64, 896, dict(dact=True)), ('plain384', 384, 384, 16, 896, {})):
-    x = torch.randn(n, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
-    pk = ops.PackedConv(w, torch.randn(cout, device=dev)); out = torch.empty(n, cout, h, h, device=dev)
+                                  ('dact96', 96, 96, 64, 896, dict(dact=True)), ('plain384', 384, 384, 16, 896, {}),
+                                  ('uptail192', 192, 96, 64, 896, dict(ln=True, res=True, up=True)), ('pooled96', 96, 192, 64, 896, dict(pool=True))):
+    hs = h // 2 if fz.get('up') else h
+    x = torch.randn(n, cin, hs, hs, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    pk = ops.PackedConv(w, torch.randn(cout, device=dev))
+    out = torch.empty(n, cout, h // 2, h // 2, device=dev) if fz.get('pool') else torch.empty(n, cout, h, h, device=dev)
     kw = dict(circular=True, bias=pk.bias)
-    if fz.get('ln'): kw['ln'] = (torch.zeros(n * h * h, device=dev), torch.ones(n * h * h, device=dev))
+    if fz.get('ln'): kw['ln'] = (torch.zeros(n * hs * hs, device=dev), torch.ones(n * hs * hs, device=dev))
+    if fz.get('up'): kw['up'] = (2, 2)
+    if fz.get('pool'): kw['pool'] = (2, 2)
     if fz.get('mod'): kw['mod'] = torch.randn(1, cin, device=dev)
     if fz.get('silu'): kw['act_in'] = 1
     if fz.get('res'): kw['res'] = torch.randn_like(out)
