@@ -227,6 +227,7 @@ __host__ __device__ constexpr bool w4_dead(int p) { return ZP != 0 && ((p >> 2) 
 //          the upsample fused into the epilogue): one value per (cout, tile), written at half resolution.
 template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
+    constexpr bool ZPOS = ZP != 0;                         // 9 live Winograd positions of 16 (see ZP above)
     constexpr bool EPI = EPM == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             float* dst = vb + vwr;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
+                if (ZPOS && a == 2) continue;              // (positions 8 .. 11 are never read)
                 f32x2 o01, o23;
                 asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(ua[a]), "v"(ub[a]));
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o23) : "v"(ub[a]), "v"(ua[a]));
@@ -430,9 +432,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 12 KiB = 12 wave-wide dwordx4 (one per cout fragment and pair)
         f32x4 ureg[12];
+        // ZP: the pairs 4, 5 (positions 8 .. 11) are never multiplied -- the six live pairs are dealt out as 9 fragments per helper:
+        // one whole pair zp_full and three cout fragments (zp_mo ..) of the pair zp_half
+        const int zp_full = pw == 0 ? 0 : (pw == 1 ? 2 : (pw == 2 ? 3 : 7));
+        const int zp_half = pw < 2 ? 1 : 6, zp_mo = 3 * (pw & 1);
         auto u_load = [&](const W4Cur& t) {
-            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
             const int64_t pstride = (int64_t)g.mtiles * 1024;         // bytes between position pairs
+            if constexpr (ZPOS) {
+                const char* base = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8) * g.mtiles + 6 * t.ct) * 256);
+                const char* sp = base + zp_full * pstride;
+                const char* sq = sp + 3072;
+                const char* sh = base + zp_half * pstride + zp_mo * 1024;
+                w4_ld4<0>(ureg[0], sp, lane16);
+                w4_ld4<1024>(ureg[1], sp, lane16);
+                w4_ld4<2048>(ureg[2], sp, lane16);
+                w4_ld4<0>(ureg[3], sq, lane16);
+                w4_ld4<1024>(ureg[4], sq, lane16);
+                w4_ld4<2048>(ureg[5], sq, lane16);
+                w4_ld4<0>(ureg[6], sh, lane16);
+                w4_ld4<1024>(ureg[7], sh, lane16);
+                w4_ld4<2048>(ureg[8], sh, lane16);
+                return;
+            }
+            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const char* sp = src + pp * pstride;
@@ -451,6 +473,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                  "+v"(pfreg[1]) : "n"(N) : "memory");                                                                         \
     W4_PIN_EPI()
         auto u_store = [&](float* ub) {
+            if constexpr (ZPOS) {
+                float* df = ub + zp_full * W4_UPP + lane * 4;
+                float* dh = ub + zp_half * W4_UPP + zp_mo * 256 + lane * 4;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) *reinterpret_cast<f32x4*>(df + m * 256) = ureg[m];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(dh + m * 256) = ureg[6 + m];
+                return;
+            }
             float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp)
@@ -568,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         W4_TRACE_DECL;
         constexpr int NHL = 2 * W4_NSLOT + (LN ? 2 * W4_NSLOT : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
-        constexpr int NUL = 12, NPF = EPI ? 4 : 1;         // loads per U slab quarter / per prefetch (EPI: operand loads)
+        constexpr int NUL = ZPOS ? 9 : 12, NPF = EPI ? 4 : 1;   // loads per helper's share of the U slab / per prefetch (EPI: operand loads)
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;
@@ -686,7 +717,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     int ard = (3 * wm * 64 + lane) * 4;
     int brd = kq * W4_VKQ + (16 * wn + li) * 2;
     f32x4 acc[16][3];
-    constexpr bool ZPOS = ZP != 0;
     if constexpr (ZPOS) {                                  // (never written: constants for the epilogue, no registers)
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -1054,6 +1084,16 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
     // zero-position kernels (ZP, see the kernel): the pooled-output launch, and the 2 x 2 up-sampled LayerNorm + skip launch of the
     // reference tails; SDA_W4_ZP=0 runs the latter on the full kernels (A/B runs)
     const int zp = wino4_zp(d, g);
+#ifdef SDA_W4_VARIANTS
+    if (zp && getenv("SDA_W4_VAR") && atoi(getenv("SDA_W4_VAR")) == 11) {                      // phase tracing of the ZP kernels
+        static long long* tbuf = nullptr;
+        if (!tbuf && hipMalloc(&tbuf, 256 * 64 * sizeof(long long)) != hipSuccess) return SDA_E_BADARG;
+        (void)hipMemsetAsync(tbuf, 0, 256 * 64 * sizeof(long long), stream);
+        Wino4Geom gt = g; gt.trace = tbuf; w4_trace_buf = tbuf; w4_trace_grid = grid;
+        return zp == 2 ? wino4_launch_t<false, false, false, 0, 11, 2>(d, gt, grid, stream)
+                       : wino4_launch_t<false, true, false, 1, 11, 1>(d, gt, grid, stream);
+    }
+#endif
     if (zp == 2) return wino4_launch_t<false, false, false, 0, 0, 2>(d, g, grid, stream);      // (eligibility: the plan)
     if (zp == 1) return wino4_launch_t<false, true, false, 1, 0, 1>(d, g, grid, stream);
     switch (wino4_config(d)) {

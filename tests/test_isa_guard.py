@@ -65,7 +65,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
             assert k['vgpr_spill_count'] <= 2 and scratch_ops <= 4, (name, k, scratch_ops)
         # ---- the hand-counted waits.  Loads per halo set / U slab quarter / prefetch as in the kernel source:
         nhl = 6 + (6 if ln else 0) + (2 if mod else 0)
-        nul = 12
+        nul = 9 if zp else 12                            # zero-position kernels: the six live position pairs, 9 fragments per helper
         npf = 4 if epm == 1 else 1
         npf_text = 28 if epm == 1 else 2                # EPI: 6 window slots x 4 + 4 dummies; else: the two arms of one branch
         wait_u, wait_halo = nhl + npf, min(63, 2 * (nhl + npf + nul) + nul)
@@ -78,7 +78,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         assert len(body) == 8, (name, seq)
         for j in range(4):
             assert body[2 * j] == (wait_u, nhl + npf_text), (name, j, body)       # before W4_WAIT_U: prefetch + halo issue
-            assert body[2 * j + 1] == (wait_halo, nul), (name, j, body)           # before W4_WAIT_HALO: the 12 U loads
+            assert body[2 * j + 1] == (wait_halo, nul), (name, j, body)           # before W4_WAIT_HALO: the U loads
         assert seq[-1][0] == 0                                                    # final drain
         # no compiler-inserted full drain anywhere else
         assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) == 3, name

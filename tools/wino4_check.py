@@ -87,6 +87,9 @@ def run_case(n, cin, cout, h, w_, circular, mod, ln, silu, up, dact, res, bias, 
 def expect_path(c):
     """the second-generation kernel serves the four loader configurations of the reference U-Net; the first generation the rest"""
     key = (bool(c['mod']), bool(c['ln']), bool(c['silu']))
+    # (5 = its zero-position form: 2 x 2 up-sampled source with the LayerNorm loader and the skip operand through the helpers)
+    if key == (False, True, False) and c['up'] and c['res'] and not c['dact'] and c['cin'] >= 96 - 7 and os.environ.get('SDA_W4_ZP', '1') != '0':
+        return 5
     return 2 if key in ((False, False, False), (False, False, True), (False, True, False), (True, True, False)) else 1
 
 
@@ -264,13 +267,22 @@ def trace():
     for dbg in dbgs:
       os.environ['SDA_CONV_DEBUG'] = str(dbg)
       print(f'=== helper skips (debug bits: 16 U store, 32 transform, 64 patch reads, 128 raw commit) = {dbg}')
-      for name, cin, cout, h, n, epi in (('96->96 @64', 96, 96, 64, 896, ''), ('96->96 @64 +dact', 96, 96, 64, 896, 'dact'),
-                                         ('96->96 @64 +res', 96, 96, 64, 896, 'res'), ('384->384 @16', 384, 384, 16, 896, '')):
-        x = torch.randn(n, cin, h, h, device=dev)
+      cases = (('96->96 @64', 96, 96, 64, 896, ''), ('96->96 @64 +dact', 96, 96, 64, 896, 'dact'),
+               ('96->96 @64 +res', 96, 96, 64, 896, 'res'), ('384->384 @16', 384, 384, 16, 896, ''),
+               ('pooled 96->192 @64 (ZP 2)', 96, 192, 64, 896, 'pool'), ('up-sampled LN tail 192->96 @32->64 +res (ZP 1)', 192, 96, 64, 896, 'up'))
+      if os.environ.get('W4_TRACE_CASES'):
+          cases = [c for c in cases if any(k in c[0] for k in os.environ['W4_TRACE_CASES'].split(','))]
+      for name, cin, cout, h, n, epi in cases:
+        hs = h // 2 if epi == 'up' else h
+        x = torch.randn(n, cin, hs, hs, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         pk = ops.PackedConv(w, None)
-        out = torch.empty(n, cout, h, h, device=dev)
+        out = torch.empty(n, cout, h // 2, h // 2, device=dev) if epi == 'pool' else torch.empty(n, cout, h, h, device=dev)
         kw = dict(circular=True)
+        if epi == 'pool':
+            kw.update(pool=(2, 2))
+        if epi == 'up':
+            kw.update(up=(2, 2), ln=(torch.zeros(n * hs * hs, device=dev), torch.ones(n * hs * hs, device=dev)), res=torch.randn_like(out))
         if epi == 'dact':
             kw.update(dact_z=torch.randn_like(out), act_d=1)
         if epi == 'res':
