@@ -296,6 +296,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         }
         const int up_sh_h = d.up_h == 2 ? 1 : 0, up_sh_w = d.up_w == 2 ? 1 : 0;
         const bool circ = d.circular != 0;
+        // ZP == 1 (2 x 2 up-sampled source): the 10 x 18 halo is 6 x 10 SOURCE pixels -- one per lane (lanes 0 .. 59), loaded and
+        // normalised once (slot 0) and committed to the up to four halo cells it covers: 4 loads per stage and lane instead of 12
+        constexpr int NSL = ZP == 1 ? 1 : W4_NSLOT;
+        const int sj = lane / 10, si = lane - 10 * (lane / 10);
+        int lidx4[4];
+        {
+            const int r0 = 2 * sj - 1 < 0 ? 0 : 2 * sj - 1, r1 = 2 * sj > W4_HRW - 1 ? W4_HRW - 1 : 2 * sj;
+            const int q0 = 2 * si - 1 < 0 ? 0 : 2 * si - 1, q1 = 2 * si > W4_HC - 1 ? W4_HC - 1 : 2 * si;
+            const bool sv = lane < 60;
+            lidx4[0] = sv ? r0 * W4_HS + q0 : W4_HS - 1; lidx4[1] = sv ? r0 * W4_HS + q1 : W4_HS - 1;
+            lidx4[2] = sv ? r1 * W4_HS + q0 : W4_HS - 1; lidx4[3] = sv ? r1 * W4_HS + q1 : W4_HS - 1;
+        }
         // lane (t, e): tile t = lane & 31 = (ty, tx) = (t >> 3, t & 7), channel e = lane >> 5 of the wave's pair
         const int pe = lane >> 5;
         const int pbase = pe * W4_HPLANE + (2 * ((lane & 31) >> 3)) * W4_HS + 2 * (lane & 7);
@@ -312,6 +324,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             gimg = d.x + (int64_t)m_out * d.x_sn_outer + (int64_t)(m_img - m_out * d.n_inner) * d.x_sn_inner;
             if (d.cctx > 0) gctx = d.ctx + (int64_t)t.n * d.ctx_sn;
             glive = 0;
+            if constexpr (ZP == 1) {
+                const int sy0 = 4 * t.by - 1 + sj, sx0 = 8 * t.bx - 1 + si;          // source pixel of this lane
+                const bool inside = sy0 >= 0 && sy0 < d.hs && sx0 >= 0 && sx0 < d.ws;
+                const int syw = sy0 < 0 ? sy0 + d.hs : (sy0 >= d.hs ? sy0 - d.hs : sy0);
+                const int sxw = sx0 < 0 ? sx0 + d.ws : (sx0 >= d.ws ? sx0 - d.ws : sx0);
+                const bool ok = lane < 60 && (circ || inside);
+                const int sy = ok ? syw : 0, sx = ok ? sxw : 0;
+                goff[0] = (unsigned)(sy * (int)d.x_sy + sx * (int)d.x_sx) * 4u;
+                glive = ok ? 1u : 0u;
+                if constexpr (LN) gstat[0] = (unsigned)((t.n * d.hs + sy) * d.ws + sx) * 4u;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < W4_NSLOT; ++i) {
                 const int vy0 = 8 * t.by - 1 + hy[i], vx0 = 16 * t.bx - 1 + hx[i];
@@ -340,12 +364,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const char* xc = reinterpret_cast<const char*>(gimg + (int64_t)cce * d.x_sc);
                 if (cce >= d.cx) xc = reinterpret_cast<const char*>(gctx + (int64_t)(cce - d.cx) * (d.hs * d.ws));   // (wave uniform)
 #pragma unroll
-                for (int i = 0; i < W4_NSLOT; ++i) w4_ld1(h.v[ch][i], xc, goff[i]);
+                for (int i = 0; i < NSL; ++i) w4_ld1(h.v[ch][i], xc, goff[i]);
                 if constexpr (MOD) w4_ld1(h.mv[ch], reinterpret_cast<const char*>(d.mod + cce), 0u);
             }
             if constexpr (LN) {
 #pragma unroll
-                for (int i = 0; i < W4_NSLOT; ++i) {
+                for (int i = 0; i < NSL; ++i) {
                     w4_ld1(h.mean[i], reinterpret_cast<const char*>(d.ln_mean), gstat[i]);
                     w4_ld1(h.rstd[i], reinterpret_cast<const char*>(d.ln_rstd), gstat[i]);
                 }
@@ -378,6 +402,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             for (int ch = 0; ch < 2; ++ch) {
                 const int cc = W4_CK * t.st + 2 * pw + ch;
                 const bool real = cc < g.cin;              // wave uniform (false only in a partial last stage)
+                if constexpr (ZP == 1) {
+                    float v = h.v[ch][0];
+                    if constexpr (MOD) v += h.mv[ch];
+                    if constexpr (LN) v = (v - h.mean[0]) * h.rstd[0];
+                    if constexpr (SILU) v = sda_act(SDA_ACT_SILU, v);
+                    v = (real && (h.live & 1u)) ? v : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) priv[ch * W4_HPLANE + lidx4[k]] = v;
+                    continue;
+                }
                 float val[W4_NSLOT];
 #pragma unroll
                 for (int i = 0; i < W4_NSLOT; ++i) {
@@ -598,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if (new_tile) geometry(ci);
         };
         W4_TRACE_DECL;
-        constexpr int NHL = 2 * W4_NSLOT + (LN ? 2 * W4_NSLOT : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
+        constexpr int NHL = 2 * NSL + (LN ? 2 * NSL : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
         constexpr int NUL = ZPOS ? 9 : 12, NPF = EPI ? 4 : 1;   // loads per helper's share of the U slab / per prefetch (EPI: operand loads)
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
