@@ -229,3 +229,38 @@ def test_wide_image_and_5x5(emu):
     assert_close(run(emu, x, pack(emu, w), 2, 256, circular=True, bias=b), ref_conv(x, w, b, 1, True), 2e-6)
     x, w = torch.randn(2, 3, 16, 16), torch.randn(4, 3, 5, 5) * 0.1
     assert_close(run(emu, x, pack(emu, w), 16, 16, circular=True), ref_conv(x, w, None, 1, True), 2e-6)
+
+
+def test_winograd_zero_positions_of_upsampled_sources_and_pooled_outputs():
+    """The algebra conv_wino4's zero-position kernels (ZP, csrc/conv_wino4.hip) rest on, in float64 on the host:
+    F(2x2,3x3): Y = A^T [(G g G^T) . (B^T d B)] A.  (1) A 4 x 4 patch of a 2 x 2 nearest-upsampled image whose tile starts at an even
+    pixel has equal rows 1, 2 and equal columns 1, 2: row / column 2 of B^T d B vanish EXACTLY (d2 - d1), so 7 of the 16 products are
+    never needed.  (2) The sum of the tile's 2 x 2 outputs is v^T M v with v = (1, 2, 0, -1): the same 7 positions carry weight 0."""
+    torch.manual_seed(0)
+    Bt = torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    G = torch.tensor([[1., 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    At = torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    dead = [(xi, nu) for xi in range(4) for nu in range(4) if xi == 2 or nu == 2]
+    assert len(dead) == 7
+    # (1) up-sampled source, float32 data: exact zeros
+    src = torch.randn(3, 3, dtype=torch.float32)
+    up = src.repeat_interleave(2, 0).repeat_interleave(2, 1)             # 6 x 6; a tile at even pixel (2, 2) reads rows / cols 1 .. 4
+    d = up[1:5, 1:5]
+    assert torch.equal(d[1], d[2]) and torch.equal(d[:, 1], d[:, 2])
+    V = Bt.float() @ d @ Bt.float().T
+    for xi, nu in dead:
+        assert V[xi, nu].item() == 0.0
+    # (2) pooled output of an arbitrary patch / filter
+    dd, g = torch.randn(4, 4, dtype=torch.float64), torch.randn(3, 3, dtype=torch.float64)
+    M = (G @ g @ G.T) * (Bt @ dd @ Bt.T)
+    Y = At @ M @ At.T
+    ref = F.conv2d(dd[None, None], g[None, None])[0, 0]                   # the direct 2 x 2 outputs
+    assert torch.allclose(Y, ref, atol=1e-12)
+    v = At.sum(0)
+    assert v.tolist() == [1.0, 2.0, 0.0, -1.0]
+    assert abs((v @ M @ v - Y.sum()).item()) < 1e-12
+    Mz = M.clone()
+    for xi, nu in dead:
+        Mz[xi, nu] = float('nan')                                         # never read
+    live = sum(v[xi] * v[nu] * Mz[xi, nu] for xi in (0, 1, 3) for nu in (0, 1, 3))
+    assert abs((live - Y.sum()).item()) < 1e-12

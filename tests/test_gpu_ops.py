@@ -666,3 +666,41 @@ torch.save((ops.conv_path(d), out.cpu()), sys.argv[1])
         outs.append(torch.load(f))
     assert outs[0][0] == 5 and outs[1][0] == 2, (outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+def test_zero_position_kernels_random_shapes(dev):
+    """A bounded random sweep of conv_wino4's two zero-position launches (1-3 cout tiles, 12-50 K stages incl. partial 8-channel
+    alignment, macro grids of 1-4 x 1-3 tiles, both paddings): the up-sampled LayerNorm + skip tail against torch, and the pooled VJP
+    against torch.autograd through Upsample -> conv."""
+    import random
+    import torch.nn as nn
+    from sda_amd import ops
+    from sda_amd.engine import _ConvCache, launch_conv, planar_source
+    rng = random.Random(7)
+    for case in range(10):
+        n = rng.choice([1, 2, 5])
+        cin = rng.choice([96, 100, 192, 250, 384])
+        cout = 96 * rng.choice([1, 1, 2, 3])
+        h, w_ = 8 * rng.choice([1, 2, 3]), 16 * rng.choice([1, 2, 4])       # fine resolution
+        circular = rng.random() < 0.5
+        torch.manual_seed(case)
+        # ---- forward tail: LN -> up -> conv (+ skip)
+        x = torch.randn(n, cin, h // 2, w_ // 2) * 1.5 + 0.2
+        wt, b = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5), torch.randn(cout)
+        skip = torch.randn(n, cout, h, w_)
+        var, mean = torch.var_mean(x, dim=1, unbiased=True, keepdim=True)
+        rstd = 1 / torch.sqrt(var + 1e-5)
+        up = O.layer_norm(x, dim=1).repeat_interleave(2, -1).repeat_interleave(2, -2)
+        out = hip_conv(x, wt, b, h, w_, dev, circular=circular, up=(2, 2), ln=(mean.reshape(n, -1), rstd.reshape(n, -1)), res=skip)
+        assert_close(out, ref_conv(up, wt, b, 1, circular) + skip, TOL, what=f'case {case}: up-sampled tail')
+        # ---- its input VJP with the cell sums in the epilogue (produced channels = cout of the launch)
+        conv = nn.Conv2d(cout, cin, 3, padding=1, padding_mode='circular' if circular else 'zeros')
+        a = torch.randn(n, cout, h // 2, w_ // 2, requires_grad=True)
+        y = conv(F.interpolate(a, scale_factor=2, mode='nearest'))
+        g = torch.randn_like(y)
+        gref, = torch.autograd.grad(y, a, g)
+        pooled = torch.full((n, cout, h // 2, w_ // 2), float('nan'), device=dev)
+        d = launch_conv(_ConvCache(conv.to(dev)).bwd(), planar_source(g.to(dev)), pooled, h, w_, circular=circular, pool=(2, 2))
+        assert d is not None and ops.conv_path(d) == 5, f'case {case}: pooled launch not served'
+        assert_close(pooled.cpu(), gref, TOL, what=f'case {case}: pooled VJP')
