@@ -169,7 +169,8 @@ def one_case(rng, dev, idx, large=False):
     cfg['path'] = ops.conv_path(desc)
     # the second-generation Winograd kernel serves the four loader configurations of the reference U-Net
     w4_cfg = (use_mod, use_ln, act == 'SiLU') in ((False, False, False), (False, False, True), (False, True, False), (True, True, False))
-    if mode == 'wino4' and act in (None, 'SiLU') and w4_cfg and ops.WINOGRAD4 and ops.WINOGRAD and cfg['path'] != 2:
+    # (5 = its zero-position form)
+    if mode == 'wino4' and act in (None, 'SiLU') and w4_cfg and ops.WINOGRAD4 and ops.WINOGRAD and cfg['path'] not in (2, 5):
         return cfg, f'expected the second-generation Winograd kernel, got path {cfg["path"]}'
     torch.cuda.synchronize()
     got = out.cpu().double()
