@@ -178,5 +178,6 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, 'WINOGRAD', False)      # the Winograd form has no host replay; the direct form is emulated
     monkeypatch.setattr(ops, 'PARITY4', False)       # (the one-launch parity kernel is a device kernel: the four class launches are emulated)
     monkeypatch.setattr(ops, 'NET1D', False)         # (likewise the whole-net 1-D kernel)
+    monkeypatch.setattr(ops, 'POOLED', False)        # (and the pooled-output form of the tails' VJP: plain launch + pooling reader)
     monkeypatch.setattr(ops, 'BLOCK1D', False)       # the fused 1-D block is a device kernel: the host replay takes the per-layer path
     monkeypatch.setattr(E.UNetEngine, "chunk_size", lambda self, n, hs, ws, save, device, fraction=None: n)
