@@ -3,7 +3,7 @@
 #   weak:   every rank owns a configuration shard (16 trajectories of 64x2x256x256); N = 8 is BASELINE configs[3] itself
 #   strong: the configuration's global batch (128 trajectories) is split over the ranks; N = 1 streams it in groups
 # usage: tools/run_scale.sh [outdir] [extra bench.py args...]      (no curve has been measured by the builder: 1-GPU boxes only)
-# NOTE strong scaling at N = 1 streams all 128 trajectories through one GPU: 62.3 s per step measured (8.1 x the shard step) -- budget
+# NOTE strong scaling at N = 1 streams all 128 trajectories through one GPU: 60.0 s per step measured (8.1 x the shard step) -- budget
 # ~5.5 min for its 2 steps + warm-up + capture + the eager profile step.
 set -u
 OUT=${1:-gpurun_out/scale}; shift || true
