@@ -3,12 +3,16 @@
 // general kernels put output channels on the 32-wide M side of v_mfma_f32_32x32x2_f32: 10 of 32 rows carry data (0.17 of the
 // matrix peak, 2 % of a configs[3] step for 0.5 % of its flops).  Here M is 16 wide (v_mfma_f32_16x16x4_f32), the launch is
 // plain enough to need no loader fusions, and nothing is specialised away from the memory system:
-//   * workgroup = 4 waves, tile = 8 rows x 32 columns of one image, wave w owns rows 2 w, 2 w + 1 (four 16-pixel fragments, 16
-//     accumulator registers); two workgroups per CU hide each other's global round trips (no producer / consumer split);
+//   * workgroup = 4 consumer + 4 producer waves (two workgroups per CU), tile = 8 rows x 32 columns of one image; consumer wave w owns
+//     rows 2 w, 2 w + 1 (four 16-pixel fragments, 16 accumulator registers).  (Round 3 first ran this with four do-everything waves:
+//     0.36 -- the vector-ALU half of a wave's stage, load addresses and the commit's selects, cannot issue while the sibling
+//     workgroup's wave on the same SIMD multiplies, so the two workgroups serialised; the split keeps the multiply streams free of it);
 //   * K runs in stages of 16 input channels: the 10 x 34 halo tile of each channel and the [9][16][16] weight slab go global ->
-//     registers (issued before the stage's multiply) -> LDS (after it); one barrier per stage, two LDS buffers;
-//   * A (weights, 16 couts x 4 channels) fragments are read once per stage and reused by the four pixel fragments; B comes from
-//     the halo tile, plane stride 368 floats (= 16 mod 32: the two channel rows a 32-lane group reads sit in disjoint banks).
+//     producer registers -> LDS one stage ahead; one barrier per stage, two LDS buffers;
+//   * A (weights, 16 couts x 4 channels): one 8-byte LDS read per tap and half stage (the slab is staged [tap][kq][cout][k-step]);
+//     B: every tile value a lane multiplies in the stage is read once (4 rows x 6 columns x 4 k-steps = 96 reads, not 9 taps x 16)
+//     and reused by the taps that meet it -- halo tile plane stride 368 floats (= 16 mod 32: the two channel rows a 32-lane group
+//     reads sit in disjoint banks).
 // Roofline: fp32 matrix pipe at 10/16 useful rows; HBM floor (input read once) is ~5x below.
 #include "sda_common.hpp"
 #include <stdlib.h>
@@ -21,100 +25,129 @@
 #define CF_PLANE 368                   // >= CF_HR * 36, = 16 mod 32
 #define CF_ROW 36
 #define CF_NPOS (CF_HR * CF_HC)        // 340 halo positions per channel
-#define CF_NLD ((CF_CK * CF_NPOS + 255) / 256)     // 22 input loads per thread and stage
-#define CF_WLD ((9 * CF_CK * 16 + 255) / 256)      // 9 weight loads per thread and stage
 #define CF_BUF (CF_CK * CF_PLANE + 9 * CF_CK * 16) // floats per stage buffer: tile + weights
 
 typedef float cf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float cf_f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void conv_few_kernel(const sda_conv_desc d, int tiles_x, int tiles_y) {
-    __shared__ float smem[2 * CF_BUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, li = lane & 15;
+__global__ __launch_bounds__(512, 4) void conv_few_kernel(const sda_conv_desc d, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * CF_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int t = blockIdx.x;
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int n = t / tiles_y;
     const int oy0 = by * CF_TR, ox0 = bx * CF_TW;
-    const int ng = n + d.x_n_off;
-    const float* ximg = d.x + (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
-    // ---- per-thread load plan (tile invariant across stages): element e = tid + 256 i -> (local channel, halo position)
-    unsigned goff[CF_NLD];             // element offset from the stage's first channel
-    int loff[CF_NLD];                  // LDS offset inside the stage's tile, -1 = no element
-    unsigned live = 0;                 // bit i: the position carries data (inside the image or circular)
-#pragma unroll
-    for (int i = 0; i < CF_NLD; ++i) {
-        const int e = tid + 256 * i;
-        const int ch = e / CF_NPOS, pos = e - ch * CF_NPOS;
-        const int hy = pos / CF_HC, hx = pos - hy * CF_HC;
-        int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-        bool ok = e < CF_CK * CF_NPOS;
-        if (d.circular) {
-            y = y < 0 ? y + d.hs : (y >= d.hs ? y - d.hs : y);
-            x = x < 0 ? x + d.ws : (x >= d.ws ? x - d.ws : x);
-        } else {
-            ok = ok && y >= 0 && y < d.hs && x >= 0 && x < d.ws;
-        }
-        const int yc = ok ? y : 0, xc = ok ? x : 0, cc = e < CF_CK * CF_NPOS ? ch : 0;
-        goff[i] = (unsigned)(cc * (int)d.x_sc + yc * (int)d.x_sy + xc * (int)d.x_sx);
-        loff[i] = e < CF_CK * CF_NPOS ? ch * CF_PLANE + hy * CF_ROW + hx : -1;
-        live |= ok ? (1u << i) : 0u;
-    }
-    // weights: slab element f = tid + 256 i -> (tap, channel, cout): packed layout [tap][cin_pad][cout_pad]
-    unsigned woff[CF_WLD];
-#pragma unroll
-    for (int i = 0; i < CF_WLD; ++i) {
-        const int f = tid + 256 * i;
-        const int tap = f / (CF_CK * 16), r = f - tap * (CF_CK * 16), ch = r >> 4, co = r & 15;
-        woff[i] = (unsigned)((tap * d.cin_pad + ch) * d.cout_pad + co);
-    }
-    float vin[CF_NLD], vw[CF_WLD];
     const int nstage = d.cin_pad / CF_CK;
-    auto load = [&](int st) {
-        const float* xs = ximg + (int64_t)(st * CF_CK) * d.x_sc;
-        const float* ws = d.w + (int64_t)(st * CF_CK) * d.cout_pad;
+    if (wave >= 4) {
+        // ================================================================ producers: global -> registers -> LDS, one stage ahead
+        const int ptid = tid - 256;
+        const int ng = n + d.x_n_off;
+        const float* ximg = d.x + (int64_t)(ng / d.n_inner) * d.x_sn_outer + (int64_t)(ng % d.n_inner) * d.x_sn_inner;
+        // per-thread load plan (tile invariant across stages): halo positions ptid and ptid + 256 (of 340) of EVERY channel of a stage
+        // -- the channel offset is a scalar, so a load needs no vector address arithmetic and the plan is four registers
+        unsigned goff[2];                  // element offset inside a channel plane
+        int loff[2];                       // LDS offset inside a channel's tile plane, -1 = no position
+        bool live[2];                      // the position carries data (inside the image or circular)
 #pragma unroll
-        for (int i = 0; i < CF_NLD; ++i) vin[i] = xs[goff[i]];
+        for (int j = 0; j < 2; ++j) {
+            const int pos = ptid + 256 * j;
+            const bool valid = pos < CF_NPOS;
+            const int hy = pos / CF_HC, hx = pos - hy * CF_HC;
+            int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
+            bool ok = valid;
+            if (d.circular) {
+                y = y < 0 ? y + d.hs : (y >= d.hs ? y - d.hs : y);
+                x = x < 0 ? x + d.ws : (x >= d.ws ? x - d.ws : x);
+            } else {
+                ok = ok && y >= 0 && y < d.hs && x >= 0 && x < d.ws;
+            }
+            goff[j] = (unsigned)((ok ? y : 0) * (int)d.x_sy + (ok ? x : 0) * (int)d.x_sx);
+            loff[j] = valid ? hy * CF_ROW + hx : -1;
+            live[j] = ok;
+        }
+        // weights: thread ptid = (channel, cout) of every tap of the packed layout [tap][cin_pad][cout_pad]; LDS slot
+        // [tap][kq = ch & 3][cout][ks = ch >> 2]: a consumer lane reads the k-steps of a tap as one value
+        const int wch = ptid >> 4, wco = ptid & 15;
+        const unsigned woff = (unsigned)(wch * d.cout_pad + wco);
+        const int wdst = CF_CK * CF_PLANE + ((wch & 3) * 16 + wco) * 4 + (wch >> 2);
+        const int64_t wtap = (int64_t)d.cin_pad * d.cout_pad;
+        auto produce = [&](int st, float* buf) {
+            // (every staged channel exists: the launcher requires cx == cin_pad)
+            const float* xs = ximg + (int64_t)(st * CF_CK) * d.x_sc;
+            const float* ws = d.w + (int64_t)(st * CF_CK) * d.cout_pad;
+            float vin[CF_CK][2], vw[9];
 #pragma unroll
-        for (int i = 0; i < CF_WLD; ++i) vw[i] = ws[woff[i]];
-    };
-    auto commit = [&](float* buf) {
-        // (every staged channel exists: the launcher requires cx == cin_pad)
+            for (int ch = 0; ch < CF_CK; ++ch) {
+                vin[ch][0] = (xs + (int64_t)ch * d.x_sc)[goff[0]];
+                vin[ch][1] = loff[1] >= 0 ? (xs + (int64_t)ch * d.x_sc)[goff[1]] : 0.f;
+            }
 #pragma unroll
-        for (int i = 0; i < CF_NLD; ++i)
-            if (loff[i] >= 0) buf[loff[i]] = ((live >> i) & 1u) ? vin[i] : 0.f;
+            for (int tap = 0; tap < 9; ++tap) vw[tap] = (ws + tap * wtap)[woff];
+            if (d.circular) {
+                // every position carries data: plain stores -- no vector-ALU instruction in a producer's stage (one would wait for a
+                // gap in the consumers' MFMA streams on its SIMD)
 #pragma unroll
-        for (int i = 0; i < CF_WLD; ++i) buf[CF_CK * CF_PLANE + tid + 256 * i] = vw[i];
-    };
+                for (int ch = 0; ch < CF_CK; ++ch) {
+                    buf[ch * CF_PLANE + loff[0]] = vin[ch][0];
+                    if (loff[1] >= 0) buf[ch * CF_PLANE + loff[1]] = vin[ch][1];
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < CF_CK; ++ch) {
+                    buf[ch * CF_PLANE + loff[0]] = live[0] ? vin[ch][0] : 0.f;
+                    if (loff[1] >= 0) buf[ch * CF_PLANE + loff[1]] = live[1] ? vin[ch][1] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) buf[wdst + tap * 256] = vw[tap];
+        };
+        produce(0, smem);
+        __syncthreads();
+        for (int st = 0; st < nstage; ++st) {
+            if (st + 1 < nstage) produce(st + 1, smem + ((st + 1) & 1) * CF_BUF);
+            __syncthreads();
+        }
+        return;
+    }
+    // ==================================================================== consumers: LDS reads + MFMA only in the loop
     cf_f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = cf_f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment f of this wave: row 2 wave + (f >> 1), columns 16 (f & 1) ..
     const int brow = (2 * wave) * CF_ROW + li + kq * CF_PLANE;
-    load(0);
-    commit(smem);
-    __syncthreads();
+    __syncthreads();                                       // stage 0 has landed
     for (int st = 0; st < nstage; ++st) {
         const float* buf = smem + (st & 1) * CF_BUF;
-        if (st + 1 < nstage) load(st + 1);
-        const float* wl = buf + CF_CK * CF_PLANE + kq * 16 + li;          // A[m = li][k = kq] of (tap, k-step): + (tap * 16 + 4 ks) * 16
+        const float* wl = buf + CF_CK * CF_PLANE + (kq * 16 + li) * 4;
+        // two halves of two k-steps each.  A[m = li][k = kq] of the half's k-steps for all nine taps: one 8-byte read per tap;
+        // B: every tile value this lane multiplies is read ONCE per half -- rows 0 .. 3 of the wave's window, columns li + dx and
+        // li + 16 + dx (dx = 0 .. 2) -- and reused by the (up to two) taps that meet it
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            float a[4], b[4][4];
+        for (int half = 0; half < 2; ++half) {
+            cf_f32x2 a[9];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[ks] = wl[(tap * CF_CK + 4 * ks) * 16];
+            for (int tap = 0; tap < 9; ++tap) a[tap] = *reinterpret_cast<const cf_f32x2*>(wl + tap * 256 + 2 * half);
+            float bb[2][4][6];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    b[ks][f] = buf[brow + 4 * ks * CF_PLANE + ((f >> 1) + dy) * CF_ROW + 16 * (f & 1) + dx];
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                    for (int c = 0; c < 6; ++c)
+                        bb[k2][r][c] = buf[brow + 4 * (2 * half + k2) * CF_PLANE + r * CF_ROW + 16 * (c / 3) + (c % 3)];
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks][f], acc[f], 0, 0, 0);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][k2], bb[k2][(f >> 1) + dy][3 * (f & 1) + dx], acc[f], 0, 0, 0);
+            }
         }
-        if (st + 1 < nstage) commit(smem + ((st + 1) & 1) * CF_BUF);
-        __syncthreads();
+        __syncthreads();                                   // the producers may refill this buffer; the next stage is ready
     }
     // ---- epilogue: D[m = 4 kq + r][n = li] -> out[n][co][oy][ox .. ox + 15], + bias (+ residual)
     const int64_t hw = (int64_t)d.ho * d.wo;
@@ -162,6 +195,6 @@ int sda_few_path(const sda_conv_desc* d) { return few_ok(d) ? 1 : 0; }
 int sda_few_try(const sda_conv_desc* d, hipStream_t stream) {
     if (!few_ok(d)) return SDA_E_UNSUPPORTED;
     const int tx = d->wo / CF_TW, ty = d->ho / CF_TR;
-    hipLaunchKernelGGL(conv_few_kernel, dim3((unsigned)((int64_t)d->n * tx * ty)), dim3(256), 0, stream, *d, tx, ty);
+    hipLaunchKernelGGL(conv_few_kernel, dim3((unsigned)((int64_t)d->n * tx * ty)), dim3(512), 0, stream, *d, tx, ty);
     return sda_launch_status();
 }
