@@ -60,7 +60,7 @@ WORKLOADS = {
 
 
 class SyntheticScore(torch.nn.Module):
-    """eps(x,t) = sigma(t) x / (mu^2 + sigma^2) + scale * net(x, t)   (SURVEY section 8d 'synthetic net').
+    """eps(x,t) = sigma(t) x / (mu^2 + sigma^2) + scale * net(x, t)   (SURVEY section 8d 'synthetic net'; mu^2 + sigma^2 = 1 + eta^2).
     mu / sigma are the VP 'cos' schedule of sda/score.py:195-210 (eta = 1e-3)."""
 
     def __init__(self, net, scale=0.1, eta=1e-3):
@@ -74,9 +74,10 @@ class SyntheticScore(torch.nn.Module):
         else:
             mu = torch.cos(math.acos(math.sqrt(self.eta)) * t) ** 2
             sigma = (1 - mu ** 2 + self.eta ** 2).sqrt()
-        # (the same expression in five elementwise launches instead of seven, three instead of five in its autograd VJP: on the
-        # latency-bound Lorenz workloads every scalar-tensor launch is ~1 % of a step)
-        k = sigma / torch.addcmul(sigma * sigma, mu, mu)
+        # (sigma^2 = 1 - mu^2 + eta^2 for every VP schedule (sda/score.py:209-210), so mu^2 + sigma^2 = 1 + eta^2: the coefficient is one
+        # scalar launch, the expression three elementwise launches instead of seven, two in its autograd VJP: on the latency-bound
+        # Lorenz workloads every scalar-tensor launch is ~1 % of a step)
+        k = sigma * (1.0 / (1.0 + self.eta ** 2))
         return torch.add(x * k, self.net(x, t, c), alpha=self.scale)
 
 
