@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- diffusion-steps/s of the posterior-sampling hot path on MI355X (contract: see the round prompt).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one iteration of VPSDE.sample's loop (sda/score.py:250-261): 1 predictor + C corrector score
@@ -309,6 +309,23 @@ def roofline_report(prof, prof_steps, step_s, args, root):
             'families': fam}
 
 
+def launch_plan(gpus, env, argv):
+    """argv of the torch.distributed.run launcher this process re-executes itself under, or None when it already IS a rank
+    (WORLD_SIZE set: launched by torchrun / the driver's `python -m torch.distributed.run ...` form) or a 1-GPU job.
+    The reference has no multi-process launcher (experiments/lorenz/eval.py:42: Slurm job arrays); one process per GPU over
+    RCCL is this project's data-parallel form."""
+    if gpus <= 1 or env.get('WORLD_SIZE') is not None:
+        return None
+    port = env.get('MASTER_PORT')
+    if port is None:
+        import socket
+        with socket.socket() as so:                  # a free port: concurrent jobs on one node must not collide
+            so.bind(('127.0.0.1', 0))
+            port = str(so.getsockname()[1])
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -330,6 +347,14 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if plan is not None:
+        # `python bench.py --gpus N` (the driver's verbatim call, no torchrun): this process becomes the launcher of N ranks
+        if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+            sys.exit(f'bench.py: --gpus {args.gpus} with backend nccl (RCCL) needs {args.gpus} visible GPUs, found '
+                     f'{torch.cuda.device_count()} (one rank per GPU; `--backend gloo` only exercises the launch path on a smaller box)')
+        os.execv(sys.executable, plan)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -343,7 +368,8 @@ def main():
             dist.init_process_group('nccl', device_id=device)                          # nccl == RCCL on ROCm
         else:
             dist.init_process_group(args.backend)
-    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.gpus != world:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (pass the same N to both)')
 
     from sda_amd import ops, parallel
     from sda_amd.score import GaussianScore, VPSDE
@@ -462,6 +488,8 @@ def main():
             'wallclock_per_1000_steps_s': elapsed / args.steps * 1000,
             'samples_finite': finite, 'final_allgather_ms': gather_ms,
         }
+        if os.environ.get('SDA_HIP_LIB'):            # a tooling build of the kernels was swapped in: say so in the line
+            out['kernel_library_override'] = os.environ['SDA_HIP_LIB']
         if prof is not None and prof_steps > 0:
             out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT)
         if world == 1 and not args.no_cpu_baseline:

@@ -163,6 +163,10 @@ def load():
         raise SdaHipError(
             f'{LIB_PATH} not found: the HIP extension is not built. Run `python -m sda_amd.build` '
             f'(or __graft_entry__.build()). sda_amd has no CPU fallback.')
+    if os.environ.get('SDA_HIP_LIB'):
+        import warnings
+        warnings.warn(f'sda_amd: kernel library overridden by SDA_HIP_LIB={LIB_PATH} (a tooling build; bench.py records it as '
+                      f'`kernel_library_override`)')
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -197,7 +197,10 @@ __device__ __forceinline__ void w4_ld4(f32x4& dst, const char* base, unsigned of
 // SiLU'(z) = s (1 + z (1 - s)), s = 1 / (1 + e), e = exp(-z); with 1 - s = e s: s (1 + z e s).  On register PAIRS: the four
 // multiplies / adds are packed instructions (v_pk_mul / v_pk_add / v_pk_fma: two values each), only exp and rcp are per
 // value -- the consumers' epilogue arithmetic is time the matrix pipe stands still (the x act'(z) layers lose ~12 % to it).
+// z is clamped at -80 first: below it e = exp(-z) overflows (z e -> -inf at z ~ -85, e = inf -> fma(-inf, 0, 1) = NaN at z ~ -89) where the
+// true derivative is ~ z exp(z) -> -0 (sda_dact and torch's silu_backward return ~ -1e-35 / -0 there); at the clamp the value is -1.4e-33.
 __device__ __forceinline__ f32x2 w4_dsilu2(f32x2 z) {
+    z = f32x2{__builtin_fmaxf(z[0], -80.f), __builtin_fmaxf(z[1], -80.f)};
     const f32x2 t = z * f32x2{-1.4426950408889634f, -1.4426950408889634f};
     const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
     const f32x2 dn = e + f32x2{1.f, 1.f};

@@ -37,6 +37,12 @@ def _lib_net1d_maxb() -> int:
     from ._lib import NET1D_MAXB
     return NET1D_MAXB
 
+
+def _net1d_span_ok(sc: int, sx: int, channels: int, length: int) -> bool:
+    """(channel, position) strides the whole-net 1-D kernel can address: non-negative, one image spans < 2^30 elements."""
+    return sc >= 0 and sx >= 0 and sc * channels + sx * length < 1 << 30
+
+
 # fraction of currently-unallocated HBM one chunk's activations may occupy
 CHUNK_HBM_FRACTION = 0.45
 # fraction of unallocated HBM that activations kept from the forward for the VJP may occupy
@@ -370,6 +376,10 @@ class UNetEngine:
             return None
         if 64 - 2 * (2 * len(blocks) + 2) < 4:
             return None
+        # the kernel forms offsets inside one image in 32 bits (net1d_check in csrc/net1d.hip: same limits, so that a view it would
+        # decline takes the per-block path here instead of raising from the launch)
+        if src.ws * 64 >= 1 << 30 or not _net1d_span_ok(src.sc, src.sx, src.cx, src.ws):
+            return None
         return dict(lev=lev, blocks=blocks)
 
     def _net1d_weights(self, plan, backward: bool, cin_keep: int = 0):
@@ -445,6 +455,8 @@ class UNetEngine:
     def _net1d_backward(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
         plan, a_s, z_s, m_s, r_s = saved['net1d']
         n, length = g_out.shape[0], src.ws
+        if not _net1d_span_ok(g_out.stride(1), g_out.stride(3), g_out.shape[1], length):
+            g_out = g_out.contiguous()
         d, keep = self._net1d_desc(plan, n, length, mod_all, lo, per_image, True, cin_keep=src.cx)
         d.x = g_out.data_ptr()
         d.x_sn, d.x_sc, d.x_sx = g_out.stride(0), g_out.stride(1), g_out.stride(3)
@@ -644,7 +656,8 @@ class UNetEngine:
                 done = False
                 if classes is not None and ops.PARITY4:
                     w4 = hd.bwd_parity4()
-                    if w4 is not None:
+                    # (the one-launch kernel addresses the skip gradient with the OUTPUT strides: same layout required)
+                    if w4 is not None and skip.is_contiguous() and skip.shape == g2.shape:
                         pk0, pad0 = classes[0][2], classes[0][3]
                         view = g2[:, :, 0::2, 0::2]
                         done = launch_conv(pk0, planar_source(g), view, view.shape[2], view.shape[3], circular=hd.circular, pad=pad0,

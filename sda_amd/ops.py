@@ -317,7 +317,8 @@ NET1D = os.environ.get('SDA_NET1D', '1') != '0'
 
 
 def net1d_launch(d: '_lib.Net1dDesc', backward: bool):
-    """One launch for a whole single-level 1-D U-Net (csrc/net1d.hip), forward or input VJP; see include/sda_hip.h."""
+    """One launch for a whole single-level 1-D U-Net (csrc/net1d.hip), forward or input VJP; see include/sda_hip.h.
+    (engine.net1d_plan mirrors the kernel's eligibility checks, so SDA_E_UNSUPPORTED here is a planning bug and raises.)"""
     lib = _lib.load()
     fn, name = (lib.sda_net1d_bwd, 'sda_net1d_bwd') if backward else (lib.sda_net1d_fwd, 'sda_net1d_fwd')
     prof = conv_profile

@@ -514,6 +514,22 @@ class GaussianScore(nn.Module):
         self.sde = sde
         self.detach = detach
         self._scalar_cache = None
+        self._prime_scalars()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._prime_scalars())
+
+    def _prime_scalars(self):
+        """Read std / gamma back NOW (construction, .to(), load_state_dict) so that the first guided evaluation -- possibly inside a
+        hipGraph capture, where a device read-back is illegal -- finds the cache filled."""
+        self._scalar_cache = None
+        try:
+            self._scalars
+        except Exception:  # noqa: BLE001 -- e.g. meta tensors; the lazy path reports a real problem at first use
+            self._scalar_cache = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._prime_scalars()
+        return out
 
     @property
     def _scalars(self):
@@ -524,9 +540,14 @@ class GaussianScore(nn.Module):
         std, gamma = self.std, self.gamma
         if std.numel() != 1 or gamma.numel() != 1:
             return None
-        key = (std.data_ptr(), std._version, std.device, gamma.data_ptr(), gamma._version, gamma.device)
+        ver = lambda b: 0 if b.is_inference() else b._version        # (inference-mode tensors have no version counter)
+        key = (std.data_ptr(), ver(std), std.device, gamma.data_ptr(), ver(gamma), gamma.device)
         hit = self._scalar_cache
         if hit is None or hit[0] != key:
+            if std.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise SdaHipError('GaussianScore.std / gamma changed (fill_ / copy_ / a new tensor) and are first read inside a hipGraph '
+                                  'capture, where the device read-back is illegal: evaluate the score once (or call '
+                                  '_prime_scalars()) before capturing')
             hit = (key, (float(std), float(gamma)))
             self._scalar_cache = hit
         return hit[1]

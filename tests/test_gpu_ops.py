@@ -704,3 +704,30 @@ def test_zero_position_kernels_random_shapes(dev):
         d = launch_conv(_ConvCache(conv.to(dev)).bwd(), planar_source(g.to(dev)), pooled, h, w_, circular=circular, pool=(2, 2))
         assert d is not None and ops.conv_path(d) == 5, f'case {case}: pooled launch not served'
         assert_close(pooled.cpu(), gref, TOL, what=f'case {case}: pooled VJP')
+
+
+@pytest.mark.parametrize('cin,hw', [(96, 32), (88, 16)])
+def test_wino4_silu_derivative_strongly_negative_preactivation(dev, cin, hw):
+    """the packed SiLU' of conv_wino4's epilogue (conv2^T x act'(z), backward of sda/nn.py:139) must stay
+    finite and ~0 for z << 0 (e = exp(-z) overflows from z ~ -85), as sda_dact / torch's silu_backward do -- both the helper-fed
+    (EPM = 1, >= 12 stages) and the consumer-side (EPM = 2, 11 stages) operand paths."""
+    from sda_amd import ops
+    from sda_amd._lib import ACT_IDS
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(cin)
+    n, cout = 2, 96
+    x = torch.randn(n, cin, hw, hw)
+    wgt = torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5
+    z = torch.randn(n, cout, hw, hw) * 3
+    flat = z.view(-1)
+    bad = torch.tensor([-85.0, -88.5, -89.5, -100.0, -1e4, -3e38, 85.0, 100.0, 1e4])
+    flat[torch.randperm(flat.numel())[:bad.numel() * 40]] = bad.repeat(40)
+    zz = z.clone().requires_grad_(True)
+    dz, = torch.autograd.grad(F.silu(zz).sum(), zz)
+    pk = ops.PackedConv(wgt.to(dev), None)
+    out = torch.full((n, cout, hw, hw), float('nan'), device=dev)
+    desc = launch_conv(pk, planar_source(x.to(dev)), out, hw, hw, circular=True, dact_z=z.to(dev), act_d=ACT_IDS['SiLU'])
+    torch.cuda.synchronize()
+    assert ops.conv_path(desc) == 2                      # conv_wino4
+    assert torch.isfinite(out).all(), 'SiLU\'(z) overflowed for a strongly negative pre-activation'
+    assert_close(out.cpu(), ref_conv(x, wgt, None, 1, True) * dz, TOL)

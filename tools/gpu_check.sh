@@ -9,6 +9,6 @@ for wl in kolmogorov64 qg128 lorenz96 lorenz63; do
   timeout 900 python bench.py --workload $wl --steps 20 --warmup 3 > gpurun_out/check/bench_$wl.json 2> /dev/null; tail -1 gpurun_out/check/bench_$wl.json | cut -c1-200
 done
 # multi-rank launch path on a 1-GPU box: two ranks over gloo, both on cuda:0 (the driver runs the RCCL curve on an 8-GPU node)
-timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29655 \
-  bench.py --gpus 2 --backend gloo --workload kolmogorov64 --steps 4 --warmup 1 > gpurun_out/check/bench_2rank_gloo_kolmogorov64.json 2> gpurun_out/check/bench_2rank_gloo.err
+timeout 900 python bench.py --gpus 2 --backend gloo --workload kolmogorov64 --steps 4 --warmup 1 \
+  > gpurun_out/check/bench_2rank_gloo_kolmogorov64.json 2> gpurun_out/check/bench_2rank_gloo.err    # (no torchrun: bench.py launches its ranks)
 tail -1 gpurun_out/check/bench_2rank_gloo_kolmogorov64.json | cut -c1-300

@@ -11,12 +11,8 @@ mkdir -p "$OUT"
 for mode in weak strong; do
   for n in 1 2 4 8; do
     steps=4; [ "$mode" = strong ] && [ "$n" -le 2 ] && steps=2
-    if [ "$n" = 1 ]; then
-      python bench.py --gpus 1 --steps $steps --warmup 1 --scaling $mode --no-cpu-baseline "$@" > "$OUT/${mode}_n$n.json" 2> "$OUT/${mode}_n$n.err"
-    else
-      python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) \
-        bench.py --gpus $n --steps $steps --warmup 1 --scaling $mode --no-cpu-baseline "$@" > "$OUT/${mode}_n$n.json" 2> "$OUT/${mode}_n$n.err"
-    fi
+    # the driver's verbatim form: bench.py starts its own N ranks (torch.distributed.run, one per GPU, RCCL) when N > 1
+    python bench.py --gpus $n --steps $steps --warmup 1 --scaling $mode --no-cpu-baseline "$@" > "$OUT/${mode}_n$n.json" 2> "$OUT/${mode}_n$n.err"
     tail -c 400 "$OUT/${mode}_n$n.json"; echo
   done
 done
