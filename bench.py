@@ -56,7 +56,12 @@ WORKLOADS = {
                      per_gpu=1, state=3),
     'lorenz96': dict(desc='BASELINE configs[1]: Lorenz-96 40-state, L=128, 1-D ScoreUNet (64,)/(3,), batch 64', kind='lorenz',
                      L=128, per_gpu=64, state=40),
+    # the reference's canonical caller (experiments/lorenz/eval.py:72-84), run as a whole: see run_lorenz_eval
+    'lorenz_eval': dict(desc='experiments/lorenz/eval.py:72-84: sde.sample((1024,), steps=256, corrections=C, tau=0.25) for C in '
+                             '(0, 1, 2, 4, 8, 16), event (65, 3), GaussianScore(A = x[..., ::step, :1], std, gamma=3e-2)',
+                        kind='lorenz_eval', L=65, per_gpu=1024, state=3),
 }
+LORENZ_EVAL_FREQ = {'lo': (8, 0.05), 'hi': (1, 0.25)}          # (step, std): experiments/lorenz/eval.py:50-53
 
 
 class SyntheticScore(torch.nn.Module):
@@ -261,7 +266,7 @@ def roofline_report(prof, prof_steps, step_s, args, root):
     conv = {k: v for k, v in fam.items() if 'issued_mfma_tflops' in v}
     dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
     traffic, tfile = None, None
-    for rnd in ('r03', 'r02'):             # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    for rnd in ('r04', 'r03', 'r02'):             # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
@@ -309,6 +314,121 @@ def roofline_report(prof, prof_steps, step_s, args, root):
             'families': fam}
 
 
+def run_lorenz_eval(args, device):
+    """The reference's canonical workload, whole (experiments/lorenz/eval.py:72-84): six posterior-sampling runs of 1024 trajectories
+    x 256 steps with C = 0, 1, 2, 4, 8, 16 Langevin corrections, tau = 0.25, event (65, 3), Gaussian guidance through
+    A = x[..., ::step, :1] with std / step = 0.05 / 8 ("lo") or 0.25 / 1 ("hi"), gamma = 3e-2, for the global (lorenz/utils.py:26-42)
+    or the local (:45-59) score network -- random-init inside the synthetic estimator (module docstring).  The reference budgets one
+    such six-run job (plus its ground-truth particle filter) at <= 1 h on one GPU (eval.py:42).  `value` = all 6 x 256 diffusion
+    steps / their wall-clock; every run is a full `VPSDE.sample` loop replayed from a captured hipGraph, initial draw on the host RNG
+    as the reference (score.py:243), corrector noise from the device RNG."""
+    from sda_amd import observe as Ob
+    from sda_amd.experiments.lorenz import make_global_score, make_local_score
+    from sda_amd.score import GaussianScore, VPSDE
+    step, std = LORENZ_EVAL_FREQ[args.lorenz_freq]
+    B, L, S, steps = args.per_gpu or 1024, 65, 3, 256
+    torch.manual_seed(0)
+    net = make_local_score() if args.lorenz_net == 'local' else make_global_score()
+    score = SyntheticScore(net)
+    inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)
+    y = torch.randn((L + step - 1) // step, 1, generator=torch.Generator().manual_seed(2))      # one observation for the batch (eval.py:47)
+    gs = GaussianScore(y, A=Ob.Subsample((slice(None, None, step), slice(0, 1))), std=std, sde=inner, gamma=3e-2)
+    sde = VPSDE(gs, shape=(L, S)).to(device)
+    # warm-up: weight packing, allocator pools, clocks
+    wu = sde.sampler((B,), steps=steps, corrections=1, tau=0.25)
+    for _ in range(max(args.warmup, 1)):
+        wu.step()
+    torch.cuda.synchronize(device)
+    runs, loop_s, setup_s, finite, note = {}, 0.0, 0.0, True, None
+    torch.manual_seed(1)
+    for C in (0, 1, 2, 4, 8, 16):
+        t0 = time.perf_counter()
+        sampler = sde.sampler((B,), steps=steps, corrections=C, tau=0.25)
+        if args.graph:
+            try:
+                sampler.capture()
+            except Exception as e:  # noqa: BLE001
+                note = f'capture failed, ran eagerly: {type(e).__name__}: {str(e)[:160]}'
+                args.graph = 0
+                sampler = sde.sampler((B,), steps=steps, corrections=C, tau=0.25)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            sampler.step()
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        ok = bool(torch.isfinite(sampler.result()).all().item())
+        finite = finite and ok
+        runs[str(C)] = {'sample_s': t2 - t1, 'setup_s': t1 - t0, 'ms_per_step': (t2 - t1) / steps * 1e3,
+                        'ms_per_score_eval': (t2 - t1) / steps / (1 + C) * 1e3, 'finite': ok}
+        loop_s += t2 - t1
+        setup_s += t1 - t0
+    nsteps = 6 * steps
+    out = {'metric': 'diffusion-steps/s (experiments/lorenz/eval.py protocol: six 256-step posterior-sampling runs, C = 0..16)',
+           'value': nsteps / loop_s, 'unit': 'diffusion-steps/s', 'n_gpus': 1, 'steps': nsteps, 'warmup': max(args.warmup, 1),
+           'ms_per_step': loop_s / nsteps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+           'data': 'synthetic (random-init net + exact Gaussian term, synthetic observation)',
+           'config': {'workload': 'lorenz_eval', 'description': WORKLOADS['lorenz_eval']['desc'], 'event': [L, S], 'per_gpu_batch': B,
+                      'global_batch': B, 'guided': True, 'corrections': [0, 1, 2, 4, 8, 16], 'tau': 0.25, 'schedule_steps': steps,
+                      'gamma': 3e-2, 'net': args.lorenz_net, 'freq': args.lorenz_freq, 'obs_step': step, 'std': std,
+                      'score_evals_total': steps * 37, 'hipgraph_step': bool(args.graph), 'hipgraph_note': note,
+                      'observation': 'fused Subsample (hand-written adjoint; no autograd through A)',
+                      'corrector_noise': 'device RNG (torch.randn_like under graph capture)', 'parallelism': 'dp1'},
+           'six_run_wallclock_s': loop_s + setup_s, 'six_run_sampling_s': loop_s, 'six_run_setup_and_capture_s': setup_s,
+           'reference_budget': 'one (network, freq) job of eval.py -- these six runs + its ground-truth particle filter -- is a Slurm '
+                               'request of <= 1 h on one GPU (experiments/lorenz/eval.py:42); the reference publishes no timing',
+           'per_C': runs, 'samples_finite': finite,
+           'ms_per_score_eval_all_runs': loop_s / (steps * 37) * 1e3}
+    if os.environ.get('SDA_HIP_LIB'):
+        out['kernel_library_override'] = os.environ['SDA_HIP_LIB']
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = lorenz_eval_cpu(args, step, std, B, L, S, steps)
+        out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    print(json.dumps(out), flush=True)
+
+
+def lorenz_eval_cpu(args, step, std, B, L, S, steps):
+    """CPU leg of lorenz_eval: the oracle's loop (C = 1) on a bounded sample of rows, scaled by rows and by score evaluations (37
+    evaluations per schedule step over the six runs; the cost of a step is its evaluations)."""
+    from oracle import sda_oracle as O
+    torch.manual_seed(0)
+    sched = O.Schedule()
+    rows = 64
+    if args.lorenz_net == 'local':
+        cfg = O.ResMLPConfig(15 + 32, 15, (128,) * 5, 'SiLU')
+        sd = O.init_score_net(0, 'kernel.', cfg, 32)
+        net = lambda xx, tt: O.mc_score_net(lambda a, b, c=None: O.score_net(sd, 'kernel.', cfg, a, b, c), 2, xx, tt)
+    else:
+        cfg = O.UNetConfig(S, S, 32, (64,), (3,), 3, 2, 'SiLU', 1, 'zeros')
+        sd = O.init_score_unet(0, 'score.', cfg)
+        net = lambda xx, tt: O.mc_score_wrapper(lambda a, b, c=None: O.score_unet(sd, 'score.', cfg, a, b, c), xx, tt)
+    A = lambda v: v[..., ::step, :1]
+    y = torch.randn((L + step - 1) // step, 1)
+
+    def eps(xx, tt):
+        mu, sg = sched.mu(tt), sched.sigma(tt)
+        return xx * (sg / (mu * mu + sg * sg)) + 0.1 * net(xx, tt)
+    score = lambda xx, tt: O.gaussian_score(eps, sched, y, A, std, 3e-2, xx, tt)
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, int(args.cpu_threads) or 32)
+    torch.set_num_threads(cores)
+    x = torch.randn(rows, L, S)
+    O.sample(score, sched, x, 2, steps=2, corrections=1, tau=0.25)                      # warm-up
+    nst, t_spent = 0, 0.0
+    while nst < 3 or (t_spent < args.cpu_seconds and nst < 64):
+        t0 = time.perf_counter()
+        x = O.sample(score, sched, x, 2, steps=1, corrections=1, tau=0.25)
+        t_spent += time.perf_counter() - t0
+        nst += 1
+    evals_per_s = 2 * nst / t_spent * rows / B                                           # guided evaluations of the full batch / s
+    value = evals_per_s / (37 / 6)                                                       # 37 evaluations per 6 protocol steps
+    return dict(value=value, unit='diffusion-steps/s (same protocol, extrapolated linearly in rows and score evaluations)', cores=cores,
+                kind='port', cpu_model=_cpu_model(), host_logical_cpus=ncpu,
+                sample=f'{nst} timed C = 1 steps after warm-up ({t_spent:.1f} s) of {rows} of the {B} trajectories, oracle loop '
+                       f'(oracle/sda_oracle.py), {cores} threads; scaled by {rows}/{B} rows and 2 / (37/6) evaluations per step')
+
+
 def launch_plan(gpus, env, argv):
     """argv of the torch.distributed.run launcher this process re-executes itself under, or None when it already IS a rank
     (WORLD_SIZE set: launched by torchrun / the driver's `python -m torch.distributed.run ...` form) or a 1-GPU job.
@@ -344,6 +464,8 @@ def main():
     ap.add_argument('--graph', type=int, default=1, help='1 (default): replay each step from a captured hipGraph')
     ap.add_argument('--profile-steps', type=int, default=1, help='extra eager steps (outside the timed region) for the per-kernel HIP-event timings when --graph 1')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help="weak: every rank owns a configuration shard (N = 8 is the configuration itself); strong: the 8-shard global batch is split over the ranks")
+    ap.add_argument('--lorenz-net', default='global', choices=['global', 'local'], help='lorenz_eval: the score network (lorenz/utils.py:26-59)')
+    ap.add_argument('--lorenz-freq', default='lo', choices=['lo', 'hi'], help='lorenz_eval: observation setting (eval.py:50-53)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -374,6 +496,10 @@ def main():
     from sda_amd import ops, parallel
     from sda_amd.score import GaussianScore, VPSDE
 
+    if args.workload == 'lorenz_eval':
+        if world != 1:
+            sys.exit('bench.py: --workload lorenz_eval is a single-GPU protocol (the reference runs it as independent Slurm array jobs)')
+        return run_lorenz_eval(args, device)
     wl = dict(WORKLOADS[args.workload])
     if args.per_gpu:
         wl['per_gpu'] = args.per_gpu

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 6
+#define SDA_ABI_VERSION 7
 
 enum {
     SDA_OK = 0,
@@ -320,8 +320,10 @@ int sda_gauss_cotangent(const float* y, int64_t y_numel, const float* ax, int64_
  *   vorticity: KolmogorovFlow.vorticity, periodic central differences   (sda/mcs.py:361-375); x = [pairs][2][h][w]
  * size5/start5/step5: host int[5] (leading dims padded with size 1, start 0, step 1).
  * ------------------------------------------------------------------------------------------ */
-int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, float* out, void* stream);
-int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, float* gx, void* stream);
+int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5,
+                      const int* stop5 /* exclusive ends per dim (a crop, figures.ipynb#cell16,23), or NULL */, float* out, void* stream);
+int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, const int* stop5, float* gx,
+                              void* stream);
 /* g = A^T((y - A((x - sigma eps)/mu)) / (std^2 + gamma (sigma/mu)^2)) for the subsampling A above, scalar std / gamma, in one
  * launch (sda/score.py:387-394); y broadcasts over the leading axis; (mu, sigma) from coef_dev when non-NULL */
 int sda_obs_subsample_guidance(const float* x, const float* eps, const float* y, int64_t y_numel, const int* size5,
@@ -331,6 +333,19 @@ int sda_obs_coarsen(const float* x, int64_t planes, int h, int w, int f, float* 
 int sda_obs_coarsen_adjoint(const float* r, int64_t planes, int h, int w, int f, float* gx, void* stream);
 int sda_obs_vorticity(const float* x, int64_t pairs, int h, int w, float* out, void* stream);
 int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, int w, float* gx, void* stream);
+/* The non-linear / masked / coupled observations of the reference's experiments with the VJP of their
+ * linearisation, so that the guidance gradient d log p / d x_hat = J_A(x_hat)^T((y - A x_hat)/var) (sda/score.py:389-394)
+ * needs no autograd through A:
+ *   pointwise kind 1: w / (1 + |w|)  (the saturating sensor of kolmogorov/figures.ipynb#cell23), 2: tanh, 3: w^2, 4: |w|;
+ *             _vjp: gx = r * f'(x)
+ *   mask:     out = x * m, m broadcast over the leading dims (m_numel divides n)   (figures.ipynb#cell4); self-adjoint
+ *   timediff: x [outer][len][inner] -> x[:, i] - x[:, j]  (the loop closure x[:, 0] - x[:, -1] of figures.ipynb#cell43);
+ *             _adjoint: gx = +r at index i, -r at index j, 0 elsewhere */
+int sda_obs_pointwise(const float* x, int64_t n, int kind, float* out, void* stream);
+int sda_obs_pointwise_vjp(const float* x, const float* r, int64_t n, int kind, float* gx, void* stream);
+int sda_obs_mask(const float* x, int64_t n, const float* m, int64_t m_numel, float* out, void* stream);
+int sda_obs_timediff(const float* x, int64_t outer, int len, int64_t inner, int i, int j, float* out, void* stream);
+int sda_obs_timediff_adjoint(const float* r, int64_t outer, int len, int64_t inner, int i, int j, float* gx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics of the sampling experiments.

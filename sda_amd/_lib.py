@@ -122,8 +122,13 @@ SIGNATURES = {
     'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
-    'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
-    'sda_obs_subsample_adjoint': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_subsample_adjoint': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),
+    'sda_obs_pointwise': (c_int, [c_fp, c_int64, c_int, c_fp, c_void_p]),
+    'sda_obs_pointwise_vjp': (c_int, [c_fp, c_fp, c_int64, c_int, c_fp, c_void_p]),
+    'sda_obs_mask': (c_int, [c_fp, c_int64, c_fp, c_int64, c_fp, c_void_p]),
+    'sda_obs_timediff': (c_int, [c_fp, c_int64, c_int, c_int64, c_int, c_int, c_fp, c_void_p]),
+    'sda_obs_timediff_adjoint': (c_int, [c_fp, c_int64, c_int, c_int64, c_int, c_int, c_fp, c_void_p]),
     'sda_obs_subsample_guidance': (c_int, [c_fp, c_fp, c_fp, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                            c_float, c_float, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_obs_coarsen': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_fp, c_void_p]),

@@ -49,20 +49,23 @@ __global__ void strided_scatter_kernel(const float* __restrict__ r, Slice5 s, fl
     }
 }
 
-static int fill_slice(Slice5* s, const int* size, const int* start, const int* step) {
+// stop (optional): exclusive end per dim (a crop x[..., a:b:s]); NULL = to the end of the dim
+static int fill_slice(Slice5* s, const int* size, const int* start, const int* step, const int* stop = nullptr) {
     for (int d = 0; d < 5; ++d) {
         if (size[d] <= 0 || step[d] <= 0 || start[d] < 0 || start[d] >= size[d]) return SDA_E_BADARG;
+        const int end = stop ? stop[d] : size[d];
+        if (end <= start[d] || end > size[d]) return SDA_E_BADARG;
         s->size[d] = size[d]; s->start[d] = start[d]; s->step[d] = step[d];
-        s->osize[d] = (size[d] - start[d] + step[d] - 1) / step[d];
+        s->osize[d] = (end - start[d] + step[d] - 1) / step[d];
     }
     return SDA_OK;
 }
 
-extern "C" int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, float* out,
-                                 void* stream) {
+extern "C" int sda_obs_subsample(const float* x, const int* size5, const int* start5, const int* step5, const int* stop5,
+                                 float* out, void* stream) {
     if (!x || !out || !size5 || !start5 || !step5) return SDA_E_BADARG;
     Slice5 s;
-    int rc = fill_slice(&s, size5, start5, step5);
+    int rc = fill_slice(&s, size5, start5, step5, stop5);
     if (rc) return rc;
     int64_t total = 1;
     for (int d = 0; d < 5; ++d) total *= s.osize[d];
@@ -70,11 +73,11 @@ extern "C" int sda_obs_subsample(const float* x, const int* size5, const int* st
     return sda_launch_status();
 }
 
-extern "C" int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, float* gx,
-                                         void* stream) {
+extern "C" int sda_obs_subsample_adjoint(const float* r, const int* size5, const int* start5, const int* step5, const int* stop5,
+                                         float* gx, void* stream) {
     if (!r || !gx || !size5 || !start5 || !step5) return SDA_E_BADARG;
     Slice5 s;
-    int rc = fill_slice(&s, size5, start5, step5);
+    int rc = fill_slice(&s, size5, start5, step5, stop5);
     if (rc) return rc;
     int64_t total = 1;
     for (int d = 0; d < 5; ++d) total *= s.size[d];
@@ -119,13 +122,8 @@ extern "C" int sda_obs_subsample_guidance(const float* x, const float* eps, cons
                                           float mu, float sigma, const float* coef_dev, float* g, void* stream) {
     if (!x || !eps || !y || !g || !size5 || !start5 || !step5 || y_numel <= 0) return SDA_E_BADARG;
     Slice5 s;
-    int rc = fill_slice(&s, size5, start5, step5);
+    int rc = fill_slice(&s, size5, start5, step5, stop5);    // (slices with a stop: fewer observed positions along that axis)
     if (rc) return rc;
-    if (stop5)                                             // slices with a stop: fewer observed positions along that axis
-        for (int d = 0; d < 5; ++d) {
-            if (stop5[d] <= start5[d] || stop5[d] > size5[d]) return SDA_E_BADARG;
-            s.osize[d] = (stop5[d] - start5[d] + step5[d] - 1) / step5[d];
-        }
     int64_t total = 1, ototal = 1;
     for (int d = 0; d < 5; ++d) { total *= s.size[d]; ototal *= s.osize[d]; }
     if (ototal % y_numel) return SDA_E_BADARG;
@@ -220,5 +218,97 @@ extern "C" int sda_obs_vorticity_adjoint(const float* r, int64_t pairs, int h, i
     if (!r || !gx || pairs <= 0 || h < 3 || w < 3) return SDA_E_BADARG;
     hipLaunchKernelGGL(vorticity_adjoint_kernel, dim3(obs_grid(pairs * h * w)), dim3(256), 0, (hipStream_t)stream, r, pairs,
                        h, w, gx);
+    return sda_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The non-linear / masked / coupled observations of the reference's experiments, each with the VJP of its
+// linearisation so that GaussianScore (sda/score.py:389-394) needs no autograd through A:
+//   pointwise: w / (1 + |w|) (kolmogorov/figures.ipynb#cell23, the saturating sensor), tanh, square, |w|
+//   mask:      A(x) * mask  (figures.ipynb#cell4; the mask broadcasts over the leading dims)
+//   timediff:  x[.., i, ..] - x[.., j, ..] along one axis (the loop closure of figures.ipynb#cell43)
+enum { OBS_PW_SATURATE = 1, OBS_PW_TANH = 2, OBS_PW_SQUARE = 3, OBS_PW_ABS = 4 };
+
+__device__ __forceinline__ float obs_pw(int kind, float v) {
+    switch (kind) {
+        case OBS_PW_SATURATE: return __fdiv_rn(v, 1.f + fabsf(v));
+        case OBS_PW_TANH: return tanhf(v);
+        case OBS_PW_SQUARE: return v * v;
+        case OBS_PW_ABS: return fabsf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float obs_dpw(int kind, float v) {
+    switch (kind) {
+        case OBS_PW_SATURATE: { const float d = 1.f + fabsf(v); return __fdiv_rn(1.f, d * d); }     // d/dv v/(1+|v|) = 1/(1+|v|)^2
+        case OBS_PW_TANH: { const float t = tanhf(v); return 1.f - t * t; }
+        case OBS_PW_SQUARE: return 2.f * v;
+        case OBS_PW_ABS: return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+        default: return 1.f;
+    }
+}
+
+// r == nullptr: out = f(x);  else: out = r * f'(x)
+__global__ void pointwise_kernel(const float* __restrict__ x, const float* __restrict__ r, int64_t n, int kind, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = r ? r[i] * obs_dpw(kind, x[i]) : obs_pw(kind, x[i]);
+}
+
+extern "C" int sda_obs_pointwise(const float* x, int64_t n, int kind, float* out, void* stream) {
+    if (!x || !out || n <= 0 || kind < OBS_PW_SATURATE || kind > OBS_PW_ABS) return SDA_E_BADARG;
+    hipLaunchKernelGGL(pointwise_kernel, dim3(obs_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, n, kind, out);
+    return sda_launch_status();
+}
+
+extern "C" int sda_obs_pointwise_vjp(const float* x, const float* r, int64_t n, int kind, float* gx, void* stream) {
+    if (!x || !r || !gx || n <= 0 || kind < OBS_PW_SATURATE || kind > OBS_PW_ABS) return SDA_E_BADARG;
+    hipLaunchKernelGGL(pointwise_kernel, dim3(obs_grid(n)), dim3(256), 0, (hipStream_t)stream, x, r, n, kind, gx);
+    return sda_launch_status();
+}
+
+__global__ void mask_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ m, int64_t m_numel, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] * m[i % m_numel];
+}
+
+// out = x * mask, the mask broadcast over the leading dims (m_numel divides n); self-adjoint
+extern "C" int sda_obs_mask(const float* x, int64_t n, const float* m, int64_t m_numel, float* out, void* stream) {
+    if (!x || !m || !out || n <= 0 || m_numel <= 0 || n % m_numel) return SDA_E_BADARG;
+    hipLaunchKernelGGL(mask_kernel, dim3(obs_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, m, m_numel, out);
+    return sda_launch_status();
+}
+
+// x [outer][len][inner] -> out [outer][inner] = x[:, i] - x[:, j]
+__global__ void timediff_kernel(const float* __restrict__ x, int64_t outer, int len, int64_t inner, int i, int j, float* __restrict__ out) {
+    const int64_t total = outer * inner;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = e / inner, q = e - o * inner;
+        const float* b = x + o * len * inner + q;
+        out[e] = b[(int64_t)i * inner] - b[(int64_t)j * inner];
+    }
+}
+
+// gx [outer][len][inner] = +r at index i, -r at index j, 0 elsewhere (i == j: all zero)
+__global__ void timediff_adjoint_kernel(const float* __restrict__ r, int64_t outer, int len, int64_t inner, int i, int j,
+                                        float* __restrict__ gx) {
+    const int64_t total = outer * len * inner;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = e % inner, l = (e / inner) % len, o = e / (inner * len);
+        const float v = r[o * inner + q];
+        gx[e] = (l == i ? v : 0.f) - (l == j ? v : 0.f);
+    }
+}
+
+extern "C" int sda_obs_timediff(const float* x, int64_t outer, int len, int64_t inner, int i, int j, float* out, void* stream) {
+    if (!x || !out || outer <= 0 || len <= 0 || inner <= 0 || i < 0 || j < 0 || i >= len || j >= len) return SDA_E_BADARG;
+    hipLaunchKernelGGL(timediff_kernel, dim3(obs_grid(outer * inner)), dim3(256), 0, (hipStream_t)stream, x, outer, len, inner, i, j, out);
+    return sda_launch_status();
+}
+
+extern "C" int sda_obs_timediff_adjoint(const float* r, int64_t outer, int len, int64_t inner, int i, int j, float* gx, void* stream) {
+    if (!r || !gx || outer <= 0 || len <= 0 || inner <= 0 || i < 0 || j < 0 || i >= len || j >= len) return SDA_E_BADARG;
+    hipLaunchKernelGGL(timediff_adjoint_kernel, dim3(obs_grid(outer * len * inner)), dim3(256), 0, (hipStream_t)stream, r, outer, len,
+                       inner, i, j, gx);
     return sda_launch_status();
 }

@@ -467,6 +467,15 @@ def _eps_with_vjp(sde: VPSDE, x: Tensor, t: Tensor, c, detach: bool):
     return eps, vjp
 
 
+def _linearizer(A):
+    """``x -> (A(x), r -> J_A(x)^T r)`` for operators that bring their own VJP (sda_amd.observe: ``linearize``; any object with
+    ``adjoint(r, x_shape)`` counts as linear), else None (torch autograd differentiates ``A``, as the reference does)."""
+    lin = getattr(A, 'linearize', None)
+    if lin is None and hasattr(A, 'adjoint'):
+        return lambda xh: (A(xh), lambda r: A.adjoint(r, xh.shape))
+    return lin
+
+
 class DPSGaussianScore(nn.Module):
     r"""Diffusion posterior sampling guidance for p(y|x) = N(y | A(x), Sigma)  (score.py:305-344).
     Returns :math:`-\sigma(t) s(x(t), t | y)`.  Note ``err`` is summed over the whole batch, as in the reference."""
@@ -486,10 +495,21 @@ class DPSGaussianScore(nn.Module):
         eps_d = eps.detach().contiguous()
         xhat = torch.empty_like(eps_d)
         ops.denoise(x.contiguous(), eps_d, mu, sigma, xhat)
-        with torch.enable_grad():
-            xhat.requires_grad_(True)
-            err = (self.y - self.A(xhat)).square().sum()
-        ghat, = torch.autograd.grad(err, xhat)
+        lin = _linearizer(self.A)
+        if lin is not None:
+            # d/dx_hat sum (y - A x_hat)^2 = -2 J_A^T (y - A x_hat): no autograd through an operator with a hand-written VJP
+            ax, a_vjp = lin(xhat)
+            res = self.y - ax
+            err = res.square().sum()
+            cot = res * -2.0
+            if cot.shape != ax.shape:
+                cot = cot.sum_to_size(ax.shape)
+            ghat = a_vjp(cot.contiguous())
+        else:
+            with torch.enable_grad():
+                xhat.requires_grad_(True)
+                err = (self.y - self.A(xhat)).square().sum()
+            ghat, = torch.autograd.grad(err, xhat)
         ghat = (ghat * (-self.zeta / err.detach().sqrt())).contiguous()      # d/dxhat of the DPS potential
         out = torch.empty_like(eps_d)
         ops.guided_combine(eps_d, ghat, vjp(ghat).contiguous(), mu, sigma, out)
@@ -632,9 +652,11 @@ class GaussianScore(nn.Module):
                 return self.y[rows[0]:rows[1]]
             return self.y
 
-        if hasattr(self.A, 'adjoint'):
-            # linear operator with a hand-written adjoint (sda_amd.observe): d log p / d x_hat = A^T((y - A x_hat)/var)
-            ax = self.A(xhat)
+        lin = _linearizer(self.A)
+        if lin is not None:
+            # operator with a hand-written (linearised) adjoint (sda_amd.observe): d log p / d x_hat = J_A(x_hat)^T((y - A x_hat)/var)
+            # -- exactly what autograd.grad(log_p, x) propagates through A at sda/score.py:389-394, without building a graph
+            ax, a_vjp = lin(xhat)
             yo = observed(ax)
             if (sc is not None and ax.dtype == torch.float32 and yo.dtype == torch.float32 and
                     (yo.shape == ax.shape or yo.shape == ax.shape[1:] or
@@ -644,7 +666,9 @@ class GaussianScore(nn.Module):
             else:
                 var = self.std ** 2 + self.gamma * (sigma / mu) ** 2
                 cot = ((yo - ax) / var).contiguous()
-            ghat = self.A.adjoint(cot, xhat.shape).contiguous()
+            if cot.shape != ax.shape:
+                cot = cot.sum_to_size(ax.shape)
+            ghat = a_vjp(cot.contiguous()).contiguous()
         else:
             with torch.enable_grad():
                 xhat.requires_grad_(True)

@@ -138,6 +138,67 @@ def test_config4_qg_shaped_128_guided(dev):
     assert_close(got_v.cpu(), ref_v, TOL, what='vjp qg')
 
 
+def _full_shard_properties(dev, net, B, L, C, size, group):
+    """The size-independent properties of test_config3_full_shard_properties on another configuration's whole per-GPU shard, with
+    the group-streaming planner exercised explicitly: the shard fits HBM in one pass here, so the streamed form (`group`
+    trajectories at a time, GaussianScore.group_size) must equal the one-pass form."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    x = torch.randn(B, L, C, size, size, device=dev)
+    t = torch.tensor(0.5, device=dev)
+    A = Ob.Subsample.space(4)
+    ys = [torch.randn(B, L, C, size // 4, size // 4) for _ in range(2)]
+
+    def run(y, xs=x, group=None):
+        gs = GaussianScore(y, A=A, std=0.1, sde=VPSDE(net, shape=())).to(dev)
+        if group is not None:
+            gs.group_size = group
+        return gs(xs, t)
+    outs = [run(y) for y in ys]
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(run(ys[0]), outs[0]), 'guided evaluation is not deterministic'
+    one_pass = run(ys[0], group=0)
+    streamed = run(ys[0], group=group)
+    assert_close(streamed.cpu(), one_pass.cpu(), 1e-6, what=f'streamed in groups of {group} vs one pass')
+    ragged = run(ys[0], group=group + 1 if B % (group + 1) else group + 2)          # a last group that is not full
+    assert_close(ragged.cpu(), one_pass.cpu(), 1e-6, what='ragged last group vs one pass')
+    solo = run(ys[0][:1], xs=x[:1])
+    assert_close(outs[0][:1].cpu(), solo.cpu(), 1e-6, what='trajectory 0: in the batch vs alone')
+    last = run(ys[0][-1:], xs=x[-1:])
+    assert_close(outs[0][-1:].cpu(), last.cpu(), 1e-6, what='last trajectory: in the batch vs alone')
+    mid = run((ys[0] + ys[1]) / 2)                                                   # affine in y
+    assert rel_err(mid, (outs[0] + outs[1]) / 2) < 1e-4
+    # unguided score of the shard: windows of different trajectories do not mix (first / last trajectory alone)
+    with torch.no_grad():
+        e = net(x, t)
+        assert_close(e[:1].cpu(), net(x[:1], t).cpu(), 1e-6, what='eps trajectory 0')
+        assert_close(e[-1:].cpu(), net(x[-1:], t).cpu(), 1e-6, what='eps last trajectory')
+
+
+def test_config2_full_shard_properties(dev):
+    """BASELINE configs[2] whole: 32 trajectories x 32 x 2 x 64 x 64 (896 windows) through the reference Kolmogorov net, guided."""
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(20)
+    net = make_score(size=64, **K64).to(dev)
+    torch.manual_seed(21)
+    _full_shard_properties(dev, net, 32, 32, 2, 64, 8)
+
+
+def test_config4_full_shard_properties(dev):
+    """BASELINE configs[4]'s per-GPU shard whole: 8 trajectories x 32 x 4 x 128 x 128 (224 windows of 21 x 128 x 128), guided."""
+    from sda_amd.experiments.kolmogorov import LocalScoreUNet
+    from sda_amd.score import MCScoreNet
+    from sda_amd.utils import ACTIVATIONS
+    torch.manual_seed(41)
+    net = MCScoreNet(4, order=2)
+    net.kernel = LocalScoreUNet(channels=20, size=128, embedding=64, hidden_channels=(96, 192, 384),
+                                hidden_blocks=(3, 3, 3), kernel_size=3, activation=ACTIVATIONS['SiLU'], spatial=2,
+                                padding_mode='circular')
+    net.to(dev)
+    torch.manual_seed(42)
+    _full_shard_properties(dev, net, 8, 32, 4, 128, 3)
+
+
 # ------------------------------------------------------------------------------------------------ configs[1]
 def test_config1_lorenz96_guided_eager_and_graph(dev):
     """Lorenz-96: 40 states, L = 128, batch 64, 1-D ScoreUNet (64,)/(3,), guided with the

@@ -661,3 +661,87 @@ def test_whole_net_1d_kernel_chunked_and_recomputed(dev, monkeypatch):
         out2, vjp2 = run()
         assert torch.equal(out, out2), f'chunk {forced}: forward differs'
         assert torch.equal(vjp, vjp2), f'chunk {forced}: VJP differs'
+
+
+def test_nonlinear_masked_coupled_observations_without_autograd(dev):
+    """the remaining observation operators of the reference's experiments as fused ops with
+    analytic VJPs -- the saturating sensor coarsen -> vorticity -> w / (1 + |w|) -> crop (kolmogorov/figures.ipynb#cell23), the
+    masked vorticity of the last frame (#cell4), coarsen + crop (#cell16), the loop closure x[:, 0] - x[:, -1] (#cell43) -- each
+    against the reference's callable and torch.autograd (1e-5); GaussianScore then takes the linearised-adjoint path: equal to
+    the autograd path (sda/score.py:389-394), no autograd graph through A, and capturable in a hipGraph."""
+    from sda_amd import observe as Ob
+    from sda_amd.score import DPSGaussianScore, GaussianScore, VPSDE
+    torch.manual_seed(11)
+    x = torch.randn(2, 9, 2, 16, 16) * 1.5
+    ax0 = torch.linspace(-1, 1, 16)
+    dist = torch.cartesian_prod(ax0, ax0).square().sum(-1).reshape(16, 16)
+    mask = torch.logical_and(0.2 < dist, dist < 0.8)                       # the annulus of figures.ipynb#cell4, at 16 x 16
+
+    def sat(w):
+        return w / (1 + abs(w))
+
+    cases = {
+        'cell23 saturating sensor': (Ob.Compose(Ob.Subsample.frames(3), Ob.Coarsen(2), Ob.Vorticity(), Ob.Pointwise('saturate'),
+                                                Ob.Crop((slice(1, 7), slice(1, 7)))),
+                                     lambda v: sat(O.vorticity(O.coarsen(v[..., ::3, :, :, :], 2)))[..., 1:7, 1:7]),
+        'cell4 masked vorticity': (Ob.Compose(Ob.Select(-4, -1), Ob.Vorticity(), Ob.Mask(mask)),
+                                   lambda v: O.vorticity(v[..., -1, :, :, :]) * mask),
+        'cell16 coarsen + crop': (Ob.Compose(Ob.Coarsen(4), Ob.Crop((slice(None, None, 3), slice(None), slice(1, 3), slice(1, 3)))),
+                                  lambda v: O.coarsen(v, 4)[..., ::3, :, 1:3, 1:3]),
+        'cell43 loop closure': (Ob.TimeDiff(1, 0, -1), lambda v: v[:, 0] - v[:, -1]),
+        'time difference i, j': (Ob.TimeDiff(1, 2, 5), lambda v: v[:, 2] - v[:, 5]),
+        'pointwise tanh': (Ob.Pointwise('tanh'), torch.tanh),
+        'pointwise square': (Ob.Pointwise('square'), torch.square),
+        'pointwise abs': (Ob.Pointwise('abs'), torch.abs),
+        'pointwise callables': (Ob.Pointwise(torch.sin, torch.cos), torch.sin),
+        'select + mask': (Ob.Compose(Ob.Select(-3, 0), Ob.Mask(mask.float() * 0.5)), lambda v: v[..., 0, :, :] * (mask.float() * 0.5)),
+    }
+    for name, (op, ref_fn) in cases.items():
+        xo = x.clone().requires_grad_(True)
+        ref = ref_fn(xo)
+        ax, vjp = op.linearize(x.to(dev))
+        assert tuple(ax.shape) == tuple(ref.shape) == tuple(op.out_shape(x.shape)), name
+        assert ax.grad_fn is None and not ax.requires_grad, name
+        assert_close(ax.cpu(), ref.detach(), 1e-5, what=name)
+        assert_close(op(x.to(dev)).cpu(), ref.detach(), 1e-5, what=name + ' (call)')
+        r = torch.randn_like(ref)
+        gref, = torch.autograd.grad(ref, xo, r)
+        assert_close(vjp(r.to(dev)).cpu(), gref, 1e-5, what=name + ' vjp')
+
+    # the guided score with #cell23's operator: linearised adjoint == autograd through the reference's callable
+    net = _midsize_net(dev, seed=6).to(dev)
+    xg, t = torch.randn(2, 7, 2, 16, 16, device=dev), torch.tensor(0.45, device=dev)
+    op, ref_fn = cases['cell23 saturating sensor']
+    seen = []
+
+    class Spy(Ob.Observation):                                             # records whether A ever sees a graph-building input
+        def linearize(self, v):
+            seen.append(v.requires_grad)
+            return op.linearize(v)
+
+        def __call__(self, v):
+            seen.append(v.requires_grad)
+            return op(v)
+    y = torch.randn(ref_fn(xg.cpu()).shape)
+    a = GaussianScore(y, A=ref_fn, std=0.05, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    b = GaussianScore(y, A=Spy(), std=0.05, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    assert_close(b.cpu(), a.cpu(), 1e-5, what='guided, cell23 operator')
+    assert seen and not any(seen)
+    a = DPSGaussianScore(y, A=ref_fn, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    b = DPSGaussianScore(y, A=op, sde=VPSDE(net, shape=())).to(dev)(xg, t)
+    assert_close(b.cpu(), a.cpu(), 1e-5, what='DPS, cell23 operator')
+    # ... and the whole predictor-corrector step with it replays from a hipGraph
+    outs = []
+    for use_graph in (False, True):
+        sde = VPSDE(GaussianScore(y, A=op, std=0.05, sde=VPSDE(net, shape=())), shape=(7, 2, 16, 16)).to(dev)
+        torch.manual_seed(3)
+        sde.initial_noise = torch.randn(2, 7, 2, 16, 16)
+        torch.manual_seed(7)
+        sampler = sde.sampler((2,), steps=8, corrections=1, tau=0.3)
+        if use_graph:
+            sampler.capture()
+        for _ in range(4):
+            sampler.step()
+        outs.append(sampler.result().clone())
+    assert torch.isfinite(outs[0]).all()
+    assert_close(outs[1].cpu(), outs[0].cpu(), 1e-5, what='graph replay with a non-linear observation')

@@ -72,7 +72,7 @@ def build_mcscore2d_tiny():
     return net
 
 
-def oracle_eps_from_module(module, kind):
+def oracle_eps_from_module(module, kind, hidden=(128,) * 5):
     """An oracle (CPU) eps(x, t) sharing the weights of a sda_amd module."""
     from oracle import sda_oracle as O
     sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
@@ -96,5 +96,17 @@ def oracle_eps_from_module(module, kind):
         def eps(x, t, dtype=None):
             s = sd if dtype is None else O.cast_sd(sd, dtype)
             return O.mc_score_wrapper(lambda xx, tt, c=None: O.score_unet(s, 'score.', cfg, xx, tt, c), x, t)
+        return eps
+    if kind == 'local':                       # MCScoreNet over a ScoreNet / ResMLP kernel (experiments/lorenz/utils.py:45-59)
+        k = module.kernel
+        first = k.network[0]                  # Linear(features * window + embedding -> width)
+        cfg = O.ResMLPConfig(first.in_features, module.kernel.network[-1][1].in_features if not isinstance(
+            k.network[-1], torch.nn.Linear) else k.network[-1].out_features, tuple(hidden), 'SiLU')
+        order = module.order
+
+        def eps(x, t, dtype=None):
+            s = sd if dtype is None else O.cast_sd(sd, dtype)
+            kern = lambda xx, tt, c=None: O.score_net(s, 'kernel.', cfg, xx, tt, c)
+            return O.mc_score_net(kern, order, x, t)
         return eps
     raise ValueError(kind)
