@@ -72,6 +72,14 @@ class SyntheticScore(torch.nn.Module):
         super().__init__()
         self.net, self.scale, self.eta = net, scale, eta
 
+    def affine_form(self, sched):
+        """(net, cx0, cx1, cn) with eps(x, t) = (cx0 + cx1 sigma(t)) x + cn net(x, t), sigma = `sched`'s -- the protocol by which
+        sda_amd's fused 1-D evaluation (sda_amd/fused1d.py) takes an estimator of this form; None: not expressible (another
+        schedule than the one forward() uses)."""
+        if getattr(self, '_sched', None) is not sched:
+            return None
+        return self.net, 0.0, 1.0 / (1.0 + self.eta ** 2), self.scale
+
     def forward(self, x, t, c=None):
         sched = getattr(self, '_sched', None)
         if sched is not None:                       # the enclosing VPSDE's schedule (one launch for a device scalar t)

@@ -201,6 +201,56 @@ typedef struct sda_net1d_desc {
 int sda_net1d_fwd(const sda_net1d_desc* d, void* stream);
 int sda_net1d_bwd(const sda_net1d_desc* d, void* stream);
 
+/* One Gaussian-guided score evaluation (GaussianScore.forward, sda/score.py:375-396) of such a network in TWO launches -- the
+ * dependency minimum: every position of eps feeds the likelihood, whose cotangent feeds the VJP at every position -- and the
+ * predictor / corrector bookkeeping of VPSDE.sample (sda/score.py:250-261) in their epilogues (ABI v7):
+ *   sda_net1d_fwd_fused: out = eps = (cx0 + cx1 sigma) x + cn net(x, t) and
+ *                        ghat = A^T((y - A x_hat) / (std^2 + gamma (sigma/mu)^2)), x_hat = (x - sigma eps) / mu   (score.py:387-392)
+ *                        for A = x[..., p_start:p_stop:p_step, c_start:c_stop:c_step] (experiments/lorenz/eval.py:75), y
+ *                        [n or 1][positions][channels] observed values;
+ *   sda_net1d_bwd_fused: x = ghat; out = eps - (sigma/mu)(ghat - sigma J_eps^T ghat)   (score.py:394-396), then by `mode`
+ *                        0: write out;  1: x <- r x + c1 out in place (score.py:252-253; out is not written);
+ *                        2: write out and partial[image][tile] = sum of out^2 over the tile (score.py:259: delta = tau / mean(eps^2)).
+ * (cx0, cx1, cn) = (0, 0, 1) is a bare network; other values serve estimators of the form eps = a(t) x + c net(x, t) (bench.py's
+ * synthetic score).  x, eps, ghat, out share the (sn, sc, sx) strides of the descriptor's `out`; cin == cout.
+ * coef: device {mu(t), sigma(t)}; step_coef: device {r, c1}.  Arithmetic = the unfused kernels' (same operations, same order). */
+typedef struct sda_net1d_fuse {
+    float cx0, cx1, cn;
+    const float* coef;
+    const float* y; int64_t y_sn;      /* fwd: observation; per-image stride (0 = one observation shared by the batch) */
+    int32_t p_start, p_step, p_stop;   /* fwd: observed positions */
+    int32_t c_start, c_step, c_stop;   /* fwd: observed channels */
+    float std, gamma;
+    float* ghat;                       /* fwd: out */
+    const float* eps;                  /* bwd: in (the forward's out) */
+    int32_t mode;                      /* bwd */
+    float* xs;                         /* bwd mode 1: x, in place */
+    const float* step_coef;            /* bwd mode 1 */
+    float* partial; int32_t partial_stride;   /* bwd mode 2: [n][partial_stride >= sda_net1d_tiles(d)] */
+} sda_net1d_fuse;
+int sda_net1d_fwd_fused(const sda_net1d_desc* d, const sda_net1d_fuse* f, void* stream);
+int sda_net1d_bwd_fused(const sda_net1d_desc* d, const sda_net1d_fuse* f, void* stream);
+int sda_net1d_tiles(const sda_net1d_desc* d);          /* tiles per sequence of the launch serving `d` (host, no launch) */
+
+/* Everything a predictor-corrector step needs before its score evaluations, in ONE launch (sda/score.py:250-253 scalars,
+ * TimeEmbedding score.py:15-35, every block's `project` nn.py:132-135), for up to two time values:
+ *   table != NULL: row = table[istep[0]] = {t, t - dt, r, c1, sigma(t - dt)} (the host-evaluated schedule of VPSDE.sample);
+ *                  times = {t, t - dt};  istep[0] is incremented AFTER everything is written (single workgroup: the only reader);
+ *   table == NULL: times = t_dev[0 .. nt).
+ * out_coef (floats): {mu(t0), sigma(t0), mu(t1), sigma(t1), r, c1, sigma_next, t0, t1};  out_step (int64, optional): the step index
+ * the row was read at;  mod: [nt][cp] modulation vectors.  Arithmetic identical to sda_vp_schedule / sda_time_embed /
+ * sda_linear_small. */
+int sda_step1d_prologue(const float* table, int row_len, int64_t* istep, const float* t_dev, int nt,
+                        int alpha_kind, float eta, float k, int sigma_kind,
+                        const float* freqs, int nf, const float* w0, const float* b0, int hidden, const float* w2, const float* b2, int e,
+                        const float* wp, const float* bp, int cp,
+                        float* out_coef, int64_t* out_step, float* mod, void* stream);
+/* sda_pc_correct with z = the row-keyed N(0, 1) draw of sda_randn_rows generated in the kernel (same Philox counters: identical
+ * values), draw index = draw_dev[0] * draw_mul + draw_add  (sda/score.py:257-261). */
+int sda_pc_correct_keyed(float* x, const float* eps, int b, int64_t per_sample, const float* partial, int nchunk, float tau,
+                         float sigma, const float* coef_dev, uint64_t seed, int64_t row0, const int64_t* draw_dev, int64_t draw_mul,
+                         int64_t draw_add, void* stream);
+
 /* Repack torch-layout conv weights [cout][cin][kh][kw] for sda_conv_igemm.
  *   transpose = 0: forward          dst[tap][ci][co]        = w[co][ci][dy][dx]
  *   transpose = 1: backward-data    dst[tap'][co][ci]       = w[co][ci][dy][dx], tap' = (kh-1-dy)*kw + (kw-1-dx)

@@ -99,6 +99,24 @@ class Net1dDesc(Structure):
     ]
 
 
+class Net1dFuse(Structure):
+    """Mirror of `struct sda_net1d_fuse` (include/sda_hip.h)."""
+    _fields_ = [
+        ('cx0', c_float), ('cx1', c_float), ('cn', c_float),
+        ('coef', c_fp),
+        ('y', c_fp), ('y_sn', c_int64),
+        ('p_start', c_int32), ('p_step', c_int32), ('p_stop', c_int32),
+        ('c_start', c_int32), ('c_step', c_int32), ('c_stop', c_int32),
+        ('std', c_float), ('gamma', c_float),
+        ('ghat', c_fp),
+        ('eps', c_fp),
+        ('mode', c_int32),
+        ('xs', c_fp),
+        ('step_coef', c_fp),
+        ('partial', c_fp), ('partial_stride', c_int32),
+    ]
+
+
 SIGNATURES = {
     'sda_abi_version': (c_int, []),
     'sda_conv_igemm': (c_int, [POINTER(ConvDesc), c_void_p]),
@@ -107,6 +125,13 @@ SIGNATURES = {
     'sda_block1d_bwd': (c_int, [POINTER(Block1dDesc), c_void_p]),
     'sda_net1d_fwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
     'sda_net1d_bwd': (c_int, [POINTER(Net1dDesc), c_void_p]),
+    'sda_net1d_fwd_fused': (c_int, [POINTER(Net1dDesc), POINTER(Net1dFuse), c_void_p]),
+    'sda_net1d_bwd_fused': (c_int, [POINTER(Net1dDesc), POINTER(Net1dFuse), c_void_p]),
+    'sda_net1d_tiles': (c_int, [POINTER(Net1dDesc)]),
+    'sda_step1d_prologue': (c_int, [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_float, c_float, c_int, c_fp, c_int, c_fp, c_fp, c_int,
+                                    c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_void_p]),
+    'sda_pc_correct_keyed': (c_int, [c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_uint64, c_int64, c_fp, c_int64,
+                                     c_int64, c_void_p]),
     'sda_conv_parity4': (c_int, [POINTER(ConvDesc), c_void_p]),
     'sda_conv_igemm_path': (c_int, [POINTER(ConvDesc)]),
     'sda_conv_igemm_lds_bytes': (c_int64, [POINTER(ConvDesc)]),

@@ -106,7 +106,7 @@ __device__ __forceinline__ void n1_mm(const float (&wreg)[3][16], const float* t
 // sequence are zero.  Offsets inside one image are 32-bit (checked by the launcher).
 template <int NF>
 __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64_t sc, int64_t sx, int channels, const N1Ctx& c,
-                                             float* tile) {
+                                             float* tile, float scale = 1.f) {
     constexpr int NC = 16 * NF;
     const int j = c.lane, sub = c.wave;
     if (j < NC) {
@@ -119,6 +119,10 @@ __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64
         for (int i = 0; i < 16; ++i) {
             const int ci = 16 * sub + i, cic = ci < channels ? ci : channels - 1;
             v[i >> 2][i & 3] = base[lo + (unsigned)(cic * (int)sc)];
+        }
+        if (scale != 1.f) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i >> 2][i & 3] *= scale;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -202,8 +206,14 @@ __device__ __forceinline__ void n1_stage_vectors(const sda_net1d_desc& d, const 
 
 // ------------------------------------------------------------------------------------------------------------ forward
 // convolution order in d.w / d.bias: head, (conv1, conv2) of block 0 .. nblocks - 1, tail
-template <int NF>
-__global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, int ptiles, int tp) {
+// FUSED (sda_net1d_fwd_fused): the launch is one half of a Gaussian-guided score evaluation (sda/score.py:375-396).  Its epilogue
+// forms eps = (cx0 + cx1 sigma) x + cn net(x, t) on the own columns, writes it, and writes the likelihood cotangent
+//   ghat = A^T((y - A x_hat) / var),  x_hat = (x - sigma eps) / mu,  var = std^2 + gamma (sigma / mu)^2
+// for the strided observation A = x[..., p_start:p_stop:p_step, c_start:c_stop:c_step] next to it: sda_denoise / sda_obs_subsample /
+// sda_gauss_cotangent / sda_obs_subsample_adjoint (= sda_obs_subsample_guidance) without a launch of their own, in their arithmetic
+// (same operations in the same order: bit-identical to the unfused path).
+template <int NF, bool FUSED>
+__global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
     __shared__ __attribute__((aligned(16))) float tin[N1_MAXCOL * N1_LD];     // input of the next convolution, [column jj <-> conv column jj - 1][channel]
     __shared__ __attribute__((aligned(16))) float tz[N1_MAXCOL * N1_LD];      // act(z) between the two convolutions of a block
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
     __syncthreads();
     n1_f32x4 o[NF];
     n1_mm<NF>(wB, tin, c, o);
-    {
+    if constexpr (!FUSED) {
         const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
         float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
@@ -359,6 +369,43 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             for (int nf = 0; nf < NF; ++nf)
                 if (own[nf] && cok) obr[ooff[nf]] = o[nf][r] + bt[r];
         }
+    } else {
+        const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
+        const float mu = f.coef[0], sg = f.coef[1];
+        const bool bare = f.cx0 == 0.f && f.cx1 == 0.f && f.cn == 1.f;
+        const float cx = f.cx0 + f.cx1 * sg;
+        const float rr = __fdiv_rn(sg, mu);
+        const float var = __fadd_rn(__fmul_rn(f.std, f.std), __fmul_rn(f.gamma, __fmul_rn(rr, rr)));
+        const int n_oc = (f.c_stop - f.c_start + f.c_step - 1) / f.c_step;
+        const float* xb = d.x + (int64_t)c.n * d.x_sn;
+        const float* yb = f.y + (int64_t)c.n * f.y_sn;
+        float* eb = d.out + (int64_t)c.n * d.out_sn;
+        float* gb = f.ghat + (int64_t)c.n * d.out_sn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = cbase + r;
+            const bool cok = ch < d.cout;
+            const int crel = ch - f.c_start;
+            const bool c_obs = crel >= 0 && ch < f.c_stop && crel % f.c_step == 0;
+            const int och = c_obs ? crel / f.c_step : 0;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                if (!(own[nf] && cok)) continue;
+                const int ps = (int)((soff[nf] - (unsigned)(cbase * d.len)));          // this column's position
+                const float xv = xb[(unsigned)(ch * (int)d.x_sc + ps * (int)d.x_sx)];
+                const float ov = o[nf][r] + bt[r];
+                const float e = bare ? ov : (xv * cx) + (f.cn * ov);
+                const unsigned oo = ooff[nf] + (unsigned)(r * (int)d.out_sc);
+                eb[oo] = e;
+                const int prel = ps - f.p_start;
+                float gv = 0.f;
+                if (c_obs && prel >= 0 && ps < f.p_stop && prel % f.p_step == 0) {
+                    const float xh = (xv - sg * e) / mu;
+                    gv = __fdiv_rn(yb[(prel / f.p_step) * n_oc + och] - xh, var);
+                }
+                gb[oo] = gv;
+            }
+        }
     }
     N1_STAMP(9);                                           // tail convolution + output stores
 }
@@ -367,8 +414,14 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
 // d.w holds the BACKWARD-DATA packings (sda_pack_conv_weight with transpose = 1) in execution order: tail^T (cout -> c), then for
 // k = nblocks - 1 .. 0: conv2^T, conv1^T of block k, then head^T (c -> cin).  x = incoming cotangent (cin = its channels), out =
 // the input gradient (cout = its channels); d.bias is unused.
-template <int NF>
-__global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, int ptiles, int tp) {
+// FUSED (sda_net1d_bwd_fused): x = ghat (the cotangent the fused forward wrote); the tile is scaled by cn on the way in, and the
+// epilogue finishes the guided score on the own columns,
+//   vjp = (cx0 + cx1 sigma) ghat + J_net^T (cn ghat);   out = eps - (sigma / mu) (ghat - sigma vjp)            (sda_guided_combine)
+// and, by f.mode, 0: writes out;  1: applies the predictor update x <- r x + c1 out in place (sda_pc_predict; safe: this launch
+// reads x on its own columns only);  2: writes out and this tile's sum of out^2 into partial[image][tile] (a fixed slot: the
+// Langevin step size of sda/score.py:259 stays deterministic) for sda_pc_correct / sda_pc_correct_keyed.
+template <int NF, bool FUSED>
+__global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
     __shared__ __attribute__((aligned(16))) float tg[N1_MAXCOL * N1_LD];
     __shared__ __attribute__((aligned(16))) float tq[N1_MAXCOL * N1_LD];
@@ -401,7 +454,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
         poff[nf] = (unsigned)ps;
         ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
     }
-    n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tg);
+    n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tg, FUSED ? f.cn : 1.f);
     n1_stage_vectors(d, c, nullptr, smod);
     n1_load_w(d.w, 1, c, wB);
     const int64_t plane = (int64_t)d.c * d.len;
@@ -483,14 +536,52 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
     __syncthreads();
     n1_f32x4 o[NF];
     n1_mm<NF>(wB, tg, c, o);
-    float* ob = d.out + (int64_t)c.n * d.out_sn;
+    if constexpr (!FUSED) {
+        float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float* obr = ob + (int64_t)r * d.out_sc;
-        const bool cok = cbase + r < d.cout;
+        for (int r = 0; r < 4; ++r) {
+            float* obr = ob + (int64_t)r * d.out_sc;
+            const bool cok = cbase + r < d.cout;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-            if (own[nf] && cok) obr[ooff[nf]] = o[nf][r];
+            for (int nf = 0; nf < NF; ++nf)
+                if (own[nf] && cok) obr[ooff[nf]] = o[nf][r];
+        }
+    } else {
+        const float mu = f.coef[0], sg = f.coef[1];
+        const bool bare = f.cx0 == 0.f && f.cx1 == 0.f && f.cn == 1.f;
+        const float cx = f.cx0 + f.cx1 * sg;
+        const float kk = sg / mu;
+        float pr = 0.f, pc1 = 0.f;
+        if (f.mode == 1) { pr = f.step_coef[0]; pc1 = f.step_coef[1]; }
+        const float* gb = d.x + (int64_t)c.n * d.x_sn;                 // ghat (unscaled), same layout as the outputs
+        const float* eb = f.eps + (int64_t)c.n * d.out_sn;
+        float* ob = d.out + (int64_t)c.n * d.out_sn;
+        float* xb = f.xs + (int64_t)c.n * d.out_sn;
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool cok = cbase + r < d.cout;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                if (!(own[nf] && cok)) continue;
+                const unsigned oo = ooff[nf] + (unsigned)(r * (int)d.out_sc);
+                const float gv = gb[(unsigned)((cbase + r) * (int)d.x_sc) + poff[nf] * (unsigned)d.x_sx];
+                const float vj = bare ? o[nf][r] : (gv * cx) + o[nf][r];
+                const float ov = eb[oo] - kk * (gv - sg * vj);
+                if (f.mode == 1) xb[oo] = pr * xb[oo] + pc1 * ov;
+                else {
+                    ob[oo] = ov;
+                    acc += ov * ov;
+                }
+            }
+        }
+        if (f.mode == 2) {
+            acc = sda_wave_sum(acc);
+            __syncthreads();                               // (red is free: the last block's sums have been consumed)
+            if (c.lane == 0) red[c.wave] = acc;
+            __syncthreads();
+            if (c.tid == 0) f.partial[(int64_t)c.n * f.partial_stride + (blockIdx.x - c.n * ptiles)] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
     }
 }
 
@@ -526,26 +617,66 @@ static int net1d_nf(const sda_net1d_desc* d) {
     return 2;
 }
 
-template <bool BWD, int NF>
-static void net1d_launch_nf(const sda_net1d_desc* d, dim3 grid, int ptiles, int tp, hipStream_t stream) {
-    if (BWD) hipLaunchKernelGGL(net1d_bwd_kernel<NF>, grid, dim3(256), 0, stream, *d, ptiles, tp);
-    else hipLaunchKernelGGL(net1d_fwd_kernel<NF>, grid, dim3(256), 0, stream, *d, ptiles, tp);
+template <bool BWD, int NF, bool FUSED>
+static void net1d_launch_nf(const sda_net1d_desc* d, const sda_net1d_fuse& f, dim3 grid, int ptiles, int tp, hipStream_t stream) {
+    if (BWD) hipLaunchKernelGGL((net1d_bwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp);
+    else hipLaunchKernelGGL((net1d_fwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp);
 }
 
-template <bool BWD>
-static int net1d_launch(const sda_net1d_desc* d, hipStream_t stream) {
+// the tiling of a launch: columns per tile (16 nf), own positions per tile, tiles per sequence
+static int net1d_tiling(const sda_net1d_desc* d, int* tp, int* ptiles) {
+    const int nf = net1d_nf(d);
+    if (!nf) return 0;
+    *tp = 16 * nf - 2 * (2 * d->nblocks + 2);
+    *ptiles = (d->len + *tp - 1) / *tp;
+    return nf;
+}
+
+template <bool BWD, bool FUSED>
+static int net1d_launch(const sda_net1d_desc* d, const sda_net1d_fuse* fu, hipStream_t stream) {
     const int rc = net1d_check(d, BWD);
     if (rc != SDA_OK) return rc;
-    const int nf = net1d_nf(d);
+    int tp, ptiles;
+    const int nf = net1d_tiling(d, &tp, &ptiles);
     if (!nf) return SDA_E_UNSUPPORTED;
-    const int tp = 16 * nf - 2 * (2 * d->nblocks + 2), ptiles = (d->len + tp - 1) / tp;
     if ((int64_t)d->n * ptiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
+    sda_net1d_fuse f = {};
+    if (FUSED) {
+        f = *fu;
+        if (!f.coef) return SDA_E_BADARG;
+        // eps / ghat / out / x share ONE layout (the output strides); the fused epilogues address all of them with it
+        if (d->x_sn != d->out_sn || d->x_sc != d->out_sc || d->x_sx != d->out_sx || d->cin != d->cout) return SDA_E_BADARG;
+        if (!BWD) {
+            if (!f.y || !f.ghat || f.p_step < 1 || f.c_step < 1 || f.p_start < 0 || f.c_start < 0 || f.p_stop > d->len ||
+                f.c_stop > d->cout || f.p_stop <= f.p_start || f.c_stop <= f.c_start)
+                return SDA_E_BADARG;
+        } else {
+            if (!f.eps || f.mode < 0 || f.mode > 2 || (f.mode == 1 && (!f.xs || !f.step_coef)) ||
+                (f.mode == 2 && (!f.partial || f.partial_stride < ptiles)))
+                return SDA_E_BADARG;
+            if (f.mode != 1) f.xs = d->out;                  // (never dereferenced; keeps the pointer arithmetic defined)
+        }
+    }
     const dim3 grid((unsigned)(d->n * ptiles));
-    if (nf == 2) net1d_launch_nf<BWD, 2>(d, grid, ptiles, tp, stream);
-    else if (nf == 3) net1d_launch_nf<BWD, 3>(d, grid, ptiles, tp, stream);
-    else net1d_launch_nf<BWD, 4>(d, grid, ptiles, tp, stream);
+    if (nf == 2) net1d_launch_nf<BWD, 2, FUSED>(d, f, grid, ptiles, tp, stream);
+    else if (nf == 3) net1d_launch_nf<BWD, 3, FUSED>(d, f, grid, ptiles, tp, stream);
+    else net1d_launch_nf<BWD, 4, FUSED>(d, f, grid, ptiles, tp, stream);
     return sda_launch_status();
 }
 
-extern "C" int sda_net1d_fwd(const sda_net1d_desc* d, void* stream) { return net1d_launch<false>(d, (hipStream_t)stream); }
-extern "C" int sda_net1d_bwd(const sda_net1d_desc* d, void* stream) { return net1d_launch<true>(d, (hipStream_t)stream); }
+extern "C" int sda_net1d_fwd(const sda_net1d_desc* d, void* stream) { return net1d_launch<false, false>(d, nullptr, (hipStream_t)stream); }
+extern "C" int sda_net1d_bwd(const sda_net1d_desc* d, void* stream) { return net1d_launch<true, false>(d, nullptr, (hipStream_t)stream); }
+extern "C" int sda_net1d_fwd_fused(const sda_net1d_desc* d, const sda_net1d_fuse* f, void* stream) {
+    if (!f) return SDA_E_BADARG;
+    return net1d_launch<false, true>(d, f, (hipStream_t)stream);
+}
+extern "C" int sda_net1d_bwd_fused(const sda_net1d_desc* d, const sda_net1d_fuse* f, void* stream) {
+    if (!f) return SDA_E_BADARG;
+    return net1d_launch<true, true>(d, f, (hipStream_t)stream);
+}
+// tiles per sequence of the launch that would serve `d` (the row length of the fused backward's partial sums), <= 0: unsupported
+extern "C" int sda_net1d_tiles(const sda_net1d_desc* d) {
+    if (!d || d->len < 1 || d->nblocks < 0 || d->nblocks > SDA_NET1D_MAXB) return SDA_E_UNSUPPORTED;
+    int tp, ptiles;
+    return net1d_tiling(d, &tp, &ptiles) ? ptiles : SDA_E_UNSUPPORTED;
+}

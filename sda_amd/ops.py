@@ -333,6 +333,22 @@ def net1d_launch(d: '_lib.Net1dDesc', backward: bool):
     prof.records.append((e0, e1, flops, 'net1d_bwd' if backward else 'net1d_fwd'))
 
 
+def net1d_launch_fused(d: '_lib.Net1dDesc', f: '_lib.Net1dFuse', backward: bool):
+    """One half of a fused guided evaluation (sda_net1d_fwd_fused / sda_net1d_bwd_fused; sda_amd/fused1d.py)."""
+    lib = _lib.load()
+    fn, name = (lib.sda_net1d_bwd_fused, 'sda_net1d_bwd_fused') if backward else (lib.sda_net1d_fwd_fused, 'sda_net1d_fwd_fused')
+    prof = conv_profile
+    if prof is None:
+        _lib.check(fn(ctypes.byref(d), ctypes.byref(f), _stream()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(fn(ctypes.byref(d), ctypes.byref(f), _stream()), name)
+    e1.record()
+    flops = 2.0 * d.n * d.len * 3 * (d.cin * d.c + 2 * d.nblocks * d.c * d.c + d.c * d.cout)
+    prof.records.append((e0, e1, flops, 'net1d_bwd' if backward else 'net1d_fwd'))
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm pieces
 
 def ln_stats(x: Tensor, mod: Optional[Tensor], mod_sn: int, eps: float, unbiased: bool, mean: Tensor, rstd: Tensor):
@@ -473,12 +489,29 @@ def sumsq_partial(eps: Tensor, b: int, partial: Tensor):
 
 
 def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: float, sigma: float,
-               coef_dev: Optional[Tensor] = None):
+               coef_dev: Optional[Tensor] = None, nchunk: int = SUMSQ_CHUNKS):
     _dev(x, eps, z, partial, coef_dev)
-    _check_partial(partial, b)
+    if nchunk == SUMSQ_CHUNKS:
+        _check_partial(partial, b)
+    elif partial.numel() < b * nchunk or not partial.is_contiguous():
+        raise _lib.SdaHipError(f'partial-sum buffer needs {b} x {nchunk} contiguous floats, got {tuple(partial.shape)}')
     per = x.numel() // b
     _lib.check(_lib.load().sda_pc_correct(x.data_ptr(), eps.data_ptr(), z.data_ptr(), b, per, partial.data_ptr(),
-                                          SUMSQ_CHUNKS, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
+                                          nchunk, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
+
+
+def pc_correct_keyed(x: Tensor, eps: Tensor, b: int, partial: Tensor, nchunk: int, tau: float, coef_dev: Tensor, seed: int, row0: int,
+                     draw_dev: Tensor, draw_mul: int, draw_add: int):
+    """The corrector update with its row-keyed noise generated in the kernel (the z of randn_rows(seed, row0, draw_dev * mul + add))."""
+    _dev(x, eps, partial, coef_dev)
+    if partial.numel() < b * nchunk or not partial.is_contiguous():
+        raise _lib.SdaHipError(f'partial-sum buffer needs {b} x {nchunk} contiguous floats, got {tuple(partial.shape)}')
+    if not draw_dev.is_cuda or draw_dev.dtype != torch.int64:
+        raise _lib.SdaHipError('draw_dev must be a device int64 scalar')
+    per = x.numel() // b
+    _lib.check(_lib.load().sda_pc_correct_keyed(x.data_ptr(), eps.data_ptr(), b, per, partial.data_ptr(), nchunk, tau, 0.0,
+                                                coef_dev.data_ptr(), seed & 0xffffffffffffffff, row0, draw_dev.data_ptr(), draw_mul,
+                                                draw_add, _stream()), 'sda_pc_correct_keyed')
 
 
 def randn_rows(out: Tensor, seed: int, row0: int, draw: int = 0, draw_dev: Optional[Tensor] = None, draw_mul: int = 1,

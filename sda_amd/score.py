@@ -361,6 +361,14 @@ class PCSampler:
         self.partial = torch.empty(self.nb * ops.SUMSQ_CHUNKS, device=self.x.device, dtype=torch.float32)
         self.i = 0
         self._graph = None
+        # the six-launch step of sda_amd/fused1d.py when the job has the shape of experiments/lorenz/eval.py:72-84
+        self._fused = None
+        if c is None and type(sde.eps) is GaussianScore and self.x.dim() == 3:
+            from . import fused1d
+            self._fused = fused1d.plan(sde.eps, self.x, None, None)
+            if self._fused is not None:
+                self._table = self._table_cpu.to(self.x.device)
+                self._istep = torch.zeros(1, device=self.x.device, dtype=torch.int64)
 
     # ------------------------------------------------------------------ eager step
     @torch.no_grad()
@@ -376,9 +384,38 @@ class PCSampler:
             ops.sumsq_partial(eps, self.nb, self.partial)
             ops.pc_correct(x, eps, z.contiguous(), self.nb, self.partial, self.tau, self.sg_n[i])
 
+    # ------------------------------------------------------------------ fused step (eager and captured alike)
+    @torch.no_grad()
+    def _fused_step(self, i: Optional[int]):
+        """prologue, then per score evaluation two launches with the predictor update / the Langevin step-size sums in the second
+        one's epilogue, then the corrector update: 3 + 3 C launches (general path: ~14 per evaluation + 7).  The step's scalars come
+        from the device table row selected by the device step counter, which the prologue advances."""
+        from .parallel import KeyedNoise
+        sde, x, F = self.sde, self.x, self._fused
+        F.prologue_step(self._table, self._istep)
+        F.forward(x, 0)
+        F.backward(1, 0, x=x)                                 # x <- r x + c1 eps(x, t)
+        ns = sde.noise_source
+        for j in range(self.corrections):
+            F.forward(x, 1)
+            F.backward(2, 1)                                  # eps(x, t - dt) and its per-tile sums of squares
+            if type(ns) is KeyedNoise and tuple(ns.event) == tuple(x.shape[1:]) and ns.hi - ns.lo == self.nb:
+                ops.pc_correct_keyed(x, F.out, self.nb, F.partial, F.ptiles, self.tau, F.coef[6:7], ns.seed, ns.lo, F.step_i,
+                                     ns.corrections, j)
+            else:
+                if ns is None:
+                    z = torch.randn_like(x)
+                elif i is None:
+                    z = ns.draw_dev(F.step_i, j)
+                else:
+                    z = ns(i, j).to(x)
+                ops.pc_correct(x, F.out, z.contiguous(), self.nb, F.partial, self.tau, 0.0, coef_dev=F.coef[6:7], nchunk=F.ptiles)
+
     # ------------------------------------------------------------------ graph-captured step
     @torch.no_grad()
     def _graph_body(self):
+        if self._fused is not None:
+            return self._fused_step(None)
         sde, x, cur = self.sde, self.x, self._cur
         cur.copy_(self._table.index_select(0, self._istep).reshape(-1))      # this step's scalars, device side
         ops.pc_predict(x, sde.eps(x, cur[0], self.c).contiguous(), 0.0, 0.0, coef_dev=cur[2:4])
@@ -396,9 +433,10 @@ class PCSampler:
             raise SdaHipError('an injected noise_source cannot be captured into a graph (only device-keyed sources that '
                               'implement draw_dev, e.g. parallel.KeyedNoise, can)')
         dev = self.x.device
-        self._table = self._table_cpu.to(dev)
-        self._cur = torch.zeros(self.ROW, device=dev, dtype=torch.float32)
-        self._istep = torch.full((1,), self.i, device=dev, dtype=torch.int64)
+        if self._fused is None:
+            self._table = self._table_cpu.to(dev)
+            self._cur = torch.zeros(self.ROW, device=dev, dtype=torch.float32)
+            self._istep = torch.full((1,), self.i, device=dev, dtype=torch.int64)
         keep_x = self.x.clone()
         keep_rng = torch.cuda.get_rng_state(dev)
         side = torch.cuda.Stream(device=dev)
@@ -421,6 +459,8 @@ class PCSampler:
             raise StopIteration
         if self._graph is not None:
             self._graph.replay()
+        elif self._fused is not None:
+            self._fused_step(self.i)
         else:
             self._eager_step(self.i)
         self.i += 1
@@ -628,6 +668,12 @@ class GaussianScore(nn.Module):
         return out
 
     def _guided(self, x: Tensor, t: Tensor, c, rows, out: Tensor = None, grad_only: bool = False) -> Tensor:
+        if rows is None and out is None and not grad_only:
+            # the Lorenz shape of the reference's eval.py (1-D single-level U-Net, strided observation): two fused launches
+            from . import fused1d
+            fz = fused1d.plan(self, x, t, c)
+            if fz is not None:
+                return fz.evaluate(x, t)
         mu, sigma = _mu_sigma(self.sde, t)
         eps, vjp = _eps_with_vjp(self.sde, x, t, c, self.detach)
         eps_d = eps.detach().contiguous()

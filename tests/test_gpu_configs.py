@@ -157,22 +157,25 @@ def _full_shard_properties(dev, net, B, L, C, size, group):
     outs = [run(y) for y in ys]
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(run(ys[0]), outs[0]), 'guided evaluation is not deterministic'
+    errs = {}
     one_pass = run(ys[0], group=0)
-    streamed = run(ys[0], group=group)
-    assert_close(streamed.cpu(), one_pass.cpu(), 1e-6, what=f'streamed in groups of {group} vs one pass')
-    ragged = run(ys[0], group=group + 1 if B % (group + 1) else group + 2)          # a last group that is not full
-    assert_close(ragged.cpu(), one_pass.cpu(), 1e-6, what='ragged last group vs one pass')
-    solo = run(ys[0][:1], xs=x[:1])
-    assert_close(outs[0][:1].cpu(), solo.cpu(), 1e-6, what='trajectory 0: in the batch vs alone')
-    last = run(ys[0][-1:], xs=x[-1:])
-    assert_close(outs[0][-1:].cpu(), last.cpu(), 1e-6, what='last trajectory: in the batch vs alone')
-    mid = run((ys[0] + ys[1]) / 2)                                                   # affine in y
-    assert rel_err(mid, (outs[0] + outs[1]) / 2) < 1e-4
+    errs[f'streamed in groups of {group} vs one pass'] = rel_err(run(ys[0], group=group), one_pass)
+    g2 = group + 1 if B % (group + 1) else group + 2                                 # a last group that is not full
+    errs[f'ragged groups of {g2} vs one pass'] = rel_err(run(ys[0], group=g2), one_pass)
+    errs['trajectory 0: in the batch vs alone'] = rel_err(outs[0][:1], run(ys[0][:1], xs=x[:1]))
+    errs['last trajectory: in the batch vs alone'] = rel_err(outs[0][-1:], run(ys[0][-1:], xs=x[-1:]))
     # unguided score of the shard: windows of different trajectories do not mix (first / last trajectory alone)
     with torch.no_grad():
         e = net(x, t)
-        assert_close(e[:1].cpu(), net(x[:1], t).cpu(), 1e-6, what='eps trajectory 0')
-        assert_close(e[-1:].cpu(), net(x[-1:], t).cpu(), 1e-6, what='eps last trajectory')
+        errs['eps trajectory 0 vs alone'] = rel_err(e[:1], net(x[:1], t))
+        errs['eps last trajectory vs alone'] = rel_err(e[-1:], net(x[-1:], t))
+    print({k: f'{v:.2e}' for k, v in errs.items()})
+    # (not bit-equality: the LayerNorm / direct-kernel variant and the persistent tile walk depend on how many windows a launch
+    # carries, and each variant sums in its own order -- fp32 round-off through 42 convolutions and their VJPs)
+    bad = {k: v for k, v in errs.items() if v > 1e-5}
+    assert not bad, f'samples are coupled / the group planner changes results: {bad} (all: {errs})'
+    mid = run((ys[0] + ys[1]) / 2)                                                   # affine in y
+    assert rel_err(mid, (outs[0] + outs[1]) / 2) < 1e-4
 
 
 def test_config2_full_shard_properties(dev):

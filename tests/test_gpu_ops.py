@@ -726,7 +726,8 @@ def test_wino4_silu_derivative_strongly_negative_preactivation(dev, cin, hw):
     dz, = torch.autograd.grad(F.silu(zz).sum(), zz)
     pk = ops.PackedConv(wgt.to(dev), None)
     out = torch.full((n, cout, hw, hw), float('nan'), device=dev)
-    desc = launch_conv(pk, planar_source(x.to(dev)), out, hw, hw, circular=True, dact_z=z.to(dev), act_d=ACT_IDS['SiLU'])
+    xd, zd = x.to(dev), z.to(dev)                        # (held: the descriptor carries raw pointers)
+    desc = launch_conv(pk, planar_source(xd), out, hw, hw, circular=True, dact_z=zd, act_d=ACT_IDS['SiLU'])
     torch.cuda.synchronize()
     assert ops.conv_path(desc) == 2                      # conv_wino4
     assert torch.isfinite(out).all(), 'SiLU\'(z) overflowed for a strongly negative pre-activation'
