@@ -19,6 +19,12 @@
 //     the backward kernel reads it for its halo columns too (written by the neighbours' forward).
 //   * input / output are addressed through (image, channel, position) strides: the (B, L, C) <-> (B, C, L) transposes of
 //     MCScoreWrapper (sda/score.py:104-110) cost nothing on either side.
+//   * the validity cone (round 4): convolution i (0 = first of the launch) is only exact -- and only needed -- on columns
+//     [1 + i, NC - 1 - i).  The 16-column MFMA fragments are therefore mapped so that the LAST one holds the tile's outermost
+//     columns [0, 8) + [NC - 8, NC) (fragment nf < NF - 1 holds columns 8 + 16 nf ..): from convolution 7 on nothing in it is needed
+//     any more, and the rest of the launch multiplies, normalises and stores NF - 1 fragments (7 of 14 convolutions of the Lorenz
+//     nets: -25 % of the MFMAs at NF = 2, -12.5 % at NF = 4).  A stage may only drop the fragment once the stage feeding it wrote
+//     nothing the next one reads there: a block's LayerNorm / residual store goes narrow one block later than its convolutions.
 #include "sda_common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -50,6 +56,7 @@ extern "C" int sda_n1_trace_read(long long* out, int reset) {
 
 struct N1Ctx {
     int tid, lane, wave, kq, li, co0, n, p0, H, len;
+    int col_outer;                     // this lane's column in the OUTER fragment: li < 8 ? li : NC - 16 + li
     unsigned wlane;                    // this lane's element offset inside a [tap][64][64] weight slab: row 16 kq, column co0 + li
     bool circular;
 };
@@ -65,6 +72,11 @@ __device__ __forceinline__ int n1_pos(const N1Ctx& c, int j, bool& inside) {
     return inside ? p : 0;
 }
 
+// conv-output column of this lane in fragment nf: inner fragments are consecutive runs from column 8, the last fragment is the tile's
+// outermost 8 + 8 columns (see "validity cone" above)
+template <int NF>
+__device__ __forceinline__ int n1_col(const N1Ctx& c, int nf) { return nf < NF - 1 ? 8 + 16 * nf + c.li : c.col_outer; }
+
 // all A fragments of convolution `conv` for this wave: wreg[tap][cb] = W[conv][tap][k = 16 kq + cb][m = co0 + li]
 // (one batch of loads: a per-lane offset against wave-uniform bases)
 __device__ __forceinline__ void n1_load_w(const float* w, int conv, const N1Ctx& c, float (&wreg)[3][16]) {
@@ -78,24 +90,25 @@ __device__ __forceinline__ void n1_load_w(const float* w, int conv, const N1Ctx&
 // acc[nf] = sum_{tap, cb} A(tap, cb) B[channel 16 kq + cb][column 16 nf + li + tap]   (tile column jj <-> conv column jj - 1).
 // All 16 K fragments, unconditionally (see block1d.hip: a runtime trip count costs more than the surplus MFMAs).  Per tap the
 // wave reads its 16 x NF operand values as 4 x NF ds_read_b128; consecutive MFMAs rotate over the NF accumulators.
-template <int NF>
-__device__ __forceinline__ void n1_mm(const float (&wreg)[3][16], const float* tile, const N1Ctx& c, n1_f32x4 (&acc)[NF]) {
-    const float* brow = tile + c.li * N1_LD + 16 * c.kq;
-    n1_f32x4 bv[NF][4];
+// NFA <= NF: the fragments still inside the validity cone (the outer fragment is the last index); boff[nf] = this lane's float offset
+// of (column n1_col(nf), channel 16 kq) in a tile
+template <int NF, int NFA>
+__device__ __forceinline__ void n1_mm(const float (&wreg)[3][16], const float* tile, const unsigned (&boff)[NF], n1_f32x4 (&acc)[NF]) {
+    n1_f32x4 bv[NFA][4];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) acc[nf] = n1_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NFA; ++nf) acc[nf] = n1_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
         // (one operand set: the ~100 cycles until a tap's reads return are exposed three times per 6000-cycle convolution)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
+        for (int nf = 0; nf < NFA; ++nf)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                bv[nf][q] = *reinterpret_cast<const n1_f32x4*>(brow + (16 * nf + tap) * N1_LD + 4 * q);
+                bv[nf][q] = *reinterpret_cast<const n1_f32x4*>(tile + boff[nf] + tap * N1_LD + 4 * q);
 #pragma unroll
         for (int cb = 0; cb < 16; ++cb)
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
+            for (int nf = 0; nf < NFA; ++nf)
                 acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][cb], bv[nf][cb >> 2][cb & 3], acc[nf], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                 // (or the scheduler hoists all three taps' reads: 192 live registers)
     }
@@ -136,32 +149,32 @@ __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64
 
 // registers in D layout -> the tile channels of this wave (masked: columns outside the sequence and channels >= c are zero):
 // a lane's four values of a column are consecutive channels -> one 16-byte store per column
-template <int NF>
+template <int NF, int NFA>
 __device__ __forceinline__ void n1_store_tile(const n1_f32x4 (&v)[NF], const bool (&inside)[NF], const bool (&rok)[4], const N1Ctx& c,
                                               float* tile) {
     const int cb = c.co0 + 4 * c.kq;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
+    for (int nf = 0; nf < NFA; ++nf) {
         n1_f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (inside[nf] && rok[r]) ? v[nf][r] : 0.f;
-        *reinterpret_cast<n1_f32x4*>(tile + (1 + 16 * nf + c.li) * N1_LD + cb) = o;
+        *reinterpret_cast<n1_f32x4*>(tile + (1 + n1_col<NF>(c, nf)) * N1_LD + cb) = o;
     }
 }
 
 // sum over the channels of every column: lane-local over r, across the 4 lane groups, across the 4 waves (LDS; one barrier)
-template <int NF>
+template <int NF, int NFA>
 __device__ __forceinline__ void n1_colsum(float (&s)[NF], float* red, const N1Ctx& c) {
     constexpr int NC = 16 * NF;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
+    for (int nf = 0; nf < NFA; ++nf) {
         s[nf] += __shfl_xor(s[nf], 16, 64);
         s[nf] += __shfl_xor(s[nf], 32, 64);
-        if (c.kq == 0) red[c.wave * NC + 16 * nf + c.li] = s[nf];
+        if (c.kq == 0) red[c.wave * NC + 16 * nf + c.li] = s[nf];      // (slot 16 nf + li: any bijection serves the exchange)
     }
     __syncthreads();
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
+    for (int nf = 0; nf < NFA; ++nf) {
         const int m = 16 * nf + c.li;
         s[nf] = (red[m] + red[NC + m]) + (red[2 * NC + m] + red[3 * NC + m]);
     }
@@ -172,6 +185,7 @@ __device__ __forceinline__ void n1_ctx(N1Ctx& c, const sda_net1d_desc& d, int pt
     c.co0 = 16 * c.wave; c.n = blockIdx.x / ptiles; c.p0 = (blockIdx.x - c.n * ptiles) * tp;
     c.H = 2 * d.nblocks + 2; c.len = d.len; c.circular = d.circular != 0;
     c.wlane = (unsigned)(16 * c.kq * 64 + c.co0 + c.li);
+    c.col_outer = 0;                   // (set by the kernels: needs NC)
 }
 
 // biases of every convolution and the modulation vectors of every block -> LDS (once per launch; read per block as one 16-byte
@@ -215,6 +229,9 @@ __device__ __forceinline__ void n1_stage_vectors(const sda_net1d_desc& d, const 
 template <int NF, bool FUSED>
 __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
+    constexpr int NR = NF > 1 ? NF - 1 : 1;                                   // fragments once the outer one has left the validity cone
+    using FULL = std::integral_constant<int, NF>;
+    using NARROW = std::integral_constant<int, NR>;
     __shared__ __attribute__((aligned(16))) float tin[N1_MAXCOL * N1_LD];     // input of the next convolution, [column jj <-> conv column jj - 1][channel]
     __shared__ __attribute__((aligned(16))) float tz[N1_MAXCOL * N1_LD];      // act(z) between the two convolutions of a block
     __shared__ __attribute__((aligned(16))) float sb[(2 + 2 * SDA_NET1D_MAXB) * 64];
@@ -222,6 +239,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
+    c.col_outer = c.li < 8 ? c.li : NC - 16 + c.li;
     N1_T0();
     float wA[3][16], wB[3][16];
     n1_load_w(d.w, 0, c, wA);
@@ -233,17 +251,18 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         tz[col * N1_LD + ch] = 0.f;
     }
     bool inside[NF], own[NF], rok[4];
-    unsigned soff[NF], ooff[NF];
+    unsigned soff[NF], ooff[NF], boff[NF];
     const int cbase = c.co0 + 4 * c.kq;
 #pragma unroll
     for (int r = 0; r < 4; ++r) rok[r] = cbase + r < d.c;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-        const int j = 16 * nf + c.li;
+        const int j = n1_col<NF>(c, nf);
         const int ps = n1_pos(c, j, inside[nf]);
         own[nf] = inside[nf] && j >= c.H && j < c.H + tp && c.p0 - c.H + j < d.len;      // (the un-wrapped position is this tile's)
         soff[nf] = (unsigned)(cbase * d.len + ps);                                       // planar [c][len] saves
         ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
+        boff[nf] = (unsigned)(j * N1_LD + 16 * c.kq);
     }
     n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tin);
     n1_stage_vectors(d, c, sb, smod);
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
     N1_STAMP(1);                                           // the input tile's round trip
     // ---- head convolution: a = conv(x) + b
     n1_f32x4 a[NF];
-    n1_mm<NF>(wA, tin, c, a);
+    n1_mm<NF, NF>(wA, tin, boff, a);
     {
         const n1_f32x4 bh = *reinterpret_cast<const n1_f32x4*>(sb + cbase);
 #pragma unroll
@@ -263,7 +282,10 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
     const bool silu = d.act == SDA_ACT_SILU;
     const float inv_c = 1.f / (float)d.c, inv_v = 1.f / (float)(d.unbiased ? d.c - 1 : d.c);
     const int64_t plane = (int64_t)d.c * d.len;
-    for (int k = 0; k < d.nblocks; ++k) {
+    // one modulated residual block; NFL fragments through the LayerNorm and its tile store, NFC through the two convolutions, their
+    // epilogues and the residual update (NFC <= NFL; see "validity cone")
+    auto block = [&](const int k, auto NFL_, auto NFC_) {
+        constexpr int NFL = decltype(NFL_)::value, NFC = decltype(NFC_)::value;
         // ---- per-channel operands of the block (this lane's 4 channels)
         const n1_f32x4 mo = *reinterpret_cast<const n1_f32x4*>(smod + k * 64 + cbase);
         const n1_f32x4 b1 = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * k) * 64 + cbase);
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             for (int r = 0; r < 4; ++r) {
                 float* asr = as + r * d.len;               // (uniform)
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
+                for (int nf = 0; nf < NFL; ++nf)
                     if (own[nf] && rok[r]) asr[soff[nf]] = a[nf][r];
             }
         }
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         n1_f32x4 u[NF];
         float s[NF];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFL; ++nf) {
             s[nf] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -291,11 +313,11 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
                 s[nf] += u[nf][r];
             }
         }
-        n1_colsum<NF>(s, red, c);
+        n1_colsum<NF, NFL>(s, red, c);
         N1_STAMP(3);                                       // block operands, a_save stores, first channel reduction
         float mean[NF], rstd[NF];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFL; ++nf) {
             mean[nf] = s[nf] * inv_c;
             s[nf] = 0.f;
 #pragma unroll
@@ -304,9 +326,9 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
                 s[nf] += rok[r] ? dl * dl : 0.f;
             }
         }
-        n1_colsum<NF>(s, red + 4 * NC, c);
+        n1_colsum<NF, NFL>(s, red + 4 * NC, c);
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFL; ++nf) {
             rstd[nf] = __builtin_amdgcn_rsqf(s[nf] * inv_v + d.eps);       // (v_rsq_f32: 1 ulp)
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[nf][r] = (u[nf][r] - mean[nf]) * rstd[nf];
@@ -315,16 +337,16 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             float* ms = d.mean_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
             float* rs = d.rstd_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
+            for (int nf = 0; nf < NFL; ++nf)
                 if (own[nf]) { const unsigned p = soff[nf] - (unsigned)(cbase * d.len); ms[p] = mean[nf]; rs[p] = rstd[nf]; }
         }
-        n1_store_tile<NF>(u, inside, rok, c, tin);
+        n1_store_tile<NF, NFL>(u, inside, rok, c, tin);
         n1_load_w(d.w, 2 + 2 * k, c, wA);                  // conv2 of this block (set A is free: the previous conv2 / the head is done)
         __syncthreads();
         N1_STAMP(4);                                       // second reduction, normalised tile -> LDS, weight-load issue
         // ---- conv1: z = conv(LN) + b1 -> saved (own columns); act(z) -> LDS
         n1_f32x4 z[NF];
-        n1_mm<NF>(wB, tin, c, z);
+        n1_mm<NF, NFC>(wB, tin, boff, z);
         N1_STAMP(5);                                       // conv1 multiply
         float* zs = d.z_save ? d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane : nullptr;
         auto conv1_epilogue = [&](auto SILU_) {
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             for (int r = 0; r < 4; ++r) {
                 float* zsr = zs + r * d.len;
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
+                for (int nf = 0; nf < NFC; ++nf) {
                     const float zv = z[nf][r] + b1[r];
                     if (zs && own[nf] && rok[r]) zsr[soff[nf]] = zv;
                     z[nf][r] = decltype(SILU_)::value ? sda_act(SDA_ACT_SILU, zv) : sda_act(d.act, zv);
@@ -341,23 +363,45 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         };
         if (silu) conv1_epilogue(std::true_type{});
         else conv1_epilogue(std::false_type{});
-        n1_store_tile<NF>(z, inside, rok, c, tz);
+        n1_store_tile<NF, NFC>(z, inside, rok, c, tz);
         n1_load_w(d.w, 3 + 2 * k, c, wB);                  // conv1 of the next block, or the tail
         __syncthreads();
         N1_STAMP(6);                                       // conv1 epilogue: z stores, activation, tile -> LDS
         // ---- conv2 + b2 + residual
         n1_f32x4 y[NF];
-        n1_mm<NF>(wA, tz, c, y);
+        n1_mm<NF, NFC>(wA, tz, boff, y);
         N1_STAMP(7);                                       // conv2 multiply
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) a[nf] += y[nf] + b2;
+        for (int nf = 0; nf < NFC; ++nf) a[nf] += y[nf] + b2;
         N1_STAMP(8);                                       // residual update
+    };
+    // convolution index of block k: 1 + 2 k (conv1), 2 + 2 k (conv2).  Outputs of convolution i are needed on columns [1 + i, NC - 1 - i):
+    // the outer fragment (columns < 8 and >= NC - 8) is out of the multiply from i = 7 (block 3) and out of the LayerNorm + store --
+    // conv1's INPUT, columns [1 + 2 k, ..) -- from block 4.  (The own columns are inner columns whenever a block >= 3 exists: H >= 8.)
+    {
+        int k = 0;
+        const int nb = d.nblocks;
+        for (; k < nb && k < 3; ++k) block(k, FULL{}, FULL{});
+        if (k < nb) { block(k, FULL{}, NARROW{}); ++k; }
+        for (; k < nb; ++k) block(k, NARROW{}, NARROW{});
     }
-    // ---- tail convolution -> out (own columns, through the output strides)
-    n1_store_tile<NF>(a, inside, rok, c, tin);
-    __syncthreads();
+    // ---- tail convolution (index 1 + 2 nblocks) -> out (own columns, through the output strides)
     n1_f32x4 o[NF];
-    n1_mm<NF>(wB, tin, c, o);
+    if (d.nblocks >= 4) {
+        n1_store_tile<NF, NR>(a, inside, rok, c, tin);
+        __syncthreads();
+        n1_mm<NF, NR>(wB, tin, boff, o);
+    } else if (d.nblocks == 3) {
+        n1_store_tile<NF, NF>(a, inside, rok, c, tin);
+        __syncthreads();
+        n1_mm<NF, NR>(wB, tin, boff, o);
+    } else {
+        n1_store_tile<NF, NF>(a, inside, rok, c, tin);
+        __syncthreads();
+        n1_mm<NF, NF>(wB, tin, boff, o);
+    }
+    // (own columns of a fragment that was not multiplied do not exist: with nblocks >= 3 the halo is >= 8 columns)
+    const int nfo = d.nblocks >= 3 ? NR : NF;
     if constexpr (!FUSED) {
         const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
         float* ob = d.out + (int64_t)c.n * d.out_sn;
@@ -367,7 +411,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             const bool cok = cbase + r < d.cout;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-                if (own[nf] && cok) obr[ooff[nf]] = o[nf][r] + bt[r];
+                if (nf < nfo && own[nf] && cok) obr[ooff[nf]] = o[nf][r] + bt[r];
         }
     } else {
         const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
@@ -390,7 +434,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
             const int och = c_obs ? crel / f.c_step : 0;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
-                if (!(own[nf] && cok)) continue;
+                if (!(nf < nfo && own[nf] && cok)) continue;
                 const int ps = (int)((soff[nf] - (unsigned)(cbase * d.len)));          // this column's position
                 const float xv = xb[(unsigned)(ch * (int)d.x_sc + ps * (int)d.x_sx)];
                 const float ov = o[nf][r] + bt[r];
@@ -423,12 +467,16 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
 template <int NF, bool FUSED>
 __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
     constexpr int NC = 16 * NF;
+    constexpr int NR = NF > 1 ? NF - 1 : 1;
+    using FULL = std::integral_constant<int, NF>;
+    using NARROW = std::integral_constant<int, NR>;
     __shared__ __attribute__((aligned(16))) float tg[N1_MAXCOL * N1_LD];
     __shared__ __attribute__((aligned(16))) float tq[N1_MAXCOL * N1_LD];
     __shared__ __attribute__((aligned(16))) float smod[SDA_NET1D_MAXB * 64];
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
+    c.col_outer = c.li < 8 ? c.li : NC - 16 + c.li;
     float wA[3][16], wB[3][16];
     n1_load_w(d.w, 0, c, wA);
     if (c.tid < 2 * N1_MAXC) {
@@ -437,7 +485,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
         tq[col * N1_LD + ch] = 0.f;
     }
     bool inside[NF], own[NF], rok[4];
-    unsigned poff[NF], ooff[NF];
+    unsigned poff[NF], ooff[NF], boff[NF];
     const int cbase = c.co0 + 4 * c.kq;
     // (loads of saved tensors clamp their channel row: lanes beyond c read a row that exists and are masked afterwards)
     unsigned roff[4];
@@ -448,20 +496,23 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
     }
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-        const int j = 16 * nf + c.li;
+        const int j = n1_col<NF>(c, nf);
         const int ps = n1_pos(c, j, inside[nf]);
         own[nf] = inside[nf] && j >= c.H && j < c.H + tp && c.p0 - c.H + j < d.len;
         poff[nf] = (unsigned)ps;
         ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
+        boff[nf] = (unsigned)(j * N1_LD + 16 * c.kq);
     }
     n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tg, FUSED ? f.cn : 1.f);
     n1_stage_vectors(d, c, nullptr, smod);
     n1_load_w(d.w, 1, c, wB);
     const int64_t plane = (int64_t)d.c * d.len;
-    // what a block's VJP reads from the forward, in D layout on every column (halo columns: written by the neighbours)
+    // what a block's VJP reads from the forward, in D layout on every column still inside the validity cone (halo columns: written by
+    // the neighbours' forward)
     n1_f32x4 ez[NF], ea[NF];
     float emean[NF], erstd[NF];
-    auto fetch_saved = [&](int k) {
+    auto fetch_saved = [&](const int k, auto NFA_) {
+        constexpr int NFA = decltype(NFA_)::value;
         const float* zs = d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
         const float* as = d.a_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
         const float* ms = d.mean_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
@@ -469,49 +520,57 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) {
+            for (int nf = 0; nf < NFA; ++nf) {
                 const unsigned o = roff[r] + poff[nf];
                 ez[nf][r] = zs[o];
                 ea[nf][r] = as[o];
             }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) { emean[nf] = ms[poff[nf]]; erstd[nf] = rs[poff[nf]]; }
+        for (int nf = 0; nf < NFA; ++nf) { emean[nf] = ms[poff[nf]]; erstd[nf] = rs[poff[nf]]; }
     };
+    // reversed block index kk = nblocks - 1 - k: convolution indices 1 + 2 kk (conv2^T) and 2 + 2 kk (conv1^T).  As in the forward: the
+    // multiplies / act' / LayerNorm-backward of reversed block kk leave the outer fragment out from kk = 3, the store of g (conv2^T's
+    // input, columns [1 + 2 kk, ..)) from kk = 4.
     const int kl = d.nblocks - 1;
-    if (d.nblocks > 0) fetch_saved(kl);
+    if (d.nblocks > 0) {
+        if (kl >= 3) fetch_saved(kl, FULL{});              // (kk = 0: everything)
+        else fetch_saved(kl, FULL{});
+    }
     __syncthreads();
     // ---- tail^T: g = conv^T(cotangent)
     n1_f32x4 g[NF];
-    n1_mm<NF>(wA, tg, c, g);
+    n1_mm<NF, NF>(wA, tg, boff, g);
     const bool silu = d.act == SDA_ACT_SILU;
     const float inv_c = 1.f / (float)d.c, inv_v = 1.f / (float)(d.unbiased ? d.c - 1 : d.c);
     int conv = 1;                                          // index of the convolution whose weights sit in wB
-    for (int k = kl; k >= 0; --k, conv += 2) {
+    auto block = [&](const int k, auto NFS_, auto NFC_, auto NFN_) {
+        // NFS: fragments of the g store, NFC: of everything after it, NFN: of the NEXT block's saved-tensor fetch
+        constexpr int NFS = decltype(NFS_)::value, NFC = decltype(NFC_)::value;
         const n1_f32x4 emod = *reinterpret_cast<const n1_f32x4*>(smod + k * 64 + cbase);
-        n1_store_tile<NF>(g, inside, rok, c, tg);
+        n1_store_tile<NF, NFS>(g, inside, rok, c, tg);
         n1_load_w(d.w, conv + 1, c, wA);                   // conv1^T of this block
         __syncthreads();
         // ---- conv2^T, x act'(z) -> LDS
         n1_f32x4 q[NF];
-        n1_mm<NF>(wB, tg, c, q);
+        n1_mm<NF, NFC>(wB, tg, boff, q);
         auto dact = [&](auto SILU_) {
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
+            for (int nf = 0; nf < NFC; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     q[nf][r] *= decltype(SILU_)::value ? sda_dact(SDA_ACT_SILU, ez[nf][r]) : sda_dact(d.act, ez[nf][r]);
         };
         if (silu) dact(std::true_type{});
         else dact(std::false_type{});
-        n1_store_tile<NF>(q, inside, rok, c, tq);
+        n1_store_tile<NF, NFC>(q, inside, rok, c, tq);
         n1_load_w(d.w, conv + 2, c, wB);                   // conv2^T of the block before, or head^T
         __syncthreads();
         // ---- conv1^T -> gh; LayerNorm backward: g <- rstd (gh - mean_c(gh) - xh mean'_c(gh xh)) + g
         n1_f32x4 gh[NF], xh[NF];
-        n1_mm<NF>(wA, tq, c, gh);
+        n1_mm<NF, NFC>(wA, tq, boff, gh);
         float s1[NF], s2[NF];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFC; ++nf) {
             s1[nf] = 0.f; s2[nf] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -520,22 +579,42 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
                 s1[nf] += gv; s2[nf] += gv * xh[nf][r];
             }
         }
-        n1_colsum<NF>(s1, red, c);
-        n1_colsum<NF>(s2, red + 4 * NC, c);
+        n1_colsum<NF, NFC>(s1, red, c);
+        n1_colsum<NF, NFC>(s2, red + 4 * NC, c);
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
+        for (int nf = 0; nf < NFC; ++nf) {
             const float av = s1[nf] * inv_c, bv = s2[nf] * inv_v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[nf][r] += erstd[nf] * (gh[nf][r] - av - xh[nf][r] * bv);
         }
-        if (k > 0) fetch_saved(k - 1);
+        if (k > 0) fetch_saved(k - 1, NFN_);
         __syncthreads();                                   // (red is reused by the next block's sums)
+        conv += 2;
+    };
+    {
+        int kk = 0;
+        const int nb = d.nblocks;
+        for (; kk < nb && kk < 2; ++kk) block(nb - 1 - kk, FULL{}, FULL{}, FULL{});
+        if (kk < nb) { block(nb - 1 - kk, FULL{}, FULL{}, NARROW{}); ++kk; }            // kk = 2: the next block multiplies narrow
+        if (kk < nb) { block(nb - 1 - kk, FULL{}, NARROW{}, NARROW{}); ++kk; }          // kk = 3
+        for (; kk < nb; ++kk) block(nb - 1 - kk, NARROW{}, NARROW{}, NARROW{});
     }
-    // ---- head^T -> input gradient (own columns, through the output strides)
-    n1_store_tile<NF>(g, inside, rok, c, tg);
-    __syncthreads();
+    // ---- head^T (index 1 + 2 nblocks) -> input gradient (own columns, through the output strides)
     n1_f32x4 o[NF];
-    n1_mm<NF>(wB, tg, c, o);
+    if (d.nblocks >= 4) {
+        n1_store_tile<NF, NR>(g, inside, rok, c, tg);
+        __syncthreads();
+        n1_mm<NF, NR>(wB, tg, boff, o);
+    } else if (d.nblocks == 3) {
+        n1_store_tile<NF, NF>(g, inside, rok, c, tg);
+        __syncthreads();
+        n1_mm<NF, NR>(wB, tg, boff, o);
+    } else {
+        n1_store_tile<NF, NF>(g, inside, rok, c, tg);
+        __syncthreads();
+        n1_mm<NF, NF>(wB, tg, boff, o);
+    }
+    const int nfo = d.nblocks >= 3 ? NR : NF;
     if constexpr (!FUSED) {
         float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
@@ -544,7 +623,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
             const bool cok = cbase + r < d.cout;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-                if (own[nf] && cok) obr[ooff[nf]] = o[nf][r];
+                if (nf < nfo && own[nf] && cok) obr[ooff[nf]] = o[nf][r];
         }
     } else {
         const float mu = f.coef[0], sg = f.coef[1];
@@ -563,7 +642,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
             const bool cok = cbase + r < d.cout;
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
-                if (!(own[nf] && cok)) continue;
+                if (!(nf < nfo && own[nf] && cok)) continue;
                 const unsigned oo = ooff[nf] + (unsigned)(r * (int)d.out_sc);
                 const float gv = gb[(unsigned)((cbase + r) * (int)d.x_sc) + poff[nf] * (unsigned)d.x_sx];
                 const float vj = bare ? o[nf][r] : (gv * cx) + o[nf][r];

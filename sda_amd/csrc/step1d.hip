@@ -14,17 +14,74 @@
 #define S1_MAX_FEAT 128
 #define S1_MAX_HIDDEN 1024
 #define S1_MAX_E 256
+#define S1_PAD 4                       // floats of row padding in the staged weight copies (16-byte aligned rows, quarter-waves conflict free)
 
+// STAGED: all three weight matrices are copied into LDS first (coalesced 16-byte loads issued before anything depends on t -- the
+// copies overlap the schedule / feature arithmetic), and every dot product then reads LDS.  The first version read its rows from
+// global memory inside the dependent loops: 32-42 us per launch (profiles/r04a_lorenz*_kernel_stats.csv), most of what the fused
+// step had saved.  Same operations in the same order either way.
+// sum_j w[j] v[j], accumulated in index order (time_embed_kernel's loop).  VEC: both operands are 16-byte aligned LDS rows with
+// n % 4 == 0 -- 16-byte reads, eight products in flight (a scalar loop pays the LDS latency once per term: 256 x ~100 cycles)
+template <bool VEC>
+__device__ __forceinline__ float s1_dot(const float* w, const float* v, int n) {
+    float acc = 0.f;
+    if (VEC) {
+#pragma unroll 2
+        for (int j = 0; j < n; j += 8) {
+            const float4 a0 = *reinterpret_cast<const float4*>(w + j), b0 = *reinterpret_cast<const float4*>(v + j);
+            float4 a1 = a0, b1 = b0;
+            const bool two = j + 4 < n;
+            if (two) { a1 = *reinterpret_cast<const float4*>(w + j + 4); b1 = *reinterpret_cast<const float4*>(v + j + 4); }
+            acc += a0.x * b0.x; acc += a0.y * b0.y; acc += a0.z * b0.z; acc += a0.w * b0.w;
+            if (two) { acc += a1.x * b1.x; acc += a1.y * b1.y; acc += a1.z * b1.z; acc += a1.w * b1.w; }
+        }
+    } else {
+        for (int j = 0; j < n; ++j) acc += w[j] * v[j];
+    }
+    return acc;
+}
+
+template <bool STAGED>
 __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     const float* __restrict__ table, int row_len, int64_t* istep, const float* __restrict__ t_dev, int nt, int alpha_kind, float eta,
     float k, int sigma_kind, const float* __restrict__ freqs, int nf, const float* __restrict__ w0, const float* __restrict__ b0,
     int hidden, const float* __restrict__ w2, const float* __restrict__ b2, int e, const float* __restrict__ wp,
     const float* __restrict__ bp, int cp, float* __restrict__ out_coef, int64_t* out_step, float* __restrict__ mod) {
+    extern __shared__ __attribute__((aligned(16))) float s1_dyn[];
     __shared__ float tv[2];
-    __shared__ float feat[2][S1_MAX_FEAT];
-    __shared__ float hid[2][S1_MAX_HIDDEN];
-    __shared__ float emb[2][S1_MAX_E];
+    __shared__ __attribute__((aligned(16))) float feat[2][S1_MAX_FEAT];
+    __shared__ __attribute__((aligned(16))) float hid[2][S1_MAX_HIDDEN];
+    __shared__ __attribute__((aligned(16))) float emb[2][S1_MAX_E];
     const int tid = threadIdx.x;
+    const int nin = 2 * nf;
+    // row strides of the staged copies
+    const int ld0 = nin + S1_PAD, ld2 = hidden + S1_PAD, ldp = e + S1_PAD;
+    float* s0 = s1_dyn;
+    float* s2 = s0 + hidden * ld0;
+    float* sp = s2 + e * ld2;
+    if (STAGED) {
+        // (nin, hidden, e are multiples of 4 and the matrices 16-byte aligned: checked by the launcher)
+        auto stage = [&](const float* __restrict__ src, float* dst, int rows, int cols, int ld) {
+            const int q = cols >> 2, total = rows * q;
+            for (int i = tid; i < total; i += S1_THREADS) {
+                const int r = i / q, c4 = i - r * q;
+                *reinterpret_cast<float4*>(dst + r * ld + 4 * c4) = *reinterpret_cast<const float4*>(src + (int64_t)r * cols + 4 * c4);
+            }
+        };
+        stage(w0, s0, hidden, nin, ld0);
+        stage(w2, s2, e, hidden, ld2);
+        stage(wp, sp, cp, e, ldp);
+    }
+    // the bias vectors and frequencies too: a global load inside one of the dependent phases below costs a round trip each time it
+    // is reached (the projection loop paid one per output: 24 x ~0.7 us of the first staged version's 17-20 us)
+    float* sb0 = STAGED ? sp + cp * ldp : s1_dyn;
+    float* sb2 = sb0 + hidden;
+    float* sbp = sb2 + e;
+    float* sfr = sbp + cp;
+    for (int i = tid; i < hidden; i += S1_THREADS) sb0[i] = b0[i];
+    for (int i = tid; i < e; i += S1_THREADS) sb2[i] = b2[i];
+    for (int i = tid; i < cp; i += S1_THREADS) sbp[i] = bp ? bp[i] : 0.f;
+    for (int i = tid; i < nf; i += S1_THREADS) sfr[i] = freqs[i];
     int64_t step = 0;
     if (table) step = istep[0];
     if (tid < nt) {
@@ -57,37 +114,50 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     // time_embed_kernel's arithmetic, both times side by side
     for (int i = tid; i < nt * nf; i += S1_THREADS) {
         const int it = i / nf, j = i - it * nf;
-        const float ang = freqs[j] * tv[it];
+        const float ang = sfr[j] * tv[it];
         feat[it][j] = cosf(ang);
         feat[it][nf + j] = sinf(ang);
     }
     __syncthreads();
-    const int nin = 2 * nf;
     for (int i = tid; i < nt * hidden; i += S1_THREADS) {
         const int it = i / hidden, hh = i - it * hidden;
-        float acc = 0.f;
-        const float* wr = w0 + (int64_t)hh * nin;
-        for (int j = 0; j < nin; ++j) acc += wr[j] * feat[it][j];
-        hid[it][hh] = sda_act(SDA_ACT_SILU, acc + b0[hh]);
+        const float* wr = STAGED ? s0 + hh * ld0 : w0 + (int64_t)hh * nin;
+        const float acc = s1_dot<STAGED>(wr, feat[it], nin);
+        hid[it][hh] = sda_act(SDA_ACT_SILU, acc + sb0[hh]);
     }
     __syncthreads();
     for (int i = tid; i < nt * e; i += S1_THREADS) {
         const int it = i / e, o = i - it * e;
-        float acc = 0.f;
-        const float* wr = w2 + (int64_t)o * hidden;
-        for (int j = 0; j < hidden; ++j) acc += wr[j] * hid[it][j];
-        emb[it][o] = acc + b2[o];
+        const float* wr = STAGED ? s2 + o * ld2 : w2 + (int64_t)o * hidden;
+        const float acc = s1_dot<STAGED>(wr, hid[it], hidden);
+        emb[it][o] = acc + sb2[o];
     }
     __syncthreads();
-    // linear_small_kernel's arithmetic: one wavefront per output, lanes stride the input features, shuffle-reduce
+    // linear_small_kernel's arithmetic: one wavefront per output, lanes stride the input features, shuffle-reduce.  With e <= 32
+    // input features the upper half-wave only ever adds zeros there, so a wave serves TWO outputs, one per half (lane 0's / lane
+    // 32's reduction tree touches its own half only from the 16-lane step on: identical sums).
     const int lane = tid & 63, wave = tid >> 6;
-    for (int g = wave; g < nt * cp; g += S1_THREADS / 64) {
-        const int it = g / cp, o = g - it * cp;
-        const float* wr = wp + (int64_t)o * e;
-        float acc = 0.f;
-        for (int i = lane; i < e; i += 64) acc += emb[it][i] * wr[i];
-        acc = sda_wave_sum(acc);
-        if (lane == 0) mod[g] = acc + (bp ? bp[o] : 0.f);
+    if (e <= 32) {
+        const int half = lane >> 5, l32 = lane & 31;
+        for (int g0 = 2 * wave; g0 < nt * cp; g0 += 2 * (S1_THREADS / 64)) {
+            const int g = g0 + half;
+            const bool live = g < nt * cp;
+            const int it = live ? g / cp : 0, o = live ? g - it * cp : 0;
+            const float* wr = STAGED ? sp + o * ldp : wp + (int64_t)o * e;
+            float acc = (live && l32 < e) ? emb[it][l32] * wr[l32] : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) acc += __shfl_down(acc, off, SDA_WAVE);
+            if (l32 == 0 && live) mod[g] = acc + sbp[o];
+        }
+    } else {
+        for (int g = wave; g < nt * cp; g += S1_THREADS / 64) {
+            const int it = g / cp, o = g - it * cp;
+            const float* wr = STAGED ? sp + o * ldp : wp + (int64_t)o * e;
+            float acc = 0.f;
+            for (int i = lane; i < e; i += 64) acc += emb[it][i] * wr[i];
+            acc = sda_wave_sum(acc);
+            if (lane == 0) mod[g] = acc + sbp[o];
+        }
     }
     if (table && tid == 0) istep[0] = step + 1;            // (after the read above: this workgroup is the step counter's only reader)
 }
@@ -101,8 +171,23 @@ extern "C" int sda_step1d_prologue(const float* table, int row_len, int64_t* ist
     if (table ? (!istep || row_len < 5 || nt != 2) : (!t_dev || nt < 1 || nt > 2)) return SDA_E_BADARG;
     if (alpha_kind < 0 || alpha_kind > 2 || sigma_kind < 0 || sigma_kind > 2) return SDA_E_BADARG;
     if (2 * nf > S1_MAX_FEAT || hidden > S1_MAX_HIDDEN || e > S1_MAX_E) return SDA_E_UNSUPPORTED;
-    hipLaunchKernelGGL(step1d_prologue_kernel, dim3(1), dim3(S1_THREADS), 0, (hipStream_t)stream, table, row_len, istep, t_dev, nt,
-                       alpha_kind, eta, k, sigma_kind, freqs, nf, w0, b0, hidden, w2, b2, e, wp, bp, cp, out_coef, out_step, mod);
+    const int nin = 2 * nf;
+    const int64_t vecs = 4LL * (hidden + e + cp + nf);                                       // staged biases + frequencies (both variants)
+    const int64_t lds = vecs + 4LL * ((int64_t)hidden * (nin + S1_PAD) + (int64_t)e * (hidden + S1_PAD) + (int64_t)cp * (e + S1_PAD));
+    const bool aligned = !(nin & 3) && !(hidden & 3) && !(e & 3) &&
+                         !(((uintptr_t)w0 | (uintptr_t)w2 | (uintptr_t)wp) & 15);
+    if (aligned && lds <= 140 * 1024) {
+        static bool raised[SDA_MAX_DEVICES];
+        const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(step1d_prologue_kernel<true>), 140 * 1024, raised);
+        if (rc != SDA_OK) return rc;
+        hipLaunchKernelGGL(step1d_prologue_kernel<true>, dim3(1), dim3(S1_THREADS), (size_t)lds, (hipStream_t)stream, table, row_len, istep,
+                           t_dev, nt, alpha_kind, eta, k, sigma_kind, freqs, nf, w0, b0, hidden, w2, b2, e, wp, bp, cp, out_coef, out_step,
+                           mod);
+    } else {
+        if (vecs > 48 * 1024) return SDA_E_UNSUPPORTED;
+        hipLaunchKernelGGL(step1d_prologue_kernel<false>, dim3(1), dim3(S1_THREADS), (size_t)vecs, (hipStream_t)stream, table, row_len, istep, t_dev,
+                           nt, alpha_kind, eta, k, sigma_kind, freqs, nf, w0, b0, hidden, w2, b2, e, wp, bp, cp, out_coef, out_step, mod);
+    }
     return sda_launch_status();
 }
 
