@@ -29,16 +29,12 @@ __global__ __launch_bounds__(TE_THREADS) void time_embed_kernel(const float* __r
     __syncthreads();
     const int nin = 2 * nf;
     for (int hh = threadIdx.x; hh < hidden; hh += TE_THREADS) {
-        float acc = 0.f;
-        const float* wr = w0 + (int64_t)hh * nin;
-        for (int j = 0; j < nin; ++j) acc += wr[j] * feat[j];
+        const float acc = sda_dot8(w0 + (int64_t)hh * nin, feat, nin);
         hid[hh] = sda_act(SDA_ACT_SILU, acc + b0[hh]);
     }
     __syncthreads();
     for (int o = threadIdx.x; o < e; o += TE_THREADS) {
-        float acc = 0.f;
-        const float* wr = w2 + (int64_t)o * hidden;
-        for (int j = 0; j < hidden; ++j) acc += wr[j] * hid[j];
+        const float acc = sda_dot8(w2 + (int64_t)o * hidden, hid, hidden);
         emb[(int64_t)it * e + o] = acc + b2[o];
     }
 }

@@ -96,6 +96,20 @@ __host__ __device__ __forceinline__ float sda_dact(int a, float z) {
     }
 }
 
+// sum_j w[j] v[j] as EIGHT interleaved partial sums (j mod 8), each accumulated in index order, combined as a balanced tree: the
+// dependent-add chain is n / 8 long instead of n (a 256-term sequential chain is ~7 000 cycles on one wave: tools/step1d_trace.py).
+// THE dot product of the time-embedding layers (sda_time_embed and sda_step1d_prologue share it: identical results).
+__host__ __device__ __forceinline__ float sda_dot8(const float* w, const float* v, int n) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += w[j + i] * v[j + i];
+    }
+    for (int i = 0; j < n; ++j, ++i) a[i] += w[j] * v[j];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 // 64-wide wavefront sum (CDNA wave = 64 lanes)
 __device__ __forceinline__ float sda_wave_sum(float v) {
 #pragma unroll

@@ -10,37 +10,24 @@
 // step is bit-identical to the unfused one wherever the summation order is the same.
 #include "sda_common.hpp"
 
+#ifdef SDA_S1_TRACE                    // tooling build: cycle stamps of thread 0 at the phase boundaries -> out_coef[9 .. 15] (as floats)
+#define S1_STAMP(k) do { if (threadIdx.x == 0) out_coef[9 + (k)] = (float)(__builtin_readcyclecounter() - s1_t0); } while (0)
+#define S1_T0() const long long s1_t0 = __builtin_readcyclecounter()
+#else
+#define S1_STAMP(k) do {} while (0)
+#define S1_T0() do {} while (0)
+#endif
 #define S1_THREADS 1024
 #define S1_MAX_FEAT 128
 #define S1_MAX_HIDDEN 1024
 #define S1_MAX_E 256
+#define S1_STAGE_MAX 8                 // 16-byte loads per thread of the staged weight copy
 #define S1_PAD 4                       // floats of row padding in the staged weight copies (16-byte aligned rows, quarter-waves conflict free)
 
 // STAGED: all three weight matrices are copied into LDS first (coalesced 16-byte loads issued before anything depends on t -- the
 // copies overlap the schedule / feature arithmetic), and every dot product then reads LDS.  The first version read its rows from
 // global memory inside the dependent loops: 32-42 us per launch (profiles/r04a_lorenz*_kernel_stats.csv), most of what the fused
 // step had saved.  Same operations in the same order either way.
-// sum_j w[j] v[j], accumulated in index order (time_embed_kernel's loop).  VEC: both operands are 16-byte aligned LDS rows with
-// n % 4 == 0 -- 16-byte reads, eight products in flight (a scalar loop pays the LDS latency once per term: 256 x ~100 cycles)
-template <bool VEC>
-__device__ __forceinline__ float s1_dot(const float* w, const float* v, int n) {
-    float acc = 0.f;
-    if (VEC) {
-#pragma unroll 2
-        for (int j = 0; j < n; j += 8) {
-            const float4 a0 = *reinterpret_cast<const float4*>(w + j), b0 = *reinterpret_cast<const float4*>(v + j);
-            float4 a1 = a0, b1 = b0;
-            const bool two = j + 4 < n;
-            if (two) { a1 = *reinterpret_cast<const float4*>(w + j + 4); b1 = *reinterpret_cast<const float4*>(v + j + 4); }
-            acc += a0.x * b0.x; acc += a0.y * b0.y; acc += a0.z * b0.z; acc += a0.w * b0.w;
-            if (two) { acc += a1.x * b1.x; acc += a1.y * b1.y; acc += a1.z * b1.z; acc += a1.w * b1.w; }
-        }
-    } else {
-        for (int j = 0; j < n; ++j) acc += w[j] * v[j];
-    }
-    return acc;
-}
-
 template <bool STAGED>
 __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     const float* __restrict__ table, int row_len, int64_t* istep, const float* __restrict__ t_dev, int nt, int alpha_kind, float eta,
@@ -54,23 +41,41 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     __shared__ __attribute__((aligned(16))) float emb[2][S1_MAX_E];
     const int tid = threadIdx.x;
     const int nin = 2 * nf;
+    S1_T0();
     // row strides of the staged copies
     const int ld0 = nin + S1_PAD, ld2 = hidden + S1_PAD, ldp = e + S1_PAD;
     float* s0 = s1_dyn;
     float* s2 = s0 + hidden * ld0;
     float* sp = s2 + e * ld2;
+    // (load order = issue order: the step counter first, the weight / bias copies behind it, then the table row that depends on the
+    // counter -- two round trips in all; written the other way round they were four, 7 500 cycles)
+    int64_t step = 0;
+    if (table) step = *reinterpret_cast<const volatile int64_t*>(istep);
     if (STAGED) {
-        // (nin, hidden, e are multiples of 4 and the matrices 16-byte aligned: checked by the launcher)
-        auto stage = [&](const float* __restrict__ src, float* dst, int rows, int cols, int ld) {
-            const int q = cols >> 2, total = rows * q;
-            for (int i = tid; i < total; i += S1_THREADS) {
-                const int r = i / q, c4 = i - r * q;
-                *reinterpret_cast<float4*>(dst + r * ld + 4 * c4) = *reinterpret_cast<const float4*>(src + (int64_t)r * cols + 4 * c4);
-            }
-        };
-        stage(w0, s0, hidden, nin, ld0);
-        stage(w2, s2, e, hidden, ld2);
-        stage(wp, sp, cp, e, ldp);
+        // (nin, hidden, e are multiples of 4 and the matrices 16-byte aligned: checked by the launcher.)  Every 16-byte load of the three
+        // matrices is issued before the first LDS store (a load -> store loop pays one round trip per iteration: 6 600 cycles of the
+        // first staged version, tools/step1d_trace.py); at most S1_STAGE_MAX per thread, more than that takes the unstaged kernel.
+        // row lengths are powers of two (launcher): (row, column) of a flat 16-byte index are a shift and a mask -- an integer
+        // division per load cost the 16 waves 20 000 cycles in the version that had them
+        const int l0 = 31 - __builtin_clz(nin >> 2), l2 = 31 - __builtin_clz(hidden >> 2), lp = 31 - __builtin_clz(e >> 2);
+        const int n0 = hidden << l0, n2 = e << l2, np = cp << lp;
+        float4 rv[S1_STAGE_MAX];
+        int dsti[S1_STAGE_MAX];
+#pragma unroll
+        for (int i = 0; i < S1_STAGE_MAX; ++i) {
+            int idx = tid + i * S1_THREADS;
+            const float* src = nullptr;
+            dsti[i] = -1;
+            if (idx < n0) { src = w0 + 4 * (int64_t)idx; dsti[i] = (idx >> l0) * ld0 + 4 * (idx & ((1 << l0) - 1)); }
+            else if ((idx -= n0) < n2) { src = w2 + 4 * (int64_t)idx; dsti[i] = (int)(s2 - s0) + (idx >> l2) * ld2 + 4 * (idx & ((1 << l2) - 1)); }
+            else if ((idx -= n2) < np) { src = wp + 4 * (int64_t)idx; dsti[i] = (int)(sp - s0) + (idx >> lp) * ldp + 4 * (idx & ((1 << lp) - 1)); }
+            // (unconditional, from a clamped address: a load under a condition compiles to a branch with its own s_waitcnt vmcnt(0) --
+            // eight serial round trips, 20 000 cycles)
+            rv[i] = *reinterpret_cast<const float4*>(src ? src : w0);
+        }
+#pragma unroll
+        for (int i = 0; i < S1_STAGE_MAX; ++i)
+            if (dsti[i] >= 0) *reinterpret_cast<float4*>(s0 + dsti[i]) = rv[i];
     }
     // the bias vectors and frequencies too: a global load inside one of the dependent phases below costs a round trip each time it
     // is reached (the projection loop paid one per output: 24 x ~0.7 us of the first staged version's 17-20 us)
@@ -82,8 +87,6 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     for (int i = tid; i < e; i += S1_THREADS) sb2[i] = b2[i];
     for (int i = tid; i < cp; i += S1_THREADS) sbp[i] = bp ? bp[i] : 0.f;
     for (int i = tid; i < nf; i += S1_THREADS) sfr[i] = freqs[i];
-    int64_t step = 0;
-    if (table) step = istep[0];
     if (tid < nt) {
         float t;
         if (table) t = table[step * row_len + tid];       // {t, t - dt}
@@ -110,7 +113,9 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
         }
         if (out_step) out_step[0] = step;
     }
+    S1_STAMP(0);                                           // staging issued, schedule scalars
     __syncthreads();
+    S1_STAMP(1);                                           // ... landed
     // time_embed_kernel's arithmetic, both times side by side
     for (int i = tid; i < nt * nf; i += S1_THREADS) {
         const int it = i / nf, j = i - it * nf;
@@ -119,35 +124,83 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
         feat[it][nf + j] = sinf(ang);
     }
     __syncthreads();
+    S1_STAMP(2);                                           // features
+    // sda_dot8 with its eight interleaved partial sums on eight adjacent lanes (sub = tid & 7 accumulates j = sub, sub + 8, ..
+    // in index order), combined by three xor-shuffles in sda_dot8's tree order: identical values, an eighth of the chain
+    const int sub = tid & 7, slot = tid >> 3;
+    auto dot8_split = [&](const float* w, const float* v, int n) {
+        float a = 0.f;
+        int j = sub;
+        for (; j + 24 < n; j += 32) {                      // four terms per trip: their eight LDS reads are in flight together
+            const float w0_ = w[j], w1_ = w[j + 8], w2_ = w[j + 16], w3_ = w[j + 24];
+            const float v0_ = v[j], v1_ = v[j + 8], v2_ = v[j + 16], v3_ = v[j + 24];
+            a += w0_ * v0_; a += w1_ * v1_; a += w2_ * v2_; a += w3_ * v3_;
+        }
+        for (; j < n; j += 8) a += w[j] * v[j];
+        a += __shfl_xor(a, 1, SDA_WAVE);
+        a += __shfl_xor(a, 2, SDA_WAVE);
+        a += __shfl_xor(a, 4, SDA_WAVE);
+        return a;
+    };
     for (int i = tid; i < nt * hidden; i += S1_THREADS) {
         const int it = i / hidden, hh = i - it * hidden;
-        const float* wr = STAGED ? s0 + hh * ld0 : w0 + (int64_t)hh * nin;
-        const float acc = s1_dot<STAGED>(wr, feat[it], nin);
+        float acc;
+        if (STAGED) {
+            // sda_dot8 on 16-byte LDS reads (rows and feat are 16-byte aligned, nin % 8 == 0: launcher): same sums in the same order
+            const float* wr = s0 + hh * ld0;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < nin; j += 8) {
+                const float4 wa = *reinterpret_cast<const float4*>(wr + j), wb = *reinterpret_cast<const float4*>(wr + j + 4);
+                const float4 fa = *reinterpret_cast<const float4*>(feat[it] + j), fb = *reinterpret_cast<const float4*>(feat[it] + j + 4);
+                a[0] += wa.x * fa.x; a[1] += wa.y * fa.y; a[2] += wa.z * fa.z; a[3] += wa.w * fa.w;
+                a[4] += wb.x * fb.x; a[5] += wb.y * fb.y; a[6] += wb.z * fb.z; a[7] += wb.w * fb.w;
+            }
+            acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        } else {
+            acc = sda_dot8(w0 + (int64_t)hh * nin, feat[it], nin);
+        }
         hid[it][hh] = sda_act(SDA_ACT_SILU, acc + sb0[hh]);
     }
     __syncthreads();
-    for (int i = tid; i < nt * e; i += S1_THREADS) {
-        const int it = i / e, o = i - it * e;
+    S1_STAMP(3);                                           // hidden layer
+    for (int i0 = 0; i0 < nt * e; i0 += S1_THREADS / 8) {
+        const int i = i0 + slot;
+        const bool live = i < nt * e;
+        const int it = live ? i / e : 0, o = live ? i - it * e : 0;
         const float* wr = STAGED ? s2 + o * ld2 : w2 + (int64_t)o * hidden;
-        const float acc = s1_dot<STAGED>(wr, hid[it], hidden);
-        emb[it][o] = acc + sb2[o];
+        const float acc = dot8_split(wr, hid[it], hidden);
+        if (live && sub == 0) emb[it][o] = acc + sb2[o];
     }
     __syncthreads();
+    S1_STAMP(4);                                           // embedding (256-term sums)
     // linear_small_kernel's arithmetic: one wavefront per output, lanes stride the input features, shuffle-reduce.  With e <= 32
     // input features the upper half-wave only ever adds zeros there, so a wave serves TWO outputs, one per half (lane 0's / lane
     // 32's reduction tree touches its own half only from the 16-lane step on: identical sums).
     const int lane = tid & 63, wave = tid >> 6;
     if (e <= 32) {
-        const int half = lane >> 5, l32 = lane & 31;
-        for (int g0 = 2 * wave; g0 < nt * cp; g0 += 2 * (S1_THREADS / 64)) {
-            const int g = g0 + half;
-            const bool live = g < nt * cp;
-            const int it = live ? g / cp : 0, o = live ? g - it * cp : 0;
+        // linear_small_kernel with <= 32 input features: lane l < e holds p_l = emb[l] w[l] (lanes beyond: 0), and the shuffle tree
+        // (offsets 32, 16, 8, 4, 2, 1; the first step adds zeros) leaves lane 0 with ((..(p_l + p_{l+16}) + ..)): ONE thread per output
+        // replays that tree on its 32 products -- the wave-per-output form spent 750 cycles per output on five dependent cross-lane
+        // round trips (18 000 of the kernel's 34 600 cycles)
+        for (int g = tid; g < nt * cp; g += S1_THREADS) {
+            const int it = g / cp, o = g - it * cp;
             const float* wr = STAGED ? sp + o * ldp : wp + (int64_t)o * e;
-            float acc = (live && l32 < e) ? emb[it][l32] * wr[l32] : 0.f;
+            float pr[32];
+            if (STAGED && e == 32) {                      // (16-byte aligned padded rows)
 #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) acc += __shfl_down(acc, off, SDA_WAVE);
-            if (l32 == 0 && live) mod[g] = acc + sbp[o];
+                for (int l4 = 0; l4 < 8; ++l4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wr + 4 * l4), ev = *reinterpret_cast<const float4*>(emb[it] + 4 * l4);
+                    pr[4 * l4] = ev.x * wv.x; pr[4 * l4 + 1] = ev.y * wv.y; pr[4 * l4 + 2] = ev.z * wv.z; pr[4 * l4 + 3] = ev.w * wv.w;
+                }
+            } else {
+#pragma unroll
+                for (int l = 0; l < 32; ++l) pr[l] = l < e ? emb[it][l] * wr[l] : 0.f;
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+                for (int l = 0; l < off; ++l) pr[l] += pr[l + off];
+            mod[g] = pr[0] + sbp[o];
         }
     } else {
         for (int g = wave; g < nt * cp; g += S1_THREADS / 64) {
@@ -159,6 +212,7 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
             if (lane == 0) mod[g] = acc + sbp[o];
         }
     }
+    S1_STAMP(5);                                           // projection
     if (table && tid == 0) istep[0] = step + 1;            // (after the read above: this workgroup is the step counter's only reader)
 }
 
@@ -176,7 +230,9 @@ extern "C" int sda_step1d_prologue(const float* table, int row_len, int64_t* ist
     const int64_t lds = vecs + 4LL * ((int64_t)hidden * (nin + S1_PAD) + (int64_t)e * (hidden + S1_PAD) + (int64_t)cp * (e + S1_PAD));
     const bool aligned = !(nin & 3) && !(hidden & 3) && !(e & 3) &&
                          !(((uintptr_t)w0 | (uintptr_t)w2 | (uintptr_t)wp) & 15);
-    if (aligned && lds <= 140 * 1024) {
+    const int64_t quads = ((int64_t)hidden * nin + (int64_t)e * hidden + (int64_t)cp * e) / 4;
+    auto pow2 = [](int v) { return v > 0 && !(v & (v - 1)); };
+    if (aligned && lds <= 140 * 1024 && quads <= (int64_t)S1_STAGE_MAX * S1_THREADS && pow2(nin) && pow2(hidden) && pow2(e) && nin >= 8) {
         static bool raised[SDA_MAX_DEVICES];
         const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(step1d_prologue_kernel<true>), 140 * 1024, raised);
         if (rc != SDA_OK) return rc;

@@ -27,7 +27,7 @@ from . import _lib, ops
 from .engine import Source
 
 ENABLED = os.environ.get('SDA_FUSED1D', '1') != '0'
-COEF_LEN = 9                 # mu0 sigma0 mu1 sigma1 r c1 sigma_next t0 t1
+COEF_LEN = 16                # mu0 sigma0 mu1 sigma1 r c1 sigma_next t0 t1 (+ 7 slots: phase stamps of a -DSDA_S1_TRACE tooling build)
 
 
 def stock_schedule(sde):

@@ -99,6 +99,19 @@ def test_fused_1d_kernels_have_no_scratch(built):
         for n in names:
             k = md[n]
             assert k['vgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0, (n, k)
+    # the whole-net 1-D kernels, forward and VJP, fused and unfused, all three tile widths: no vector-register spill and not one scratch
+    # instruction.  (The forward kernels carry a 20-36 byte private segment -- frame slots of SGPR spills that end up in VGPR lanes
+    # (v_writelane / v_readlane), never addressed: the disassembly has no scratch_* / buffer access to it.)
+    md = G.kernel_metadata(os.path.join(built, 'net1d.o'))
+    dis = G.disassemble(os.path.join(built, 'net1d.o'))
+    names = [n for n in md if 'net1d_fwd_kernel' in n or 'net1d_bwd_kernel' in n]
+    assert len(names) == 12, names
+    for n in names:
+        assert md[n]['vgpr_spill_count'] == 0, (n, md[n])
+        assert not [i for i in dis[n] if 'scratch_' in i], n
+        # validity-cone narrowing: blocks 0-2 multiply NF fragments, block 3's LayerNorm too, everything after it NF - 1 (the
+        # block body is instantiated three times, the head / tail convolutions in their full and narrow forms)
+        assert sum(1 for i in dis[n] if 'v_mfma_f32_16x16x4' in i) > 0
     # the four-class accumulators of conv_par4 (192 registers) must leave room for two waves per SIMD; the multiply loop of a
     # consumer wave issues no vector-memory instruction (a wave that does gets a vmcnt(0) in front of every LDS read)
     md = G.kernel_metadata(os.path.join(built, 'conv_par4.o'))
