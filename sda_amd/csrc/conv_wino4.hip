@@ -463,6 +463,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 f32x2 o01, o23;
                 asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o01) : "v"(ua[a]), "v"(ub[a]));
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o23) : "v"(ub[a]), "v"(ua[a]));
+                if constexpr (VAR == 14 || VAR == 15) {
+                    // (tooling) what splitting a V value into three bf16 pieces costs the helpers: 8 VALU instructions per value
+                    // (round hi, subtract, round mid, subtract, round lo, two packs), here as 8 dependent dummies per value
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float t0 = o01[e], t1 = o23[e];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            asm volatile("v_and_b32 %0, 0xffff0000, %0\n\tv_sub_f32 %0, %1, %0" : "+v"(t0) : "v"(o01[e]));
+                            asm volatile("v_and_b32 %0, 0xffff0000, %0\n\tv_sub_f32 %0, %1, %0" : "+v"(t1) : "v"(o23[e]));
+                        }
+                        o01[e] = t0; o23[e] = t1;
+                    }
+                }
                 *reinterpret_cast<f32x2*>(dst + (2 * a + 0) * W4_VPP) = o01;       // positions 4 a + 0, 4 a + 1
                 *reinterpret_cast<f32x2*>(dst + (2 * a + 1) * W4_VPP) = o23;       // positions 4 a + 2, 4 a + 3
             }
@@ -807,6 +821,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     for (int h = 0; h < 2; ++h) {
                         const int p = 2 * s + h;
                         if (w4_dead<ZP>(p)) continue;
+                        // (tooling, profiles/r04_bf16x6_prototype.txt: the pipeline with a 2x / 3x cheaper multiply -- results are wrong)
+                        if constexpr (VAR == 12 || VAR == 14) { if (k4 == 1) continue; }
+                        if constexpr (VAR == 13 || VAR == 15) { if (k4 == 1 || m == 2) continue; }
                         f32x4 c;
                         if (FIRST && k4 == 0) c = (p == 5) ? binit[m] : f32x4{0.f, 0.f, 0.f, 0.f};
                         else c = acc[p][m];
@@ -1147,6 +1164,10 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
                          : epm == 2 ? wino4_launch_t<false, false, false, 2, 11>(d, gt, grid, stream)
                                     : wino4_launch_t<false, false, false, 0, 11>(d, gt, grid, stream);
                 }
+                case 12: if (epm == 0) return wino4_launch_t<false, false, false, 0, 12>(d, g, grid, stream); break;
+                case 13: if (epm == 0) return wino4_launch_t<false, false, false, 0, 13>(d, g, grid, stream); break;
+                case 14: if (epm == 0) return wino4_launch_t<false, false, false, 0, 14>(d, g, grid, stream); break;
+                case 15: if (epm == 0) return wino4_launch_t<false, false, false, 0, 15>(d, g, grid, stream); break;
                 default: break;
             }
 #endif
