@@ -98,7 +98,8 @@ res = {'tag': args.tag, 'kernel': f'{args.kernel} (dominant' + (', full 16-posit
                      'FETCH_SIZE reports 0.500 of the true bytes for 16 B/lane and 4 B/lane streams and for conv_wino4 halo rows alike '
                      '(128-B lines), WRITE_SIZE 1.00-1.10 (calibration on known byte counts in the kernel\'s own access shapes: '
                      'tools/fetch_calib.hip, profiles/r03_w4_traffic.txt)'}
-json.dump(res, open(os.path.join(dst, f'{args.tag}_traffic.json'), 'w'), indent=1)
+if any(glob.glob(f'{src}/{w}/**/*counter_collection.csv', recursive=True) for w in ('sq', 'grbm', 'fetch', 'write')):
+    json.dump(res, open(os.path.join(dst, f'{args.tag}_traffic.json'), 'w'), indent=1)       # (kernel-trace-only runs: no counter file)
 for name, calls, tot, a, p in stats[:8]:
     print(f'{p:6.2f} %  {calls:6d} x {a / 1e3:9.4f} ms  {name[:100]}')
 print(json.dumps(res, indent=1))
