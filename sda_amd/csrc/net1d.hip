@@ -19,6 +19,10 @@
 //     the backward kernel reads it for its halo columns too (written by the neighbours' forward).
 //   * input / output are addressed through (image, channel, position) strides: the (B, L, C) <-> (B, C, L) transposes of
 //     MCScoreWrapper (sda/score.py:104-110) cost nothing on either side.
+//   * whole-sequence tiles (round 4): with zero padding a tile that holds an ENTIRE sequence needs no halo at all -- what lies beyond
+//     its edge columns is the padding itself.  When every sequence fits 16 NF <= 80 columns and there are enough sequences to fill the
+//     chip (the reference's evaluation job: 1024 trajectories of 65 positions, experiments/lorenz/eval.py:72-84) a workgroup takes one
+//     whole sequence: 80 columns per sequence instead of two 64-column tiles (1.8x halo recompute), nothing narrowed (`whole`).
 //   * the validity cone (round 4): convolution i (0 = first of the launch) is only exact -- and only needed -- on columns
 //     [1 + i, NC - 1 - i).  The 16-column MFMA fragments are therefore mapped so that the LAST one holds the tile's outermost
 //     columns [0, 8) + [NC - 8, NC) (fragment nf < NF - 1 holds columns 8 + 16 nf ..): from convolution 7 on nothing in it is needed
@@ -36,7 +40,7 @@
 // -- and a lane's four D values of a column are consecutive channels too: one ds_write_b128 per column on the way back.
 #define N1_LD 68
 #define N1_MAXC 64
-#define N1_MAXCOL 66                   // 64 conv columns + one edge column per side
+#define N1_MAXCOL 82                   // up to 80 conv columns + one edge column per side
 
 typedef float n1_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -57,6 +61,7 @@ extern "C" int sda_n1_trace_read(long long* out, int reset) {
 struct N1Ctx {
     int tid, lane, wave, kq, li, co0, n, p0, H, len;
     int col_outer;                     // this lane's column in the OUTER fragment: li < 8 ? li : NC - 16 + li
+    int col_shift;                     // 0; 8 for whole-sequence tiles (fragment nf = columns 16 nf ..: the identity map)
     unsigned wlane;                    // this lane's element offset inside a [tap][64][64] weight slab: row 16 kq, column co0 + li
     bool circular;
 };
@@ -75,7 +80,7 @@ __device__ __forceinline__ int n1_pos(const N1Ctx& c, int j, bool& inside) {
 // conv-output column of this lane in fragment nf: inner fragments are consecutive runs from column 8, the last fragment is the tile's
 // outermost 8 + 8 columns (see "validity cone" above)
 template <int NF>
-__device__ __forceinline__ int n1_col(const N1Ctx& c, int nf) { return nf < NF - 1 ? 8 + 16 * nf + c.li : c.col_outer; }
+__device__ __forceinline__ int n1_col(const N1Ctx& c, int nf) { return nf < NF - 1 ? 8 - c.col_shift + 16 * nf + c.li : c.col_outer; }
 
 // all A fragments of convolution `conv` for this wave: wreg[tap][cb] = W[conv][tap][k = 16 kq + cb][m = co0 + li]
 // (one batch of loads: a per-lane offset against wave-uniform bases)
@@ -121,8 +126,8 @@ template <int NF>
 __device__ __forceinline__ void n1_load_tile(const float* src, int64_t sn, int64_t sc, int64_t sx, int channels, const N1Ctx& c,
                                              float* tile, float scale = 1.f) {
     constexpr int NC = 16 * NF;
-    const int j = c.lane, sub = c.wave;
-    if (j < NC) {
+    const int sub = c.wave;
+    for (int j = c.lane; j < NC; j += 64) {                // (80-column whole-sequence tiles: two passes)
         bool inside;
         const int ps = n1_pos(c, j, inside);
         const float* base = src + (int64_t)c.n * sn;
@@ -185,7 +190,7 @@ __device__ __forceinline__ void n1_ctx(N1Ctx& c, const sda_net1d_desc& d, int pt
     c.co0 = 16 * c.wave; c.n = blockIdx.x / ptiles; c.p0 = (blockIdx.x - c.n * ptiles) * tp;
     c.H = 2 * d.nblocks + 2; c.len = d.len; c.circular = d.circular != 0;
     c.wlane = (unsigned)(16 * c.kq * 64 + c.co0 + c.li);
-    c.col_outer = 0;                   // (set by the kernels: needs NC)
+    c.col_outer = 0; c.col_shift = 0;  // (set by the kernels: needs NC)
 }
 
 // biases of every convolution and the modulation vectors of every block -> LDS (once per launch; read per block as one 16-byte
@@ -227,19 +232,20 @@ __device__ __forceinline__ void n1_stage_vectors(const sda_net1d_desc& d, const 
 // sda_gauss_cotangent / sda_obs_subsample_adjoint (= sda_obs_subsample_guidance) without a launch of their own, in their arithmetic
 // (same operations in the same order: bit-identical to the unfused path).
 template <int NF, bool FUSED>
-__global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
+__global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp, int whole) {
     constexpr int NC = 16 * NF;
     constexpr int NR = NF > 1 ? NF - 1 : 1;                                   // fragments once the outer one has left the validity cone
     using FULL = std::integral_constant<int, NF>;
     using NARROW = std::integral_constant<int, NR>;
-    __shared__ __attribute__((aligned(16))) float tin[N1_MAXCOL * N1_LD];     // input of the next convolution, [column jj <-> conv column jj - 1][channel]
-    __shared__ __attribute__((aligned(16))) float tz[N1_MAXCOL * N1_LD];      // act(z) between the two convolutions of a block
+    __shared__ __attribute__((aligned(16))) float tin[(NC + 2) * N1_LD];      // input of the next convolution, [column jj <-> conv column jj - 1][channel]
+    __shared__ __attribute__((aligned(16))) float tz[(NC + 2) * N1_LD];       // act(z) between the two convolutions of a block
     __shared__ __attribute__((aligned(16))) float sb[(2 + 2 * SDA_NET1D_MAXB) * 64];
     __shared__ __attribute__((aligned(16))) float smod[SDA_NET1D_MAXB * 64];
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
     c.col_outer = c.li < 8 ? c.li : NC - 16 + c.li;
+    if (whole) { c.H = 0; c.col_outer = NC - 16 + c.li; c.col_shift = 8; }     // columns 16 nf + li: no halo, nothing to narrow
     N1_T0();
     float wA[3][16], wB[3][16];
     n1_load_w(d.w, 0, c, wA);
@@ -381,17 +387,18 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
     {
         int k = 0;
         const int nb = d.nblocks;
-        for (; k < nb && k < 3; ++k) block(k, FULL{}, FULL{});
+        for (; k < nb && (k < 3 || whole); ++k) block(k, FULL{}, FULL{});
         if (k < nb) { block(k, FULL{}, NARROW{}); ++k; }
         for (; k < nb; ++k) block(k, NARROW{}, NARROW{});
     }
     // ---- tail convolution (index 1 + 2 nblocks) -> out (own columns, through the output strides)
     n1_f32x4 o[NF];
-    if (d.nblocks >= 4) {
+    const int nbn = whole ? 0 : d.nblocks;                 // (whole-sequence tiles: every column is needed to the end)
+    if (nbn >= 4) {
         n1_store_tile<NF, NR>(a, inside, rok, c, tin);
         __syncthreads();
         n1_mm<NF, NR>(wB, tin, boff, o);
-    } else if (d.nblocks == 3) {
+    } else if (nbn == 3) {
         n1_store_tile<NF, NF>(a, inside, rok, c, tin);
         __syncthreads();
         n1_mm<NF, NR>(wB, tin, boff, o);
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         n1_mm<NF, NF>(wB, tin, boff, o);
     }
     // (own columns of a fragment that was not multiplied do not exist: with nblocks >= 3 the halo is >= 8 columns)
-    const int nfo = d.nblocks >= 3 ? NR : NF;
+    const int nfo = nbn >= 3 ? NR : NF;
     if constexpr (!FUSED) {
         const n1_f32x4 bt = *reinterpret_cast<const n1_f32x4*>(sb + (1 + 2 * d.nblocks) * 64 + cbase);
         float* ob = d.out + (int64_t)c.n * d.out_sn;
@@ -465,18 +472,19 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
 // reads x on its own columns only);  2: writes out and this tile's sum of out^2 into partial[image][tile] (a fixed slot: the
 // Langevin step size of sda/score.py:259 stays deterministic) for sda_pc_correct / sda_pc_correct_keyed.
 template <int NF, bool FUSED>
-__global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp) {
+__global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, const sda_net1d_fuse f, int ptiles, int tp, int whole) {
     constexpr int NC = 16 * NF;
     constexpr int NR = NF > 1 ? NF - 1 : 1;
     using FULL = std::integral_constant<int, NF>;
     using NARROW = std::integral_constant<int, NR>;
-    __shared__ __attribute__((aligned(16))) float tg[N1_MAXCOL * N1_LD];
-    __shared__ __attribute__((aligned(16))) float tq[N1_MAXCOL * N1_LD];
+    __shared__ __attribute__((aligned(16))) float tg[(NC + 2) * N1_LD];
+    __shared__ __attribute__((aligned(16))) float tq[(NC + 2) * N1_LD];
     __shared__ __attribute__((aligned(16))) float smod[SDA_NET1D_MAXB * 64];
     __shared__ float red[2 * 4 * NC];
     N1Ctx c;
     n1_ctx(c, d, ptiles, tp);
     c.col_outer = c.li < 8 ? c.li : NC - 16 + c.li;
+    if (whole) { c.H = 0; c.col_outer = NC - 16 + c.li; c.col_shift = 8; }
     float wA[3][16], wB[3][16];
     n1_load_w(d.w, 0, c, wA);
     if (c.tid < 2 * N1_MAXC) {
@@ -594,18 +602,19 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
     {
         int kk = 0;
         const int nb = d.nblocks;
-        for (; kk < nb && kk < 2; ++kk) block(nb - 1 - kk, FULL{}, FULL{}, FULL{});
+        for (; kk < nb && (kk < 2 || whole); ++kk) block(nb - 1 - kk, FULL{}, FULL{}, FULL{});
         if (kk < nb) { block(nb - 1 - kk, FULL{}, FULL{}, NARROW{}); ++kk; }            // kk = 2: the next block multiplies narrow
         if (kk < nb) { block(nb - 1 - kk, FULL{}, NARROW{}, NARROW{}); ++kk; }          // kk = 3
         for (; kk < nb; ++kk) block(nb - 1 - kk, NARROW{}, NARROW{}, NARROW{});
     }
     // ---- head^T (index 1 + 2 nblocks) -> input gradient (own columns, through the output strides)
     n1_f32x4 o[NF];
-    if (d.nblocks >= 4) {
+    const int nbn = whole ? 0 : d.nblocks;
+    if (nbn >= 4) {
         n1_store_tile<NF, NR>(g, inside, rok, c, tg);
         __syncthreads();
         n1_mm<NF, NR>(wB, tg, boff, o);
-    } else if (d.nblocks == 3) {
+    } else if (nbn == 3) {
         n1_store_tile<NF, NF>(g, inside, rok, c, tg);
         __syncthreads();
         n1_mm<NF, NR>(wB, tg, boff, o);
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
         __syncthreads();
         n1_mm<NF, NF>(wB, tg, boff, o);
     }
-    const int nfo = d.nblocks >= 3 ? NR : NF;
+    const int nfo = nbn >= 3 ? NR : NF;
     if constexpr (!FUSED) {
         float* ob = d.out + (int64_t)c.n * d.out_sn;
 #pragma unroll
@@ -696,27 +705,43 @@ static int net1d_nf(const sda_net1d_desc* d) {
     return 2;
 }
 
-template <bool BWD, int NF, bool FUSED>
-static void net1d_launch_nf(const sda_net1d_desc* d, const sda_net1d_fuse& f, dim3 grid, int ptiles, int tp, hipStream_t stream) {
-    if (BWD) hipLaunchKernelGGL((net1d_bwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp);
-    else hipLaunchKernelGGL((net1d_fwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp);
+// the tiling of a launch: columns per tile (16 nf), own positions per tile, tiles per sequence, and whether a tile is a WHOLE sequence
+// (zero padding, <= 80 positions: no halo) -- chosen when that costs fewer (rounds of workgroups over the CUs) x (columns per tile)
+#define N1_MAXNF 5
+static int net1d_tiling(const sda_net1d_desc* d, int* tp, int* ptiles, int* whole) {
+    static const int wforce = getenv("SDA_NET1D_WHOLE") ? atoi(getenv("SDA_NET1D_WHOLE")) : -1;      // A/B runs: 0 never, 1 whenever possible
+    *whole = 0;
+    const int nf = net1d_nf(d);
+    int64_t cost_t = -1;
+    if (nf) {
+        *tp = 16 * nf - 2 * (2 * d->nblocks + 2);
+        *ptiles = (d->len + *tp - 1) / *tp;
+        cost_t = (((int64_t)d->n * *ptiles + 255) / 256) * nf;
+    }
+    if (!d->circular && d->len <= 16 * N1_MAXNF && wforce != 0) {
+        int nfw = (d->len + 15) / 16;
+        if (nfw < 2) nfw = 2;
+        const int64_t cost_w = (((int64_t)d->n + 255) / 256) * nfw;
+        if (cost_t < 0 || cost_w < cost_t || wforce == 1) {
+            *whole = 1; *tp = 16 * nfw; *ptiles = 1;
+            return nfw;
+        }
+    }
+    return nf;
 }
 
-// the tiling of a launch: columns per tile (16 nf), own positions per tile, tiles per sequence
-static int net1d_tiling(const sda_net1d_desc* d, int* tp, int* ptiles) {
-    const int nf = net1d_nf(d);
-    if (!nf) return 0;
-    *tp = 16 * nf - 2 * (2 * d->nblocks + 2);
-    *ptiles = (d->len + *tp - 1) / *tp;
-    return nf;
+template <bool BWD, int NF, bool FUSED>
+static void net1d_launch_nf(const sda_net1d_desc* d, const sda_net1d_fuse& f, dim3 grid, int ptiles, int tp, int whole, hipStream_t stream) {
+    if (BWD) hipLaunchKernelGGL((net1d_bwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp, whole);
+    else hipLaunchKernelGGL((net1d_fwd_kernel<NF, FUSED>), grid, dim3(256), 0, stream, *d, f, ptiles, tp, whole);
 }
 
 template <bool BWD, bool FUSED>
 static int net1d_launch(const sda_net1d_desc* d, const sda_net1d_fuse* fu, hipStream_t stream) {
     const int rc = net1d_check(d, BWD);
     if (rc != SDA_OK) return rc;
-    int tp, ptiles;
-    const int nf = net1d_tiling(d, &tp, &ptiles);
+    int tp, ptiles, whole;
+    const int nf = net1d_tiling(d, &tp, &ptiles, &whole);
     if (!nf) return SDA_E_UNSUPPORTED;
     if ((int64_t)d->n * ptiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     sda_net1d_fuse f = {};
@@ -737,9 +762,12 @@ static int net1d_launch(const sda_net1d_desc* d, const sda_net1d_fuse* fu, hipSt
         }
     }
     const dim3 grid((unsigned)(d->n * ptiles));
-    if (nf == 2) net1d_launch_nf<BWD, 2, FUSED>(d, f, grid, ptiles, tp, stream);
-    else if (nf == 3) net1d_launch_nf<BWD, 3, FUSED>(d, f, grid, ptiles, tp, stream);
-    else net1d_launch_nf<BWD, 4, FUSED>(d, f, grid, ptiles, tp, stream);
+    switch (nf) {
+        case 2: net1d_launch_nf<BWD, 2, FUSED>(d, f, grid, ptiles, tp, whole, stream); break;
+        case 3: net1d_launch_nf<BWD, 3, FUSED>(d, f, grid, ptiles, tp, whole, stream); break;
+        case 4: net1d_launch_nf<BWD, 4, FUSED>(d, f, grid, ptiles, tp, whole, stream); break;
+        default: net1d_launch_nf<BWD, 5, FUSED>(d, f, grid, ptiles, tp, whole, stream); break;
+    }
     return sda_launch_status();
 }
 
@@ -756,6 +784,6 @@ extern "C" int sda_net1d_bwd_fused(const sda_net1d_desc* d, const sda_net1d_fuse
 // tiles per sequence of the launch that would serve `d` (the row length of the fused backward's partial sums), <= 0: unsupported
 extern "C" int sda_net1d_tiles(const sda_net1d_desc* d) {
     if (!d || d->len < 1 || d->nblocks < 0 || d->nblocks > SDA_NET1D_MAXB) return SDA_E_UNSUPPORTED;
-    int tp, ptiles;
-    return net1d_tiling(d, &tp, &ptiles) ? ptiles : SDA_E_UNSUPPORTED;
+    int tp, ptiles, whole;
+    return net1d_tiling(d, &tp, &ptiles, &whole) ? ptiles : SDA_E_UNSUPPORTED;
 }

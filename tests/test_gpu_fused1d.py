@@ -158,3 +158,31 @@ def test_fused_step_prologue_and_keyed_correction_are_bit_identical_to_the_kerne
     ops.pc_correct(xa, eps, z, B, partial, 0.25, 0.0, coef_dev=coef, nchunk=3)
     ops.pc_correct_keyed(xb, eps, B, partial, 3, 0.25, coef, 1234567, 40, draw, 2, 1)
     assert torch.equal(xa, xb)
+
+
+@pytest.mark.parametrize('B,L,C,blocks', [(300, 65, 3, 3), (300, 40, 3, 3), (520, 20, 5, 2), (1024, 65, 3, 3), (270, 80, 40, 1), (300, 12, 3, 3)])
+def test_whole_sequence_tiles_forward_and_vjp_vs_oracle(dev, B, L, C, blocks):
+    """Zero-padded sequences that fit one tile and come in numbers that fill the chip run as WHOLE-sequence tiles (no halo, csrc/net1d.hip:
+    NF = ceil(L / 16) = 5, 3, 2, 5, 5, 2 here): the network and its input VJP against the float64 oracle (sda/nn.py:184-206)."""
+    from sda_amd.experiments.lorenz import make_global_score
+    torch.manual_seed(80 + L)
+    net = make_global_score(channels=C, hidden_blocks=(blocks,)).to(dev)
+    eps_o = oracle_eps_from_module(net, 'wrap1d')
+    x = torch.randn(B, L, C)
+    t = torch.tensor(0.55)
+    g = torch.randn(B, L, C)
+    rows = slice(B - 6, B)
+    xo = x[rows].double().requires_grad_(True)
+    eo = eps_o(xo, t.double(), torch.float64)
+    ref_v, = torch.autograd.grad(eo, xo, g[rows].double())
+    xd = x.to(dev).requires_grad_(True)
+    out = net(xd, t.to(dev))
+    vjp, = torch.autograd.grad(out, xd, g.to(dev))
+    assert_close(out[rows].detach().cpu(), eo.detach(), TOL, what='eps (whole-sequence tiles)')
+    assert_close(vjp[rows].cpu(), ref_v, TOL, what='vjp (whole-sequence tiles)')
+    # rows do not couple: the first rows alone (a batch that takes the halo-tiled kernels) give the same values
+    xs = x[:3].to(dev).requires_grad_(True)
+    o3 = net(xs, t.to(dev))
+    v3, = torch.autograd.grad(o3, xs, g[:3].to(dev))
+    assert_close(out[:3].detach().cpu(), o3.detach().cpu(), 1e-5, what='whole-sequence vs halo tiles (eps)')
+    assert_close(vjp[:3].cpu(), v3.cpu(), 1e-5, what='whole-sequence vs halo tiles (vjp)')

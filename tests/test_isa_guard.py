@@ -105,7 +105,7 @@ def test_fused_1d_kernels_have_no_scratch(built):
     md = G.kernel_metadata(os.path.join(built, 'net1d.o'))
     dis = G.disassemble(os.path.join(built, 'net1d.o'))
     names = [n for n in md if 'net1d_fwd_kernel' in n or 'net1d_bwd_kernel' in n]
-    assert len(names) == 12, names
+    assert len(names) == 16, names                      # NF = 2 .. 5 (5: whole-sequence tiles of 65 .. 80 positions) x fwd / VJP x fused / unfused
     for n in names:
         assert md[n]['vgpr_spill_count'] == 0, (n, md[n])
         assert not [i for i in dis[n] if 'scratch_' in i], n
