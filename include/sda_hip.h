@@ -313,6 +313,35 @@ int sda_row_ln(const float* x, int rows, int f, float eps, int unbiased, float* 
 int sda_row_ln_bwd(const float* gh, const float* x, int rows, int f, const float* mean, const float* rstd, int unbiased,
                    const float* res, float* gx, void* stream);
 
+/* A whole ResMLP (sda/nn.py:31-71: per width step an optional Linear, then x + Lin2(act(Lin1(LN(x))))) in ONE launch, and its
+ * input VJP in one more (csrc/mlp1d.hip; ABI v7) -- the Lorenz local score kernel of experiments/lorenz/utils.py:45-59.
+ * The network is a list of GEMMs in forward order: kind 0 = nn.Linear; kind 1 = first half of a residual block (LayerNorm -> Linear ->
+ * activation), always followed by kind 2 = its second half (Linear + residual).  Widths <= 128.
+ *   w:    every GEMM's matrix zero padded to [pad(out)][pad(in)] row major, pad(f) = 16 if f <= 16 else 128, at float offset w_off[g]
+ *         (sda_mlp_fwd: torch's [out][in] weight; sda_mlp_bwd: its transpose [pad(in)][pad(out)], same offsets table);
+ *   bias: [pad(out)] zero padded at b_off[g] (forward only);  offsets are multiples of 4 floats, the buffers 16-byte aligned.
+ *   x / out: row-major (rows, features) with row strides x_ld / out_ld (sda_mlp_bwd: x = cotangent rows of width out_f[last], out =
+ *         input-gradient rows of width in_f[0]).
+ *   a_save / z_save [nres][rows][save_ld >= 128], mean_save / rstd_save [nres][rows] (block strides save_stride / stat_stride): written by
+ *         the forward when non-NULL (all four or none), read by the VJP.
+ * SDA_E_UNSUPPORTED outside the kernel's range (callers run the per-layer kernels sda_linear / sda_row_ln). */
+#define SDA_MLP_MAXG 32
+typedef struct sda_mlp_desc {
+    int32_t rows, ngemm;
+    int32_t act, unbiased;
+    float eps;
+    int32_t kind[SDA_MLP_MAXG];
+    int32_t in_f[SDA_MLP_MAXG], out_f[SDA_MLP_MAXG];
+    int32_t w_off[SDA_MLP_MAXG], b_off[SDA_MLP_MAXG];
+    const float* w; const float* bias;
+    const float* x; int64_t x_ld;
+    float* out; int64_t out_ld;
+    float* a_save; float* z_save; int64_t save_stride; int32_t save_ld;
+    float* mean_save; float* rstd_save; int64_t stat_stride;
+} sda_mlp_desc;
+int sda_mlp_fwd(const sda_mlp_desc* d, void* stream);
+int sda_mlp_bwd(const sda_mlp_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * MCScoreNet.fold (sda/score.py:155-164): selective gather, NOT an overlap-add.
  *   s: [b][nw][(2k+1)*c][hw] -> out: [b][nw+2k][c][hw]

@@ -99,6 +99,26 @@ class Net1dDesc(Structure):
     ]
 
 
+MLP_MAXG = 32
+
+
+class MlpDesc(Structure):
+    """Mirror of `struct sda_mlp_desc` (include/sda_hip.h)."""
+    _fields_ = [
+        ('rows', c_int32), ('ngemm', c_int32),
+        ('act', c_int32), ('unbiased', c_int32),
+        ('eps', c_float),
+        ('kind', c_int32 * MLP_MAXG),
+        ('in_f', c_int32 * MLP_MAXG), ('out_f', c_int32 * MLP_MAXG),
+        ('w_off', c_int32 * MLP_MAXG), ('b_off', c_int32 * MLP_MAXG),
+        ('w', c_fp), ('bias', c_fp),
+        ('x', c_fp), ('x_ld', c_int64),
+        ('out', c_fp), ('out_ld', c_int64),
+        ('a_save', c_fp), ('z_save', c_fp), ('save_stride', c_int64), ('save_ld', c_int32),
+        ('mean_save', c_fp), ('rstd_save', c_fp), ('stat_stride', c_int64),
+    ]
+
+
 class Net1dFuse(Structure):
     """Mirror of `struct sda_net1d_fuse` (include/sda_hip.h)."""
     _fields_ = [
@@ -145,6 +165,8 @@ SIGNATURES = {
     'sda_time_embed': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear_small': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),
+    'sda_mlp_fwd': (c_int, [POINTER(MlpDesc), c_void_p]),
+    'sda_mlp_bwd': (c_int, [POINTER(MlpDesc), c_void_p]),
     'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),

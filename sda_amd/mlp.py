@@ -8,13 +8,14 @@ Per residual block ``x + Lin2(act(Lin1(LN(x))))`` the forward is three launches 
 activation applied to its input and the residual in its epilogue) and saves ``x``, the LN statistics and the
 pre-activation ``z``; the input gradient is three launches again (gy W2 * act'(z), gz W1, LN backward + g).
 """
-from typing import List
+import os
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
 from torch import Tensor
 
-from . import ops
+from . import _lib, ops
 
 
 def _rows(x: Tensor):
@@ -26,6 +27,124 @@ def _is_res_block(block) -> bool:
     from .nn import LayerNorm
     return (isinstance(block, nn.Sequential) and len(block) == 4 and isinstance(block[0], LayerNorm)
             and isinstance(block[1], nn.Linear) and isinstance(block[3], nn.Linear) and block[0].dim == -1)
+
+
+# ---------------------------------------------------------------------------------------------- whole-MLP kernels (csrc/mlp1d.hip)
+FUSED = os.environ.get('SDA_MLP_FUSED', '1') != '0'
+_MLP_W = 128
+
+
+def _pad(f: int) -> int:
+    return 16 if f <= 16 else _MLP_W
+
+
+class _FusedPlan:
+    """The GEMM list of a ResMLP for sda_mlp_fwd / sda_mlp_bwd and its packed (zero-padded) weights, forward and transposed; rebuilt when
+    a parameter changes (pointer / version keys, as the convolution caches)."""
+
+    def __init__(self, layers):
+        from .nn import LN_UNBIASED, activation_id
+        self.gemms = []                 # (kind, in_f, out_f, Linear)
+        acts, epss = set(), set()
+        for layer in layers:
+            if isinstance(layer, nn.Linear):
+                self.gemms.append((0, layer.in_features, layer.out_features, layer))
+            else:
+                ln, l1, act_m, l2 = layer[0], layer[1], layer[2], layer[3]
+                acts.add(activation_id(act_m))
+                epss.add(float(ln.eps))
+                self.gemms.append((1, l1.in_features, l1.out_features, l1))
+                self.gemms.append((2, l2.in_features, l2.out_features, l2))
+        self.ok = (1 <= len(self.gemms) <= _lib.MLP_MAXG and len(acts) <= 1 and len(epss) <= 1 and
+                   all(i <= _MLP_W and o <= _MLP_W and lin.bias is not None for _, i, o, lin in self.gemms) and
+                   all(i == o for k, i, o, _ in self.gemms if k) and
+                   all(self.gemms[j][1] == self.gemms[j - 1][2] for j in range(1, len(self.gemms))))
+        self.act = acts.pop() if acts else 0
+        self.eps = epss.pop() if epss else 1e-5
+        self.unbiased = LN_UNBIASED
+        self.nres = sum(1 for k, *_ in self.gemms if k == 2)
+        self._key = None
+
+    def _pack(self):
+        key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.bias._version, str(lin.weight.device)) for *_, lin in self.gemms)
+        if key == self._key:
+            return
+        dev = self.gemms[0][3].weight.device
+        w_off, b_off, wn, bn = [], [], 0, 0
+        for _, i, o, _lin in self.gemms:
+            w_off.append(wn); b_off.append(bn)
+            wn += _pad(i) * _pad(o)
+            bn += _pad(o)
+        wf = torch.zeros(wn, device=dev, dtype=torch.float32)
+        wb = torch.zeros(wn, device=dev, dtype=torch.float32)
+        bias = torch.zeros(bn, device=dev, dtype=torch.float32)
+        for (k, i, o, lin), wo, bo in zip(self.gemms, w_off, b_off):
+            W = lin.weight.detach().to(torch.float32)
+            wf[wo:wo + _pad(i) * _pad(o)].view(_pad(o), _pad(i))[:o, :i] = W
+            wb[wo:wo + _pad(i) * _pad(o)].view(_pad(i), _pad(o))[:i, :o] = W.t()
+            bias[bo:bo + o] = lin.bias.detach()
+        self.wf, self.wb, self.bias, self.w_off, self.b_off, self._key = wf, wb, bias, w_off, b_off, key
+
+    def desc(self, rows: int, backward: bool):
+        self._pack()
+        d = _lib.MlpDesc()
+        d.rows, d.ngemm, d.act, d.unbiased, d.eps = rows, len(self.gemms), self.act, int(self.unbiased), self.eps
+        for g, (k, i, o, _lin) in enumerate(self.gemms):
+            d.kind[g], d.in_f[g], d.out_f[g], d.w_off[g], d.b_off[g] = k, i, o, self.w_off[g], self.b_off[g]
+        d.w = (self.wb if backward else self.wf).data_ptr()
+        d.bias = self.bias.data_ptr()
+        return d
+
+
+def _fused_plan(layers) -> Optional['_FusedPlan']:
+    """The cached plan of this layer list (kept on its first module), or None when the whole-MLP kernels do not take it."""
+    if not FUSED or not layers:
+        return None
+    holder = layers[0]
+    key = tuple(id(l) for l in layers)
+    hit = holder.__dict__.get('_sda_mlp_plan')
+    if hit is None or hit[0] != key:
+        hit = (key, _FusedPlan(layers))
+        holder.__dict__['_sda_mlp_plan'] = hit
+    return hit[1] if hit[1].ok else None
+
+
+class _FusedMLPFunction(torch.autograd.Function):
+    """The whole layer chain in one launch (sda_mlp_fwd) and its input VJP in one more (sda_mlp_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, plan: _FusedPlan):
+        need = ctx.needs_input_grad[0]
+        rows = x.shape[0]
+        d = plan.desc(rows, False)
+        out = torch.empty(rows, plan.gemms[-1][2], device=x.device, dtype=torch.float32)
+        d.x, d.x_ld, d.out, d.out_ld = x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0)
+        saves = None
+        if need and plan.nres:
+            a_s = torch.empty(plan.nres, rows, _MLP_W, device=x.device, dtype=torch.float32)
+            z_s = torch.empty_like(a_s)
+            m_s = torch.empty(plan.nres, rows, device=x.device, dtype=torch.float32)
+            r_s = torch.empty_like(m_s)
+            d.a_save, d.z_save, d.save_stride, d.save_ld = a_s.data_ptr(), z_s.data_ptr(), rows * _MLP_W, _MLP_W
+            d.mean_save, d.rstd_save, d.stat_stride = m_s.data_ptr(), r_s.data_ptr(), rows
+            saves = (a_s, z_s, m_s, r_s)
+        ops.mlp_launch(d, False)
+        ctx.plan, ctx.saves, ctx.rows = plan, saves, rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        plan, rows = ctx.plan, ctx.rows
+        g = g.contiguous()
+        d = plan.desc(rows, True)
+        gx = torch.empty(rows, plan.gemms[0][1], device=g.device, dtype=torch.float32)
+        d.x, d.x_ld, d.out, d.out_ld = g.data_ptr(), g.stride(0), gx.data_ptr(), gx.stride(0)
+        if ctx.saves is not None:
+            a_s, z_s, m_s, r_s = ctx.saves
+            d.a_save, d.z_save, d.save_stride, d.save_ld = a_s.data_ptr(), z_s.data_ptr(), rows * _MLP_W, _MLP_W
+            d.mean_save, d.rstd_save, d.stat_stride = m_s.data_ptr(), r_s.data_ptr(), rows
+        ops.mlp_launch(d, True)
+        return gx, None
 
 
 class _MLPFunction(torch.autograd.Function):
@@ -79,7 +198,12 @@ class _MLPFunction(torch.autograd.Function):
 def _run(layers, x: Tensor) -> Tensor:
     ops._dev(x)
     xr = _rows(x)
-    out = _MLPFunction.apply(xr, list(layers))
+    layers = list(layers)
+    plan = _fused_plan(layers)
+    if plan is not None and xr.is_cuda and xr.shape[0] > 0 and xr.stride(1) == 1 and xr.shape[1] == plan.gemms[0][1]:
+        out = _FusedMLPFunction.apply(xr, plan)
+        return out.reshape(*x.shape[:-1], out.shape[-1])
+    out = _MLPFunction.apply(xr, layers)
     return out.reshape(*x.shape[:-1], out.shape[-1])
 
 

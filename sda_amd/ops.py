@@ -445,6 +445,22 @@ def row_ln_bwd(gh: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, unbiased: bool
                                           int(unbiased), _ptr(res), gx.data_ptr(), _stream()), 'sda_row_ln_bwd')
 
 
+def mlp_launch(d: '_lib.MlpDesc', backward: bool):
+    """A whole ResMLP in one launch (csrc/mlp1d.hip), forward or input VJP; see include/sda_hip.h."""
+    lib = _lib.load()
+    fn, name = (lib.sda_mlp_bwd, 'sda_mlp_bwd') if backward else (lib.sda_mlp_fwd, 'sda_mlp_fwd')
+    prof = conv_profile
+    if prof is None:
+        _lib.check(fn(ctypes.byref(d), _stream()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(fn(ctypes.byref(d), _stream()), name)
+    e1.record()
+    flops = 2.0 * d.rows * sum(d.in_f[g] * d.out_f[g] for g in range(d.ngemm))
+    prof.records.append((e0, e1, flops, 'mlp_bwd' if backward else 'mlp_fwd'))
+
+
 # ------------------------------------------------------------------------------------------ fold / unfold adjoints
 
 def fold(s: Tensor, b: int, nw: int, k: int, c: int, hw: int, out: Tensor):

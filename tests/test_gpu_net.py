@@ -745,3 +745,43 @@ def test_nonlinear_masked_coupled_observations_without_autograd(dev):
         outs.append(sampler.result().clone())
     assert torch.isfinite(outs[0]).all()
     assert_close(outs[1].cpu(), outs[0].cpu(), 1e-5, what='graph replay with a non-linear observation')
+
+
+@pytest.mark.parametrize('rows,widths,act', [(61, (128,) * 5, 'SiLU'), (40000, (128,) * 5, 'SiLU'), (33000, (64, 128, 32), 'GELU'),
+                                              (7, (16, 16), 'ReLU'), (1000, (100,), 'ELU')])
+def test_whole_mlp_kernel_equals_layer_path_and_oracle(dev, rows, widths, act, monkeypatch):
+    """csrc/mlp1d.hip (a whole ResMLP, sda/nn.py:31-71, per launch; forward and input VJP) against the per-layer kernels (1e-5) and
+    the float64 oracle (1e-4): the Lorenz local kernel's shape (47 -> 5 x 128 -> 15, experiments/lorenz/utils.py:45-59) on both tile
+    sizes, mixed widths (padding to 16 / 128), every activation family, row counts that leave a ragged last tile."""
+    from sda_amd import mlp
+    from sda_amd.nn import ResMLP
+    from sda_amd.utils import ACTIVATIONS
+    torch.manual_seed(rows % 1000)
+    in_f, out_f = 47, 15
+    net = ResMLP(in_f, out_f, hidden_features=list(widths), activation=ACTIVATIONS[act]).to(dev)
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    cfg = O.ResMLPConfig(in_f, out_f, tuple(widths), act)
+    x = torch.randn(rows, in_f)
+    g = torch.randn(rows, out_f)
+    sl = slice(max(0, rows - 50), rows)
+    xo = x[sl].double().requires_grad_(True)
+    ro = O.resmlp_forward(sd, '', cfg, xo)
+    gref, = torch.autograd.grad(ro, xo, g[sl].double())
+
+    def run(fused):
+        monkeypatch.setattr(mlp, 'FUSED', fused)
+        xd = x.to(dev).requires_grad_(True)
+        out = net(xd)
+        gx, = torch.autograd.grad(out, xd, g.to(dev))
+        return out.detach(), gx
+    out_f_, gx_f = run(True)
+    out_l, gx_l = run(False)
+    monkeypatch.setattr(mlp, 'FUSED', True)
+    assert mlp._fused_plan(list(net)) is not None
+    assert_close(out_f_.cpu(), out_l.cpu(), 1e-5, what='fused vs per-layer forward')
+    assert_close(gx_f.cpu(), gx_l.cpu(), 1e-5, what='fused vs per-layer VJP')
+    assert_close(out_f_[sl].cpu(), ro.detach(), TOL, what='fused forward vs fp64 oracle')
+    assert_close(gx_f[sl].cpu(), gref, TOL, what='fused VJP vs fp64 oracle')
+    # no-grad call (no saves) gives the same output
+    with torch.no_grad():
+        assert torch.equal(net(x.to(dev)), out_f_)
