@@ -317,8 +317,10 @@ int sda_row_ln_bwd(const float* gh, const float* x, int rows, int f, const float
  * input VJP in one more (csrc/mlp1d.hip; ABI v7) -- the Lorenz local score kernel of experiments/lorenz/utils.py:45-59.
  * The network is a list of GEMMs in forward order: kind 0 = nn.Linear; kind 1 = first half of a residual block (LayerNorm -> Linear ->
  * activation), always followed by kind 2 = its second half (Linear + residual).  Widths <= 128.
- *   w:    every GEMM's matrix zero padded to [pad(out)][pad(in)] row major, pad(f) = 16 if f <= 16 else 128, at float offset w_off[g]
- *         (sda_mlp_fwd: torch's [out][in] weight; sda_mlp_bwd: its transpose [pad(in)][pad(out)], same offsets table);
+ *   w:    every GEMM's matrix Wp, zero padded to [M = pad(out)][K = pad(in)], pad(f) = 16 if f <= 16 else 128, at float offset w_off[g],
+ *         packed in MFMA lane order [slot M/16][q K/16][lane 64][4]: element e of lane (kq = lane >> 4, li = lane & 15) =
+ *         Wp[16 slot + li][(K/4) kq + 4 q + e]  (sda_mlp_fwd: Wp = torch's [out][in] weight; sda_mlp_bwd: Wp = its transpose, M = pad(in),
+ *         K = pad(out); same offsets table);
  *   bias: [pad(out)] zero padded at b_off[g] (forward only);  offsets are multiples of 4 floats, the buffers 16-byte aligned.
  *   x / out: row-major (rows, features) with row strides x_ld / out_ld (sda_mlp_bwd: x = cotangent rows of width out_f[last], out =
  *         input-gradient rows of width in_f[0]).

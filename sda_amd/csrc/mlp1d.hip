@@ -16,12 +16,28 @@
 // Roofline: the Lorenz local net is 0.34 MFLOP per window and direction; at 62 464 windows (eval.py's batch) 21.5 GFLOP = 0.14 ms of
 // fp32 MFMA time per direction -- MFMA-bound once the launches are gone.
 #include "sda_common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 #define ML_LD 132                      // LDS row stride (floats): 16-byte reads of consecutive rows land 4 banks apart
 #define ML_W 128                       // padded width
+#define ML_RL 20                       // floats per row line of the reduction exchange (16 used; 20: the 16 rows of a fragment hit 16 bank groups)
 
 typedef float ml_f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef SDA_ML_TRACE                    // tooling (tools/mlp_trace.py): per-phase cycle sums of workgroup 0 / thread 0
+__device__ long long ml_trace[16];
+#define ML_T0() long long ml_tl = __builtin_readcyclecounter()
+#define ML_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); ml_trace[k] += n_ - ml_tl; ml_tl = n_; } } while (0)
+extern "C" int sda_ml_trace_read(long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ml_trace), sizeof(long long) * 16) != hipSuccess) return SDA_E_BADARG;
+    if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ml_trace), z, sizeof(z)); }
+    return SDA_OK;
+}
+#else
+#define ML_T0() do {} while (0)
+#define ML_STAMP(k) do {} while (0)
+#endif
 
 struct MlCtx {
     int tid, lane, wave, kq, li;
@@ -32,15 +48,20 @@ struct MlCtx {
 static inline int ml_pad(int f) { return f <= 16 ? 16 : ML_W; }
 __device__ __forceinline__ int ml_padd(int f) { return f <= 16 ? 16 : ML_W; }
 
-// weights of GEMM fragment mf of this wave: wreg[s] = Wp[row = 16 (2 wave + mf) + li][KS kq + s], Wp = the padded [M][K] matrix at w
+// weights of GEMM fragment mf of this wave: wreg[s] = Wp[row = 16 (2 wave + mf) + li][KS kq + s], Wp = the padded [M][K] matrix.  In
+// memory the matrix is packed in LANE order -- [fragment slot 2 wave + mf][q][lane][4]: element e of lane (kq, li) = Wp[16 slot + li][KS kq +
+// 4 q + e] -- so every load instruction of a wave is one contiguous KiB.  (Read from the row-major matrix each instruction touched 64
+// different cache lines, 16 bytes of each, and the 64 KiB of a 128 x 128 layer do not survive in a 32 KiB L1 until the line's other
+// seven pieces are asked for: ~8x the bytes through the CU's L2 port, the kernel's bound in its first version -- 421 us per forward of the
+// eval.py batch against 137 us of fp32 MFMA time.)
 template <int KS>
 __device__ __forceinline__ void ml_load_w(const float* w, int K, int M, int mf, const MlCtx& c, float (&wreg)[32]) {
-    const int mrow = 16 * (2 * c.wave + mf) + c.li;
-    if (16 * (2 * c.wave + mf) < M) {                      // (wave uniform)
-        const ml_f32x4* src = reinterpret_cast<const ml_f32x4*>(w + (int64_t)mrow * K + KS * c.kq);
+    const int slot = 2 * c.wave + mf;
+    if (16 * slot < M) {                                   // (wave uniform)
+        const ml_f32x4* src = reinterpret_cast<const ml_f32x4*>(w) + (int64_t)slot * (KS / 4) * 64 + c.lane;
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
-            const ml_f32x4 v = src[q];
+            const ml_f32x4 v = src[q * 64];
             wreg[4 * q] = v[0]; wreg[4 * q + 1] = v[1]; wreg[4 * q + 2] = v[2]; wreg[4 * q + 3] = v[3];
         }
     }
@@ -57,19 +78,28 @@ __device__ __forceinline__ void ml_mm(const float (&wreg)[32], const float* tile
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[nf] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int CH = KS < 8 ? KS : 8;                    // K steps per operand chunk
+    constexpr int NCH = KS / CH;
+    // two operand sets: chunk j + 1 is read while chunk j multiplies (a single set exposed the LDS latency at every chunk boundary)
+    ml_f32x4 bv[2][NF][CH / 4];
 #pragma unroll
-    for (int s0 = 0; s0 < KS; s0 += CH) {
-        ml_f32x4 bv[NF][CH / 4];
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
+        for (int q = 0; q < CH / 4; ++q) bv[0][nf][q] = *reinterpret_cast<const ml_f32x4*>(brow + 16 * nf * ML_LD + 4 * q);
 #pragma unroll
-            for (int q = 0; q < CH / 4; ++q) bv[nf][q] = *reinterpret_cast<const ml_f32x4*>(brow + 16 * nf * ML_LD + s0 + 4 * q);
+    for (int j = 0; j < NCH; ++j) {
+        if (j + 1 < NCH) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int q = 0; q < CH / 4; ++q)
+                    bv[(j + 1) & 1][nf][q] = *reinterpret_cast<const ml_f32x4*>(brow + 16 * nf * ML_LD + (j + 1) * CH + 4 * q);
+        }
 #pragma unroll
         for (int e = 0; e < CH; ++e)
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
-                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s0 + e], bv[nf][e >> 2][e & 3], acc[nf], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);                 // (keeps one chunk of operands live)
+                acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * CH + e], bv[j & 1][nf][e >> 2][e & 3], acc[nf], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // (keeps two chunks of operands live, not all of them)
     }
 }
 
@@ -103,21 +133,20 @@ __device__ __forceinline__ void ml_store_tile(const ml_f32x4 (&v)[2][NF], int wi
     }
 }
 
-// sum over the features of every row: lane-local (2 fragments x 4), across the 4 lane groups, across the 4 waves
+// sum over the features of every row: lane-local (2 fragments x 4), then ONE exchange through LDS -- every (wave, lane group) writes its
+// partial of a row into that row's 16-float line, and each lane adds up the line of its rows (4 x 16-byte reads, a fixed tree).  (Two
+// cross-lane shuffles per row before the exchange were two more dependent LDS-crossbar round trips per reduction.)
 template <int NF>
 __device__ __forceinline__ void ml_rowsum(float (&s)[NF], float* red, const MlCtx& c) {
-    constexpr int NC = 16 * NF;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        s[nf] += __shfl_xor(s[nf], 16, 64);
-        s[nf] += __shfl_xor(s[nf], 32, 64);
-        if (c.kq == 0) red[c.wave * NC + 16 * nf + c.li] = s[nf];
-    }
+    for (int nf = 0; nf < NF; ++nf) red[(16 * nf + c.li) * ML_RL + 4 * c.wave + c.kq] = s[nf];
     __syncthreads();
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-        const int m = 16 * nf + c.li;
-        s[nf] = (red[m] + red[NC + m]) + (red[2 * NC + m] + red[3 * NC + m]);
+        const ml_f32x4* line = reinterpret_cast<const ml_f32x4*>(red + (16 * nf + c.li) * ML_RL);
+        const ml_f32x4 p0 = line[0], p1 = line[1], p2 = line[2], p3 = line[3];
+        const ml_f32x4 q = (p0 + p1) + (p2 + p3);
+        s[nf] = (q[0] + q[1]) + (q[2] + q[3]);
     }
 }
 
@@ -130,11 +159,23 @@ __device__ __forceinline__ void ml_ctx(MlCtx& c, const sda_mlp_desc& d, int nc) 
 template <int NF>
 __device__ __forceinline__ void ml_load_rows(const float* src, int64_t ld, int width, const MlCtx& c, float* tile, ml_f32x4 (&a)[2][NF]) {
     constexpr int NC = 16 * NF;
-    const int wp = ml_padd(width);
-    for (int i = c.tid; i < NC * wp; i += 256) {
-        const int r = i / wp, f = i - r * wp;
+    const int wp = ml_padd(width), lw = wp == 16 ? 4 : 7;
+    // (all loads first, unconditional from clamped addresses: a load under a condition is a branch with its own s_waitcnt -- 32 serial
+    // round trips, 35 000 cycles per tile in the first version, tools/mlp_trace.py)
+    constexpr int PER = NC * ML_W / 256;
+    float v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = c.tid + 256 * k, r = i >> lw, f = i & (wp - 1);
         const int64_t gr = c.row0 + r;
-        tile[r * ML_LD + f] = (gr < c.rows && f < width) ? src[gr * ld + f] : 0.f;
+        const bool ok = i < NC * wp && gr < c.rows && f < width;
+        v[k] = src[ok ? gr * ld + f : 0];
+        if (!ok) v[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = c.tid + 256 * k;
+        if (i < NC * wp) tile[(i >> lw) * ML_LD + (i & (wp - 1))] = v[k];
     }
     __syncthreads();
 #pragma unroll
@@ -148,20 +189,23 @@ __device__ __forceinline__ void ml_load_rows(const float* src, int64_t ld, int w
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-// (one workgroup per CU at NF = 4: the 64-row tile needs ~300 registers per lane; at two per CU it spilled 128-266 of them)
+// (NF = 4: the 64-row tile needs ~300 registers per lane -- one workgroup per CU; at two per CU it spilled 128-266 of them.  NF <= 2
+// fits 256 registers: two workgroups per CU, one's LayerNorm / epilogue phases under the other's multiplies.)
 template <int NF>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
+__global__ __launch_bounds__(256, NF <= 2 ? 2 : 1) void mlp_fwd_kernel(const sda_mlp_desc d) {
     constexpr int NC = 16 * NF;
     __shared__ __attribute__((aligned(16))) float tA[NC * ML_LD];
     __shared__ __attribute__((aligned(16))) float tB[NC * ML_LD];
-    __shared__ float red[2 * 4 * NC];
+    __shared__ __attribute__((aligned(16))) float red[2 * ML_RL * NC];
     MlCtx c;
     ml_ctx(c, d, NC);
     float w0[32], w1[32];
     ml_load_w_any(d.w + d.w_off[0], ml_padd(d.in_f[0]), ml_padd(d.out_f[0]), 0, c, w0);
     ml_load_w_any(d.w + d.w_off[0], ml_padd(d.in_f[0]), ml_padd(d.out_f[0]), 1, c, w1);
     ml_f32x4 a[2][NF];
+    ML_T0();
     ml_load_rows<NF>(d.x, d.x_ld, d.in_f[0], c, tA, a);
+    ML_STAMP(0);                                           // input rows
     const bool silu = d.act == SDA_ACT_SILU;
     int rb = 0;                                            // residual-block counter (index into the saves)
     for (int g = 0; g < d.ngemm; ++g) {
@@ -181,12 +225,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
             // ---- Linear: a <- W a + b
             ml_store_tile<NF>(a, d.in_f[g], c, tA);
             __syncthreads();
+            ML_STAMP(1);
             ml_gemm<NF>(w0, w1, nullptr, K, M, tA, c, acc, wn, Kn, Mn);
+            ML_STAMP(2);
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) a[mf][nf] = acc[mf][nf] + bias[mf];
             __syncthreads();                               // (tA is rewritten by the next layer's input)
+            ML_STAMP(4);
         } else if (d.kind[g] == 1) {
             // ---- residual block, first half: save a; u = LN(a); z = W1 u + b1 (saved); act(z) -> tB
             const int cw = d.in_f[g];
@@ -228,7 +275,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
                         s[nf] += (32 * c.wave + 16 * mf + 4 * c.kq + r < cw) ? dl * dl : 0.f;
                     }
             }
-            ml_rowsum<NF>(s, red + 4 * NC, c);
+            ml_rowsum<NF>(s, red + ML_RL * NC, c);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 rstd[nf] = __builtin_amdgcn_rsqf(s[nf] * inv_v + d.eps);
@@ -247,9 +294,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
                     }
                 }
             }
+            ML_STAMP(3);                                   // a_save, LayerNorm
             ml_store_tile<NF>(u, cw, c, tA);
             __syncthreads();
+            ML_STAMP(1);
             ml_gemm<NF>(w0, w1, nullptr, K, M, tA, c, acc, wn, Kn, Mn);
+            ML_STAMP(2);
             float* zs = d.z_save ? d.z_save + (int64_t)rb * d.save_stride : nullptr;
             auto epi = [&](auto SILU_) {
 #pragma unroll
@@ -268,11 +318,14 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
             };
             if (silu) epi(std::true_type{});
             else epi(std::false_type{});
+            ML_STAMP(4);                                   // z_save, activation
             ml_store_tile<NF>(acc, d.out_f[g], c, tB);
             __syncthreads();
+            ML_STAMP(1);
         } else {
             // ---- residual block, second half: a += W2 act(z) + b2
             ml_gemm<NF>(w0, w1, nullptr, K, M, tB, c, acc, wn, Kn, Mn);
+            ML_STAMP(2);
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -300,11 +353,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
 // d.w = the TRANSPOSED padded matrices ([in_pad][out_pad] per GEMM, same offsets table); x = cotangent rows (width out_f[last]), out =
 // input-gradient rows (width in_f[0]); the GEMM list is walked backwards.
 template <int NF>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d) {
+__global__ __launch_bounds__(256, NF <= 2 ? 2 : 1) void mlp_bwd_kernel(const sda_mlp_desc d) {
     constexpr int NC = 16 * NF;
     __shared__ __attribute__((aligned(16))) float tA[NC * ML_LD];
     __shared__ __attribute__((aligned(16))) float tB[NC * ML_LD];
-    __shared__ float red[2 * 4 * NC];
+    __shared__ __attribute__((aligned(16))) float red[2 * ML_RL * NC];
     MlCtx c;
     ml_ctx(c, d, NC);
     float w0[32], w1[32];
@@ -388,7 +441,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d) {
                 }
             }
             ml_rowsum<NF>(s1, red, c);
-            ml_rowsum<NF>(s2, red + 4 * NC, c);
+            ml_rowsum<NF>(s2, red + ML_RL * NC, c);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 const float av = s1[nf] * inv_c, bv = s2[nf] * inv_v;
@@ -446,17 +499,21 @@ template <bool BWD>
 static int mlp_launch(const sda_mlp_desc* d, hipStream_t stream) {
     const int rc = mlp_check(d, BWD);
     if (rc != SDA_OK) return rc;
-    // 64-row tiles when that still fills the chip twice over (two workgroups per CU), else 16-row tiles
-    const bool big = d->rows >= 64 * 512;
-    const int nc = big ? 64 : 16;
+    // rows per tile: 64 (one workgroup per CU) / 32 (two per CU) when that fills the chip, else 16-row tiles
+    static const int forced = getenv("SDA_MLP_NF") ? atoi(getenv("SDA_MLP_NF")) : 0;
+    int nf = d->rows >= 32 * 512 ? 2 : 1;
+    if (forced == 1 || forced == 2 || forced == 4) nf = forced;
+    const int nc = 16 * nf;
     const int64_t tiles = ((int64_t)d->rows + nc - 1) / nc;
     if (tiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     const dim3 grid((unsigned)tiles);
     if (BWD) {
-        if (big) hipLaunchKernelGGL(mlp_bwd_kernel<4>, grid, dim3(256), 0, stream, *d);
+        if (nf == 4) hipLaunchKernelGGL(mlp_bwd_kernel<4>, grid, dim3(256), 0, stream, *d);
+        else if (nf == 2) hipLaunchKernelGGL(mlp_bwd_kernel<2>, grid, dim3(256), 0, stream, *d);
         else hipLaunchKernelGGL(mlp_bwd_kernel<1>, grid, dim3(256), 0, stream, *d);
     } else {
-        if (big) hipLaunchKernelGGL(mlp_fwd_kernel<4>, grid, dim3(256), 0, stream, *d);
+        if (nf == 4) hipLaunchKernelGGL(mlp_fwd_kernel<4>, grid, dim3(256), 0, stream, *d);
+        else if (nf == 2) hipLaunchKernelGGL(mlp_fwd_kernel<2>, grid, dim3(256), 0, stream, *d);
         else hipLaunchKernelGGL(mlp_fwd_kernel<1>, grid, dim3(256), 0, stream, *d);
     }
     return sda_launch_status();

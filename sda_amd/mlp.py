@@ -78,10 +78,19 @@ class _FusedPlan:
         wf = torch.zeros(wn, device=dev, dtype=torch.float32)
         wb = torch.zeros(wn, device=dev, dtype=torch.float32)
         bias = torch.zeros(bn, device=dev, dtype=torch.float32)
+        def lane_order(Wp: Tensor) -> Tensor:
+            # [M][K] -> [slot M/16][q K/16][lane = 16 kq + li][4]: element e of lane (kq, li) = Wp[16 slot + li][(K/4) kq + 4 q + e]
+            M, K = Wp.shape
+            return Wp.view(M // 16, 16, 4, K // 16, 4).permute(0, 3, 2, 1, 4).contiguous().reshape(-1)
+
         for (k, i, o, lin), wo, bo in zip(self.gemms, w_off, b_off):
             W = lin.weight.detach().to(torch.float32)
-            wf[wo:wo + _pad(i) * _pad(o)].view(_pad(o), _pad(i))[:o, :i] = W
-            wb[wo:wo + _pad(i) * _pad(o)].view(_pad(i), _pad(o))[:i, :o] = W.t()
+            Wf = torch.zeros(_pad(o), _pad(i), device=dev, dtype=torch.float32)
+            Wf[:o, :i] = W
+            Wb = torch.zeros(_pad(i), _pad(o), device=dev, dtype=torch.float32)
+            Wb[:i, :o] = W.t()
+            wf[wo:wo + _pad(i) * _pad(o)] = lane_order(Wf)
+            wb[wo:wo + _pad(i) * _pad(o)] = lane_order(Wb)
             bias[bo:bo + o] = lin.bias.detach()
         self.wf, self.wb, self.bias, self.w_off, self.b_off, self._key = wf, wb, bias, w_off, b_off, key
 
