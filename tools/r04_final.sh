@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-4 final evidence on one box: headline bench, its rocprofv3 passes (kernel trace + PMC), the other workloads' lines
+mkdir -p gpurun_out/r4z
+timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/r4z/kolmogorov256_g1c1_bench.json 2> gpurun_out/r4z/k256.err; cut -c1-260 gpurun_out/r4z/kolmogorov256_g1c1_bench.json
+bash tools/profile_bench.sh r04_kolmogorov256_g1c1 --steps 1 --warmup 1 2>&1 | tail -5
+for net in global local; do for fr in lo hi; do
+  timeout 900 python bench.py --workload lorenz_eval --lorenz-net $net --lorenz-freq $fr --cpu-seconds 8 > gpurun_out/r4z/lorenz_eval_${net}_${fr}_bench.json 2> /dev/null
+done; done
+for wl in lorenz63 lorenz96; do
+  timeout 900 python bench.py --workload $wl --steps 200 --warmup 20 > gpurun_out/r4z/${wl}_g1c1_bench.json 2> /dev/null
+  PROFILE_PMC=0 PROFILE_KERNEL=net1d bash tools/profile_bench.sh r04_${wl}_g1c1 --workload $wl --steps 200 --warmup 20 > /dev/null 2>&1
+done
+ls gpurun_out/r4z
