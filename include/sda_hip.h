@@ -317,11 +317,12 @@ int sda_row_ln_bwd(const float* gh, const float* x, int rows, int f, const float
  * input VJP in one more (csrc/mlp1d.hip; ABI v7) -- the Lorenz local score kernel of experiments/lorenz/utils.py:45-59.
  * The network is a list of GEMMs in forward order: kind 0 = nn.Linear; kind 1 = first half of a residual block (LayerNorm -> Linear ->
  * activation), always followed by kind 2 = its second half (Linear + residual).  Widths <= 128.
- *   w:    every GEMM's matrix Wp, zero padded to [M = pad(out)][K = pad(in)], pad(f) = 16 if f <= 16 else 128, at float offset w_off[g],
- *         packed in MFMA lane order [slot M/16][q K/16][lane 64][4]: element e of lane (kq = lane >> 4, li = lane & 15) =
- *         Wp[16 slot + li][(K/4) kq + 4 q + e]  (sda_mlp_fwd: Wp = torch's [out][in] weight; sda_mlp_bwd: Wp = its transpose, M = pad(in),
- *         K = pad(out); same offsets table);
- *   bias: [pad(out)] zero padded at b_off[g] (forward only);  offsets are multiples of 4 floats, the buffers 16-byte aligned.
+ *   w:    per GEMM one SLAB at float offset w_off[g] (a multiple of 4): the matrix Wp = W zero padded to [16 mf][16 kq] (mf = 1 if out <= 16
+ *         else 8 output fragments; kq = 1 / 4 / 8 K quads for in <= 16 / 64 / 128) in MFMA A-operand order [m mf][sq kq][lane 64][4] --
+ *         element e of lane (k = lane >> 4, li = lane & 15) = Wp[16 m + li][16 sq + 4 k + e] --, zero padded to a multiple of 4096 floats;
+ *         sda_mlp_slab_floats(in, out) = its length.  sda_mlp_fwd: W = torch's [out][in] weight; sda_mlp_bwd: W = its transpose (the slab
+ *         of (out -> in)), same offsets table;
+ *   bias: [16 mf] zero padded at float offset b_off[g] (a multiple of 4; forward only);
  *   x / out: row-major (rows, features) with row strides x_ld / out_ld (sda_mlp_bwd: x = cotangent rows of width out_f[last], out =
  *         input-gradient rows of width in_f[0]).
  *   a_save / z_save [nres][rows][save_ld >= 128], mean_save / rstd_save [nres][rows] (block strides save_stride / stat_stride): written by
@@ -343,6 +344,7 @@ typedef struct sda_mlp_desc {
 } sda_mlp_desc;
 int sda_mlp_fwd(const sda_mlp_desc* d, void* stream);
 int sda_mlp_bwd(const sda_mlp_desc* d, void* stream);
+int sda_mlp_slab_floats(int in_f, int out_f);         /* host, no launch */
 
 /* ------------------------------------------------------------------------------------------
  * MCScoreNet.fold (sda/score.py:155-164): selective gather, NOT an overlap-add.

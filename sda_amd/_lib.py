@@ -167,6 +167,7 @@ SIGNATURES = {
     'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_mlp_fwd': (c_int, [POINTER(MlpDesc), c_void_p]),
     'sda_mlp_bwd': (c_int, [POINTER(MlpDesc), c_void_p]),
+    'sda_mlp_slab_floats': (c_int, [c_int, c_int]),
     'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),

@@ -34,8 +34,28 @@ FUSED = os.environ.get('SDA_MLP_FUSED', '1') != '0'
 _MLP_W = 128
 
 
-def _pad(f: int) -> int:
-    return 16 if f <= 16 else _MLP_W
+def _mf(out_f: int) -> int:
+    """D fragments (16 features each) of an output width: padded to 16 or 128 features."""
+    return 1 if out_f <= 16 else 8
+
+
+def _kq(in_f: int) -> int:
+    """K quads (16 values each) of a contraction length: padded to 16 / 64 / 128."""
+    return 1 if in_f <= 16 else (4 if in_f <= 64 else 8)
+
+
+_PIECE = 4096          # floats per staging piece of the kernel (slabs are zero padded to whole pieces in memory)
+
+
+def _slab(W: Tensor) -> Tensor:
+    """The LDS slab of one GEMM y = W x, W [out][in] (csrc/mlp1d.hip): [fragment m][k quad sq][lane = 16 kq + li][4] with element e of lane
+    (kq, li) = Wp[16 m + li][16 sq + 4 kq + e], Wp zero padded; padded with zeros to whole staging pieces."""
+    o, i = W.shape
+    mf, kq = _mf(o), _kq(i)
+    Wp = torch.zeros(16 * mf, 16 * kq, device=W.device, dtype=torch.float32)
+    Wp[:o, :i] = W
+    mat = Wp.view(mf, 16, kq, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+    return torch.nn.functional.pad(mat, (0, -mat.numel() % _PIECE))
 
 
 class _FusedPlan:
@@ -69,30 +89,21 @@ class _FusedPlan:
         key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.bias._version, str(lin.weight.device)) for *_, lin in self.gemms)
         if key == self._key:
             return
-        dev = self.gemms[0][3].weight.device
-        w_off, b_off, wn, bn = [], [], 0, 0
-        for _, i, o, _lin in self.gemms:
-            w_off.append(wn); b_off.append(bn)
-            wn += _pad(i) * _pad(o)
-            bn += _pad(o)
-        wf = torch.zeros(wn, device=dev, dtype=torch.float32)
-        wb = torch.zeros(wn, device=dev, dtype=torch.float32)
-        bias = torch.zeros(bn, device=dev, dtype=torch.float32)
-        def lane_order(Wp: Tensor) -> Tensor:
-            # [M][K] -> [slot M/16][q K/16][lane = 16 kq + li][4]: element e of lane (kq, li) = Wp[16 slot + li][(K/4) kq + 4 q + e]
-            M, K = Wp.shape
-            return Wp.view(M // 16, 16, 4, K // 16, 4).permute(0, 3, 2, 1, 4).contiguous().reshape(-1)
-
-        for (k, i, o, lin), wo, bo in zip(self.gemms, w_off, b_off):
+        fw, bw, bs, w_off, b_off, wn, bn = [], [], [], [], [], 0, 0
+        for _k, i, o, lin in self.gemms:
             W = lin.weight.detach().to(torch.float32)
-            Wf = torch.zeros(_pad(o), _pad(i), device=dev, dtype=torch.float32)
-            Wf[:o, :i] = W
-            Wb = torch.zeros(_pad(i), _pad(o), device=dev, dtype=torch.float32)
-            Wb[:i, :o] = W.t()
-            wf[wo:wo + _pad(i) * _pad(o)] = lane_order(Wf)
-            wb[wo:wo + _pad(i) * _pad(o)] = lane_order(Wb)
-            bias[bo:bo + o] = lin.bias.detach()
-        self.wf, self.wb, self.bias, self.w_off, self.b_off, self._key = wf, wb, bias, w_off, b_off, key
+            sf, sb = _slab(W), _slab(W.t())
+            # (forward and transposed slabs share one offsets table: laid out at the larger of the two sizes)
+            size = max(sf.numel(), sb.numel())
+            fw.append(torch.nn.functional.pad(sf, (0, size - sf.numel())))
+            bw.append(torch.nn.functional.pad(sb, (0, size - sb.numel())))
+            b = torch.zeros(16 * _mf(o), device=W.device, dtype=torch.float32)
+            b[:o] = lin.bias.detach()
+            bs.append(b)
+            w_off.append(wn); b_off.append(bn)
+            wn += size
+            bn += b.numel()
+        self.wf, self.wb, self.bias, self.w_off, self.b_off, self._key = torch.cat(fw), torch.cat(bw), torch.cat(bs), w_off, b_off, key
 
     def desc(self, rows: int, backward: bool):
         self._pack()

@@ -496,20 +496,29 @@ def _check_partial(partial: Tensor, b: int):
         raise _lib.SdaHipError(f'partial-sum buffer needs {b} x {SUMSQ_CHUNKS} contiguous floats, got {tuple(partial.shape)}')
 
 
-def sumsq_partial(eps: Tensor, b: int, partial: Tensor):
+def sumsq_chunks(per_sample: int) -> int:
+    """Workgroups per sample of the two-stage sum of squares: one per 4096 elements, at most SUMSQ_CHUNKS.  (A fixed 64 gave the Lorenz
+    trajectories -- 195 elements -- 64 workgroups of three elements each: 32 us per correction at eval.py's batch.)"""
+    return max(1, min(SUMSQ_CHUNKS, per_sample // 4096))
+
+
+def sumsq_partial(eps: Tensor, b: int, partial: Tensor) -> int:
+    """partial[b][nchunk] <- per-chunk sums of eps^2; returns nchunk (pass it to pc_correct)."""
     _dev(eps, partial)
     _check_partial(partial, b)
     per = eps.numel() // b
-    _lib.check(_lib.load().sda_sumsq_partial(eps.data_ptr(), b, per, partial.data_ptr(), SUMSQ_CHUNKS, _stream()),
+    nchunk = sumsq_chunks(per)
+    _lib.check(_lib.load().sda_sumsq_partial(eps.data_ptr(), b, per, partial.data_ptr(), nchunk, _stream()),
                'sda_sumsq_partial')
+    return nchunk
 
 
 def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: float, sigma: float,
-               coef_dev: Optional[Tensor] = None, nchunk: int = SUMSQ_CHUNKS):
+               coef_dev: Optional[Tensor] = None, nchunk: Optional[int] = None):
     _dev(x, eps, z, partial, coef_dev)
-    if nchunk == SUMSQ_CHUNKS:
-        _check_partial(partial, b)
-    elif partial.numel() < b * nchunk or not partial.is_contiguous():
+    if nchunk is None:
+        nchunk = sumsq_chunks(x.numel() // b)             # (what sumsq_partial wrote for this sample size)
+    if partial.numel() < b * nchunk or not partial.is_contiguous():
         raise _lib.SdaHipError(f'partial-sum buffer needs {b} x {nchunk} contiguous floats, got {tuple(partial.shape)}')
     per = x.numel() // b
     _lib.check(_lib.load().sda_pc_correct(x.data_ptr(), eps.data_ptr(), z.data_ptr(), b, per, partial.data_ptr(),

@@ -381,8 +381,8 @@ class PCSampler:
         for j in range(self.corrections):
             z = torch.randn_like(x) if sde.noise_source is None else sde.noise_source(i, j).to(x)
             eps = sde.eps(x, t - self.dt, self.c).contiguous()
-            ops.sumsq_partial(eps, self.nb, self.partial)
-            ops.pc_correct(x, eps, z.contiguous(), self.nb, self.partial, self.tau, self.sg_n[i])
+            nchunk = ops.sumsq_partial(eps, self.nb, self.partial)
+            ops.pc_correct(x, eps, z.contiguous(), self.nb, self.partial, self.tau, self.sg_n[i], nchunk=nchunk)
 
     # ------------------------------------------------------------------ fused step (eager and captured alike)
     @torch.no_grad()
@@ -422,8 +422,8 @@ class PCSampler:
         for j in range(self.corrections):
             z = torch.randn_like(x) if sde.noise_source is None else sde.noise_source.draw_dev(self._istep, j)
             eps = sde.eps(x, cur[1], self.c).contiguous()
-            ops.sumsq_partial(eps, self.nb, self.partial)
-            ops.pc_correct(x, eps, z, self.nb, self.partial, self.tau, 0.0, coef_dev=cur[4:5])
+            nchunk = ops.sumsq_partial(eps, self.nb, self.partial)
+            ops.pc_correct(x, eps, z, self.nb, self.partial, self.tau, 0.0, coef_dev=cur[4:5], nchunk=nchunk)
         self._istep.add_(1)
 
     def capture(self):

@@ -109,8 +109,9 @@ def install(monkeypatch):
     def sumsq_partial(eps, b, partial):
         partial.zero_()
         partial.reshape(b, -1)[:, 0] = eps.reshape(b, -1).square().sum(1)
+        return partial.numel() // b
 
-    def pc_correct(x, eps, z, b, partial, tau, sigma, coef_dev=None):
+    def pc_correct(x, eps, z, b, partial, tau, sigma, coef_dev=None, nchunk=None):
         per = x.numel() // b
         delta = (tau / (partial.reshape(b, -1).sum(1) / per)).reshape(b, *([1] * (x.dim() - 1)))
         x.copy_(x - (delta * eps + torch.sqrt(2 * delta) * z) * sigma)
