@@ -224,8 +224,9 @@ def test_pc_updates_and_guidance_glue(dev):
     ops.pc_predict(xd, eps.to(dev), 1.25, -0.37)
     assert_close(xd.cpu(), 1.25 * x + (-0.37) * eps, 1e-6)
     partial = torch.empty(b * ops.SUMSQ_CHUNKS, device=dev)
-    ops.sumsq_partial(eps.to(dev), b, partial)
-    assert_close(partial.reshape(b, -1).sum(1).cpu(), eps.square().sum(1), 1e-5)
+    nch = ops.sumsq_partial(eps.to(dev), b, partial)           # (chunks per sample: one per 4096 elements, layout [b][nch])
+    assert nch == ops.sumsq_chunks(per)
+    assert_close(partial[:b * nch].reshape(b, nch).sum(1).cpu(), eps.square().sum(1), 1e-5)
     xd = x.to(dev).clone()
     ops.pc_correct(xd, eps.to(dev), z.to(dev), b, partial, 0.5, 0.8)
     delta = 0.5 / eps.square().mean(dim=1, keepdim=True)
