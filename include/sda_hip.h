@@ -238,7 +238,8 @@ int sda_net1d_tiles(const sda_net1d_desc* d);          /* tiles per sequence of 
  *                  times = {t, t - dt};  istep[0] is incremented AFTER everything is written (single workgroup: the only reader);
  *   table == NULL: times = t_dev[0 .. nt).
  * out_coef (floats): {mu(t0), sigma(t0), mu(t1), sigma(t1), r, c1, sigma_next, t0, t1};  out_step (int64, optional): the step index
- * the row was read at;  mod: [nt][cp] modulation vectors.  Arithmetic identical to sda_vp_schedule / sda_time_embed /
+ * the row was read at;  mod: [nt][cp] modulation vectors -- or, with cp = 0 (wp NULL: a ScoreNet has no projections), the time
+ * embedding itself, [nt][e].  Arithmetic identical to sda_vp_schedule / sda_time_embed /
  * sda_linear_small. */
 int sda_step1d_prologue(const float* table, int row_len, int64_t* istep, const float* t_dev, int nt,
                         int alpha_kind, float eta, float k, int sigma_kind,
@@ -345,6 +346,33 @@ typedef struct sda_mlp_desc {
 int sda_mlp_fwd(const sda_mlp_desc* d, void* stream);
 int sda_mlp_bwd(const sda_mlp_desc* d, void* stream);
 int sda_mlp_slab_floats(int in_f, int out_f);         /* host, no launch */
+
+/* The same two launches as the halves of a Gaussian-guided evaluation of a LOCAL score network -- MCScoreNet over a ScoreNet kernel
+ * (sda/score.py:134-164, 53-63; experiments/lorenz/utils.py:45-59) inside GaussianScore (score.py:375-396) --, the rows being the
+ * nw = len - 2k windows of each of rows / nw trajectories x (B, len, c), (2k + 1) c <= 16:
+ *   sda_mlp_fwd_win: the loader gathers a window's (2k + 1) c consecutive values and appends the time embedding emb[emb_n]
+ *                    (`unfold`, `cat`: in_f[0] = (2k + 1) c + emb_n); the epilogue applies `fold` (score.py:155-164), forms
+ *                    eps = (cx0 + cx1 sigma) x + cn s and the likelihood cotangent ghat exactly as sda_net1d_fwd_fused does, and writes both
+ *                    as (B, len, c) tensors (d.x / d.out are unused);
+ *   sda_mlp_bwd_win: the loader applies fold's adjoint to cn ghat; the window part of the input gradient leaves as gwin [rows][16];
+ *   sda_mc_finish:   sums the overlapping windows (unfold's adjoint), adds the affine part, forms the guided score
+ *                    eps - (sigma/mu)(ghat - sigma J_eps^T ghat) and, by mode (as sda_net1d_bwd_fused): 0 writes it; 1 x <- r x + c1 . in
+ *                    place; 2 writes it and partial[b] = its sum of squares over the trajectory (one chunk per sample). */
+typedef struct sda_mlp_win {
+    int32_t nw, len, c, emb_n;
+    const float* x; const float* emb;
+    float cx0, cx1, cn;
+    const float* coef;                 /* device {mu(t), sigma(t)} */
+    const float* y; int64_t y_sn;
+    int32_t p_start, p_step, p_stop, c_start, c_step, c_stop;
+    float std, gamma;
+    float* eps; float* ghat;           /* fwd: out; bwd: ghat in */
+    float* gwin;                       /* bwd: out */
+} sda_mlp_win;
+int sda_mlp_fwd_win(const sda_mlp_desc* d, const sda_mlp_win* w, void* stream);
+int sda_mlp_bwd_win(const sda_mlp_desc* d, const sda_mlp_win* w, void* stream);
+int sda_mc_finish(const float* eps, const float* ghat, const float* gwin, int b, int nw, int k, int c, float cx0, float cx1,
+                  const float* coef, int mode, float* out, float* xs, const float* step_coef, float* partial, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MCScoreNet.fold (sda/score.py:155-164): selective gather, NOT an overlap-add.

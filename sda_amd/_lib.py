@@ -119,6 +119,22 @@ class MlpDesc(Structure):
     ]
 
 
+class MlpWin(Structure):
+    """Mirror of `struct sda_mlp_win` (include/sda_hip.h)."""
+    _fields_ = [
+        ('nw', c_int32), ('len', c_int32), ('c', c_int32), ('emb_n', c_int32),
+        ('x', c_fp), ('emb', c_fp),
+        ('cx0', c_float), ('cx1', c_float), ('cn', c_float),
+        ('coef', c_fp),
+        ('y', c_fp), ('y_sn', c_int64),
+        ('p_start', c_int32), ('p_step', c_int32), ('p_stop', c_int32),
+        ('c_start', c_int32), ('c_step', c_int32), ('c_stop', c_int32),
+        ('std', c_float), ('gamma', c_float),
+        ('eps', c_fp), ('ghat', c_fp),
+        ('gwin', c_fp),
+    ]
+
+
 class Net1dFuse(Structure):
     """Mirror of `struct sda_net1d_fuse` (include/sda_hip.h)."""
     _fields_ = [
@@ -168,6 +184,9 @@ SIGNATURES = {
     'sda_mlp_fwd': (c_int, [POINTER(MlpDesc), c_void_p]),
     'sda_mlp_bwd': (c_int, [POINTER(MlpDesc), c_void_p]),
     'sda_mlp_slab_floats': (c_int, [c_int, c_int]),
+    'sda_mlp_fwd_win': (c_int, [POINTER(MlpDesc), POINTER(MlpWin), c_void_p]),
+    'sda_mlp_bwd_win': (c_int, [POINTER(MlpDesc), POINTER(MlpWin), c_void_p]),
+    'sda_mc_finish': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_float, c_float, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln': (c_int, [c_fp, c_int, c_int, c_float, c_int, c_fp, c_fp, c_fp, c_void_p]),
     'sda_row_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_void_p]),
     'sda_obs_subsample': (c_int, [c_fp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_fp, c_void_p]),

@@ -182,8 +182,23 @@ __device__ __forceinline__ void ml_store_rows(float* dst, int64_t ld, int width,
         }
 }
 
+// ---- window mode (MCScoreNet over a ScoreNet kernel, sda/score.py:134-164): the rows are the windows of B trajectories; the gather
+// (`unfold`), the concatenation with the time embedding (score.py:57-62), `fold` and the Gaussian-likelihood glue of GaussianScore
+// (score.py:387-392) are the loader and the epilogue of the launch -- see sda_mlp_fwd_win / sda_mlp_bwd_win in sda_hip.h.
+struct MlWinRow { int b, i; bool first, lastw; };
+__device__ __forceinline__ MlWinRow ml_win_row(const sda_mlp_win& w, const MlCtx& c) {
+    MlWinRow r;
+    const int64_t row = c.rowok ? c.row : 0;
+    r.b = (int)(row / w.nw); r.i = (int)(row - (int64_t)r.b * w.nw);
+    r.first = r.i == 0; r.lastw = r.i == w.nw - 1;
+    return r;
+}
+// does `fold` read slot j of this window?  (the centre always; the leading slots of a trajectory's first window, the trailing ones of its last)
+__device__ __forceinline__ bool ml_win_sel(const MlWinRow& r, int j, int k) { return j == k || (r.first && j < k) || (r.lastw && j > k); }
+
 // ------------------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
+template <bool WIN>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, const sda_mlp_win w) {
     extern __shared__ __attribute__((aligned(16))) float ml_lds[];         // two slab buffers
     MlCtx c;
     ml_ctx(c, d);
@@ -195,7 +210,23 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
     st.npieces = ml_slab_floats(d.in_f[0], d.out_f[0]) / ML_PIECE;
     for (int p = 0; p < st.npieces; ++p) { st.template issue<0>(p); st.template commit<0>(p); }
     ml_f32x4 h[8], a[8], acc[8];
-    ml_load_rows(d.x, d.x_ld, d.in_f[0], c, a);
+    if constexpr (WIN) {
+        // row (b, i): features [0, WC) = x[b][i .. i + 2k][:] -- WC consecutive floats of the trajectory --, then the time embedding
+        const MlWinRow wr = ml_win_row(w, c);
+        const int wc = (w.len - w.nw + 1) * w.c;
+        const float* xr = w.x + ((int64_t)wr.b * w.len + wr.i) * w.c;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * m + 4 * c.kq + r;
+                const bool isx = f < wc, ise = !isx && f < wc + w.emb_n;
+                const float xv = xr[isx ? f : 0], ev = w.emb[ise ? f - wc : 0];
+                a[m][r] = !c.rowok ? 0.f : (isx ? xv : (ise ? ev : 0.f));
+            }
+    } else {
+        ml_load_rows(d.x, d.x_ld, d.in_f[0], c, a);
+    }
     __syncthreads();
     ML_STAMP(0);                                           // first slab + input rows
     const bool silu = d.act == SDA_ACT_SILU;
@@ -288,13 +319,49 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d) {
         }
         ML_STAMP(4);                                       // epilogue
     }
-    ml_store_rows(d.out, d.out_ld, d.out_f[d.ngemm - 1], c, a);
+    if constexpr (WIN) {
+        // fold (score.py:155-164) + eps = (cx0 + cx1 sigma) x + cn s + the likelihood cotangent, as sda_net1d_fwd_fused's epilogue
+        if (c.rowok) {
+            const MlWinRow wr = ml_win_row(w, c);
+            const int k = (w.len - w.nw) / 2, wc = (2 * k + 1) * w.c;
+            const float mu = w.coef[0], sg = w.coef[1];
+            const bool bare = w.cx0 == 0.f && w.cx1 == 0.f && w.cn == 1.f;
+            const float cx = w.cx0 + w.cx1 * sg;
+            const float rr = __fdiv_rn(sg, mu);
+            const float var = __fadd_rn(__fmul_rn(w.std, w.std), __fmul_rn(w.gamma, __fmul_rn(rr, rr)));
+            const int n_oc = (w.c_stop - w.c_start + w.c_step - 1) / w.c_step;
+            const float* yb = w.y + (int64_t)wr.b * w.y_sn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * c.kq + r;
+                if (f >= wc) continue;
+                const int j = f / w.c, ch = f - j * w.c;
+                if (!ml_win_sel(wr, j, k)) continue;
+                const int ps = wr.i + j;
+                const int64_t o = ((int64_t)wr.b * w.len + ps) * w.c + ch;
+                const float xv = w.x[o];
+                const float ov = a[0][r];
+                const float e = bare ? ov : (xv * cx) + (w.cn * ov);
+                w.eps[o] = e;
+                const int crel = ch - w.c_start, prel = ps - w.p_start;
+                float gv = 0.f;
+                if (crel >= 0 && ch < w.c_stop && crel % w.c_step == 0 && prel >= 0 && ps < w.p_stop && prel % w.p_step == 0) {
+                    const float xh = (xv - sg * e) / mu;
+                    gv = __fdiv_rn(yb[(prel / w.p_step) * n_oc + crel / w.c_step] - xh, var);
+                }
+                w.ghat[o] = gv;
+            }
+        }
+    } else {
+        ml_store_rows(d.out, d.out_ld, d.out_f[d.ngemm - 1], c, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ input VJP
 // d.w = the slabs of the TRANSPOSED matrices (backward GEMM of forward GEMM g: out_f[g] -> in_f[g], no bias), same offsets table;
 // x = cotangent rows (width out_f[last]), out = input-gradient rows (width in_f[0]); the GEMM list is walked backwards.
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d) {
+template <bool WIN>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, const sda_mlp_win w) {
     extern __shared__ __attribute__((aligned(16))) float ml_lds[];
     MlCtx c;
     ml_ctx(c, d);
@@ -307,7 +374,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d) {
     ml_f32x4 h[8], gacc[8], acc[8], zero[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) zero[m] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
-    ml_load_rows(d.x, d.x_ld, d.out_f[gl], c, gacc);
+    if constexpr (WIN) {
+        // the cotangent of the window outputs = fold's adjoint of cn ghat: slot j of window (b, i) receives ghat[b][i + j] where fold reads it
+        const MlWinRow wr = ml_win_row(w, c);
+        const int k = (w.len - w.nw) / 2, wc = (2 * k + 1) * w.c;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) gacc[m] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 4 * c.kq + r, fc = f < wc ? f : 0;
+            const int j = fc / w.c, ch = fc - j * w.c;
+            const bool sel = c.rowok && f < wc && ml_win_sel(wr, j, k);
+            const float gv = w.ghat[sel ? ((int64_t)wr.b * w.len + wr.i + j) * w.c + ch : 0];
+            gacc[0][r] = sel ? gv * w.cn : 0.f;
+        }
+    } else {
+        ml_load_rows(d.x, d.x_ld, d.out_f[gl], c, gacc);
+    }
     __syncthreads();
     const bool silu = d.act == SDA_ACT_SILU;
     int rb = 0;
@@ -381,12 +464,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d) {
             else lnb(std::false_type{});
         }
     }
-    ml_store_rows(d.out, d.out_ld, d.in_f[0], c, gacc);
+    if constexpr (WIN) {
+        // the window part of the input gradient, 16 floats per row (the embedding's part is not formed); sda_mc_finish sums the overlaps
+        if (c.rowok) *reinterpret_cast<ml_f32x4*>(w.gwin + c.row * 16 + 4 * c.kq) = gacc[0];
+    } else {
+        ml_store_rows(d.out, d.out_ld, d.in_f[0], c, gacc);
+    }
 }
 
-static int mlp_check(const sda_mlp_desc* d, bool bwd) {
+static int mlp_check(const sda_mlp_desc* d, bool bwd, bool win) {
     if (!d || d->rows < 1 || d->ngemm < 1 || d->ngemm > SDA_MLP_MAXG) return SDA_E_UNSUPPORTED;
-    if (!d->x || !d->out || !d->w || (!bwd && !d->bias)) return SDA_E_BADARG;
+    if ((!win && (!d->x || !d->out)) || !d->w || (!bwd && !d->bias)) return SDA_E_BADARG;
     int nres = 0;
     for (int g = 0; g < d->ngemm; ++g) {
         if (d->in_f[g] < 1 || d->out_f[g] < 1 || d->in_f[g] > 128 || d->out_f[g] > 128 || d->kind[g] < 0 || d->kind[g] > 2) return SDA_E_UNSUPPORTED;
@@ -411,17 +499,37 @@ static int mlp_check(const sda_mlp_desc* d, bool bwd) {
     return SDA_OK;
 }
 
-template <bool BWD>
-static int mlp_launch(const sda_mlp_desc* d, hipStream_t stream) {
-    const int rc = mlp_check(d, BWD);
+static int mlp_win_check(const sda_mlp_desc* d, const sda_mlp_win* w, bool bwd) {
+    if (!w || w->nw < 1 || w->c < 1 || w->len < w->nw || ((w->len - w->nw) & 1)) return SDA_E_BADARG;
+    const int wc = (w->len - w->nw + 1) * w->c;
+    if (wc > 16) return SDA_E_UNSUPPORTED;                 // (the window values of a row live in one D fragment)
+    if (d->rows % w->nw || !w->ghat || !w->coef) return SDA_E_BADARG;
+    if (d->out_f[d->ngemm - 1] != wc) return SDA_E_BADARG;
+    if (!bwd) {
+        if (!w->x || !w->eps || !w->y || w->emb_n < 0 || (w->emb_n > 0 && !w->emb) || d->in_f[0] != wc + w->emb_n) return SDA_E_BADARG;
+        if (w->p_step < 1 || w->c_step < 1 || w->p_start < 0 || w->c_start < 0 || w->p_stop > w->len || w->c_stop > w->c ||
+            w->p_stop <= w->p_start || w->c_stop <= w->c_start)
+            return SDA_E_BADARG;
+    } else {
+        if (!w->gwin || (reinterpret_cast<uintptr_t>(w->gwin) & 15) || d->in_f[0] < wc) return SDA_E_BADARG;
+    }
+    return SDA_OK;
+}
+
+template <bool BWD, bool WIN>
+static int mlp_launch(const sda_mlp_desc* d, const sda_mlp_win* w, hipStream_t stream) {
+    int rc = mlp_check(d, BWD, WIN);
     if (rc != SDA_OK) return rc;
+    if (WIN && (rc = mlp_win_check(d, w, BWD)) != SDA_OK) return rc;
     const int64_t tiles = ((int64_t)d->rows + 63) / 64;
     if (tiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
     constexpr int lds = 2 * ML_SLAB * 4;
     static bool raised[SDA_MAX_DEVICES];
-    const void* kern = BWD ? reinterpret_cast<const void*>(mlp_bwd_kernel) : reinterpret_cast<const void*>(mlp_fwd_kernel);
+    const void* kern = BWD ? reinterpret_cast<const void*>(mlp_bwd_kernel<WIN>) : reinterpret_cast<const void*>(mlp_fwd_kernel<WIN>);
     const int rr = sda_raise_dyn_lds(kern, lds, raised);
     if (rr != SDA_OK) return rr;
+    sda_mlp_win wv = {};
+    if (WIN) wv = *w;
 #ifdef SDA_ML_TRACE
     sda_mlp_desc dd = *d;
     if (!BWD && getenv("SDA_ML_DBG")) {                     // tooling: which save stream costs what (results of a later VJP are wrong)
@@ -432,14 +540,16 @@ static int mlp_launch(const sda_mlp_desc* d, hipStream_t stream) {
     }
     d = &dd;
 #endif
-    if (BWD) hipLaunchKernelGGL(mlp_bwd_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, *d);
-    else hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)tiles), dim3(256), lds, stream, *d);
+    if (BWD) hipLaunchKernelGGL(mlp_bwd_kernel<WIN>, dim3((unsigned)tiles), dim3(256), lds, stream, *d, wv);
+    else hipLaunchKernelGGL(mlp_fwd_kernel<WIN>, dim3((unsigned)tiles), dim3(256), lds, stream, *d, wv);
     return sda_launch_status();
 }
 
-extern "C" int sda_mlp_fwd(const sda_mlp_desc* d, void* stream) { return mlp_launch<false>(d, (hipStream_t)stream); }
-extern "C" int sda_mlp_bwd(const sda_mlp_desc* d, void* stream) { return mlp_launch<true>(d, (hipStream_t)stream); }
-// floats of GEMM (in_f -> out_f)'s slab (matrix + bias), for the packer
+extern "C" int sda_mlp_fwd(const sda_mlp_desc* d, void* stream) { return mlp_launch<false, false>(d, nullptr, (hipStream_t)stream); }
+extern "C" int sda_mlp_bwd(const sda_mlp_desc* d, void* stream) { return mlp_launch<true, false>(d, nullptr, (hipStream_t)stream); }
+extern "C" int sda_mlp_fwd_win(const sda_mlp_desc* d, const sda_mlp_win* w, void* stream) { return mlp_launch<false, true>(d, w, (hipStream_t)stream); }
+extern "C" int sda_mlp_bwd_win(const sda_mlp_desc* d, const sda_mlp_win* w, void* stream) { return mlp_launch<true, true>(d, w, (hipStream_t)stream); }
+// floats of GEMM (in_f -> out_f)'s slab, for the packer
 extern "C" int sda_mlp_slab_floats(int in_f, int out_f) {
     if (in_f < 1 || out_f < 1 || in_f > 128 || out_f > 128) return SDA_E_UNSUPPORTED;
     return ml_slab_floats(in_f, out_f);

@@ -177,7 +177,10 @@ __global__ __launch_bounds__(S1_THREADS) void step1d_prologue_kernel(
     // input features the upper half-wave only ever adds zeros there, so a wave serves TWO outputs, one per half (lane 0's / lane
     // 32's reduction tree touches its own half only from the 16-lane step on: identical sums).
     const int lane = tid & 63, wave = tid >> 6;
-    if (e <= 32) {
+    if (cp == 0) {
+        // no projection (a ScoreNet takes the embedding itself as features, sda/score.py:53-63): mod <- emb [nt][e]
+        for (int i = tid; i < nt * e; i += S1_THREADS) mod[i] = emb[i / e][i - (i / e) * e];
+    } else if (e <= 32) {
         // linear_small_kernel with <= 32 input features: lane l < e holds p_l = emb[l] w[l] (lanes beyond: 0), and the shuffle tree
         // (offsets 32, 16, 8, 4, 2, 1; the first step adds zeros) leaves lane 0 with ((..(p_l + p_{l+16}) + ..)): ONE thread per output
         // replays that tree on its 32 products -- the wave-per-output form spent 750 cycles per output on five dependent cross-lane
@@ -220,7 +223,7 @@ extern "C" int sda_step1d_prologue(const float* table, int row_len, int64_t* ist
                                    float eta, float k, int sigma_kind, const float* freqs, int nf, const float* w0, const float* b0,
                                    int hidden, const float* w2, const float* b2, int e, const float* wp, const float* bp, int cp,
                                    float* out_coef, int64_t* out_step, float* mod, void* stream) {
-    if (!freqs || !w0 || !b0 || !w2 || !b2 || !wp || !out_coef || !mod || nf <= 0 || hidden <= 0 || e <= 0 || cp <= 0)
+    if (!freqs || !w0 || !b0 || !w2 || !b2 || !out_coef || !mod || nf <= 0 || hidden <= 0 || e <= 0 || cp < 0 || (cp > 0 && !wp))
         return SDA_E_BADARG;
     if (table ? (!istep || row_len < 5 || nt != 2) : (!t_dev || nt < 1 || nt > 2)) return SDA_E_BADARG;
     if (alpha_kind < 0 || alpha_kind > 2 || sigma_kind < 0 || sigma_kind > 2) return SDA_E_BADARG;
@@ -229,7 +232,7 @@ extern "C" int sda_step1d_prologue(const float* table, int row_len, int64_t* ist
     const int64_t vecs = 4LL * (hidden + e + cp + nf);                                       // staged biases + frequencies (both variants)
     const int64_t lds = vecs + 4LL * ((int64_t)hidden * (nin + S1_PAD) + (int64_t)e * (hidden + S1_PAD) + (int64_t)cp * (e + S1_PAD));
     const bool aligned = !(nin & 3) && !(hidden & 3) && !(e & 3) &&
-                         !(((uintptr_t)w0 | (uintptr_t)w2 | (uintptr_t)wp) & 15);
+                         !(((uintptr_t)w0 | (uintptr_t)w2 | (uintptr_t)(cp ? wp : w0)) & 15);
     const int64_t quads = ((int64_t)hidden * nin + (int64_t)e * hidden + (int64_t)cp * e) / 4;
     auto pow2 = [](int v) { return v > 0 && !(v & (v - 1)); };
     if (aligned && lds <= 140 * 1024 && quads <= (int64_t)S1_STAGE_MAX * S1_THREADS && pow2(nin) && pow2(hidden) && pow2(e) && nin >= 8) {
@@ -314,5 +317,55 @@ extern "C" int sda_pc_correct_keyed(float* x, const float* eps, int b, int64_t p
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pc_correct_keyed_kernel, dim3((unsigned)blocks, b), dim3(256), 0, (hipStream_t)stream, x, eps, per_sample, partial,
                        nchunk, tau, sigma, coef_dev, (uint32_t)seed, (uint32_t)(seed >> 32), row0, draw_dev, draw_mul, draw_add);
+    return sda_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The tail of a fused guided evaluation of a LOCAL score network (sda_mlp_fwd_win / sda_mlp_bwd_win): the overlapping-window sum
+// of the input gradient (`unfold`'s adjoint, sda/score.py:146-153 -- the one place overlaps add), the estimator's affine part, the
+// guided score eps - (sigma/mu)(ghat - sigma J^T ghat) (score.py:394-396) and, by mode, what sda_net1d_bwd_fused's epilogue does:
+// 0 write it; 1 x <- r x + c1 . in place; 2 write it and the trajectory's sum of squares into partial[b] (one chunk per sample).
+// One workgroup per trajectory (L x C elements: 195 for the Lorenz job).
+__global__ __launch_bounds__(256) void mc_finish_kernel(const float* __restrict__ eps, const float* __restrict__ ghat,
+                                                        const float* __restrict__ gwin, int nw, int k, int c, float cx0, float cx1,
+                                                        const float* __restrict__ coef, int mode, float* __restrict__ out, float* xs,
+                                                        const float* __restrict__ step_coef, float* __restrict__ partial) {
+    __shared__ float wsum[4];
+    const int b = blockIdx.x, L = nw + 2 * k, per = L * c;
+    const float mu = coef[0], sg = coef[1];
+    const float cx = cx0 + cx1 * sg, kk = sg / mu;
+    const bool bare = cx0 == 0.f && cx1 == 0.f;
+    float pr = 0.f, pc1 = 0.f;
+    if (mode == 1) { pr = step_coef[0]; pc1 = step_coef[1]; }
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < per; e += 256) {
+        const int l = e / c, ch = e - l * c;
+        float gx = 0.f;
+        for (int j = 0; j <= 2 * k; ++j) {                 // (ascending j: sda_unfold_adjoint's order)
+            const int i = l - j;
+            if (i >= 0 && i < nw) gx += gwin[((int64_t)b * nw + i) * 16 + j * c + ch];
+        }
+        const int64_t o = (int64_t)b * per + e;
+        const float gv = ghat[o];
+        const float vj = bare ? gx : (gv * cx) + gx;
+        const float ov = eps[o] - kk * (gv - sg * vj);
+        if (mode == 1) xs[o] = pr * xs[o] + pc1 * ov;
+        else { out[o] = ov; acc += ov * ov; }
+    }
+    if (mode == 2) {
+        acc = sda_wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+extern "C" int sda_mc_finish(const float* eps, const float* ghat, const float* gwin, int b, int nw, int k, int c, float cx0, float cx1,
+                             const float* coef, int mode, float* out, float* xs, const float* step_coef, float* partial, void* stream) {
+    if (!eps || !ghat || !gwin || !coef || b <= 0 || nw <= 0 || k < 0 || c <= 0 || (2 * k + 1) * c > 16 || mode < 0 || mode > 2)
+        return SDA_E_BADARG;
+    if ((mode != 1 && !out) || (mode == 1 && (!xs || !step_coef)) || (mode == 2 && !partial)) return SDA_E_BADARG;
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, eps, ghat, gwin, nw, k, c, cx0, cx1, coef, mode, out,
+                       xs, step_coef, partial);
     return sda_launch_status();
 }

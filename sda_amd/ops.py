@@ -461,6 +461,29 @@ def mlp_launch(d: '_lib.MlpDesc', backward: bool):
     prof.records.append((e0, e1, flops, 'mlp_bwd' if backward else 'mlp_fwd'))
 
 
+def mlp_launch_win(d: '_lib.MlpDesc', w: '_lib.MlpWin', backward: bool):
+    """One half of a fused guided evaluation of a local score network (sda_mlp_fwd_win / sda_mlp_bwd_win; sda_amd/fused1d.py)."""
+    lib = _lib.load()
+    fn, name = (lib.sda_mlp_bwd_win, 'sda_mlp_bwd_win') if backward else (lib.sda_mlp_fwd_win, 'sda_mlp_fwd_win')
+    prof = conv_profile
+    if prof is None:
+        _lib.check(fn(ctypes.byref(d), ctypes.byref(w), _stream()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(fn(ctypes.byref(d), ctypes.byref(w), _stream()), name)
+    e1.record()
+    flops = 2.0 * d.rows * sum(d.in_f[g] * d.out_f[g] for g in range(d.ngemm))
+    prof.records.append((e0, e1, flops, 'mlp_bwd' if backward else 'mlp_fwd'))
+
+
+def mc_finish(eps: Tensor, ghat: Tensor, gwin: Tensor, b: int, nw: int, k: int, c: int, cx0: float, cx1: float, coef_ptr: int, mode: int,
+              out: Optional[Tensor], xs: Optional[Tensor], step_coef_ptr: int, partial: Optional[Tensor]):
+    _dev(eps, ghat, gwin, out, xs, partial)
+    _lib.check(_lib.load().sda_mc_finish(eps.data_ptr(), ghat.data_ptr(), gwin.data_ptr(), b, nw, k, c, cx0, cx1, coef_ptr, mode,
+                                         _ptr(out), _ptr(xs), step_coef_ptr, _ptr(partial), _stream()), 'sda_mc_finish')
+
+
 # ------------------------------------------------------------------------------------------ fold / unfold adjoints
 
 def fold(s: Tensor, b: int, nw: int, k: int, c: int, hw: int, out: Tensor):

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize('mirror,ctype', [('ConvDesc', 'sda_conv_desc'), ('Block1dDesc', 'sda_block1d_desc'),
-                                          ('Net1dDesc', 'sda_net1d_desc'), ('Net1dFuse', 'sda_net1d_fuse'), ('MlpDesc', 'sda_mlp_desc')])
+                                          ('Net1dDesc', 'sda_net1d_desc'), ('Net1dFuse', 'sda_net1d_fuse'), ('MlpDesc', 'sda_mlp_desc'), ('MlpWin', 'sda_mlp_win')])
 def test_desc_layouts_match_c(tmp_path, mirror, ctype):
     """sizeof/offsetof of the ctypes mirrors == what gcc sees in the header."""
     from sda_amd import _lib

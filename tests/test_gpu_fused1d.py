@@ -186,3 +186,105 @@ def test_whole_sequence_tiles_forward_and_vjp_vs_oracle(dev, B, L, C, blocks):
     v3, = torch.autograd.grad(o3, xs, g[:3].to(dev))
     assert_close(out[:3].detach().cpu(), o3.detach().cpu(), 1e-5, what='whole-sequence vs halo tiles (eps)')
     assert_close(vjp[:3].cpu(), v3.cpu(), 1e-5, what='whole-sequence vs halo tiles (vjp)')
+
+
+def _build_local(dev, features, window, affine, seed=90):
+    import bench
+    from sda_amd.experiments.lorenz import make_local_score
+    from sda_amd.score import VPSDE
+    torch.manual_seed(seed)
+    net = make_local_score(window=window, features=features).to(dev)
+    if affine:
+        score = bench.SyntheticScore(net)
+        inner = VPSDE(score, shape=())
+        object.__setattr__(score, '_sched', inner)
+    else:
+        inner = VPSDE(net, shape=())
+    return net, inner
+
+
+LOCAL_CASES = [
+    # B, L, C, window, slices, per-sample y, affine
+    (5, 65, 3, 5, (slice(None, None, 8), slice(0, 1)), False, True),       # eval.py "lo" (experiments/lorenz/eval.py:50-53)
+    (1100, 65, 3, 5, (slice(None, None, 1), slice(0, 1)), False, False),   # eval.py "hi" at its batch size, bare network
+    (9, 17, 3, 5, (slice(3, 15, 5), slice(1, 3)), True, False),            # offsets, stops, two observed channels
+    (1, 5, 3, 5, (slice(0, None, 2),), False, True),                        # one window per trajectory, channel slice only
+    (70, 30, 5, 3, (slice(None, None, 4), slice(0, 5, 2)), True, True),     # window 3 of five states
+    (33, 12, 2, 5, (slice(None, None, 3), slice(0, 1)), True, False),       # two states
+]
+
+
+@pytest.mark.parametrize('case', LOCAL_CASES)
+def test_fused_local_evaluation_equals_general_path_and_oracle(dev, case, monkeypatch):
+    """The fused evaluation of a LOCAL score network (MCScoreNet over a ScoreNet, experiments/lorenz/utils.py:45-59: sda_mlp_fwd_win,
+    sda_mlp_bwd_win, sda_mc_finish) against the general path (unfold + cat + whole-MLP kernels + fold + the guidance kernels) and the oracle."""
+    from sda_amd import fused1d, observe as Ob
+    from sda_amd.score import GaussianScore
+    B, L, C, window, sl, per_sample, affine = case
+    net, inner = _build_local(dev, C, window, affine)
+    torch.manual_seed(91)
+    x = torch.randn(B, L, C)
+    t = torch.tensor(0.41)
+    A = Ob.Subsample(sl)
+    oshape = A._osize(x.shape)
+    y = torch.randn(oshape if per_sample else oshape[1:])
+    gs = GaussianScore(y, A=A, std=0.3, sde=inner, gamma=3e-2).to(dev)
+    xd, td = x.to(dev), t.to(dev)
+    fz = fused1d.plan(gs, xd, td, None)
+    assert isinstance(fz, fused1d.FusedLocal), 'the fused plan declined a local Lorenz-shaped job'
+    got = gs(xd, td)
+    assert torch.equal(got, gs(xd, td))
+    monkeypatch.setattr(fused1d, 'ENABLED', False)
+    ref = gs(xd, td)
+    monkeypatch.setattr(fused1d, 'ENABLED', True)
+    assert_close(got.cpu(), ref.cpu(), 1e-5, what='fused vs general path (local net)')
+    eps_net = oracle_eps_from_module(net, 'local')
+    sched = O.Schedule()
+
+    def eps_o(xx, tt):
+        if not affine:
+            return eps_net(xx, tt)
+        mu, sg = sched.mu(tt), sched.sigma(tt)
+        return xx * (sg / (mu * mu + sg * sg)) + 0.1 * eps_net(xx, tt)
+    rows = slice(max(0, B - 6), B)
+    Af = lambda v: v[(Ellipsis,) + tuple(sl)]
+    ref_o = O.gaussian_score(eps_o, sched, y[rows] if per_sample else y, Af, 0.3, 3e-2, x[rows], t)
+    assert_close(got[rows].cpu(), ref_o, TOL, what='fused vs oracle (local net)')
+
+
+@pytest.mark.parametrize('B,L,corr', [(1, 65, 1), (300, 65, 2), (40, 9, 0)])
+@pytest.mark.parametrize('noise', ['keyed', 'torch'])
+def test_fused_local_pc_steps_equal_general_path_eager_and_graph(dev, B, L, corr, noise, monkeypatch):
+    from sda_amd import fused1d, observe as Ob, parallel
+    from sda_amd.score import GaussianScore, VPSDE
+    C = 3
+    net, inner = _build_local(dev, C, 5, True, seed=92)
+    torch.manual_seed(93)
+    x1 = torch.randn(B, L, C)
+    A = Ob.Subsample((slice(None, None, 8), slice(0, 1)))
+    y = torch.randn(A._osize(x1.shape)[1:])
+    gs = GaussianScore(y, A=A, std=0.2, sde=inner, gamma=3e-2)
+    sde = VPSDE(gs, shape=(L, C)).to(dev)
+
+    def run(fused, graph):
+        monkeypatch.setattr(fused1d, 'ENABLED', fused)
+        sde.initial_noise = x1
+        sde.noise_source = parallel.KeyedNoise((5, 5 + B), (L, C), 9, corr, dev) if noise == 'keyed' and corr else None
+        torch.manual_seed(94)
+        sampler = sde.sampler((B,), steps=50, corrections=corr, tau=0.25)
+        assert isinstance(sampler._fused, fused1d.FusedLocal) == fused
+        if graph:
+            sampler.capture()
+        for _ in range(6):
+            sampler.step()
+        torch.cuda.synchronize()
+        sde.initial_noise, sde.noise_source = None, None
+        return sampler.result().clone()
+
+    base = run(False, False)
+    assert torch.isfinite(base).all()
+    fe = run(True, False)
+    assert_close(fe.cpu(), base.cpu(), 5e-5, what='6 fused steps vs the general path (local net)')
+    fg = run(True, True)
+    assert_close(fg.cpu(), fe.cpu(), 1e-6, what='fused graph replay vs fused eager (local net)')
+    monkeypatch.setattr(fused1d, 'ENABLED', True)
