@@ -25,13 +25,15 @@
 
 #define ML_SLAB (8 * 8 * 256)          // floats of the largest slab (128 x 128)
 #define ML_PIECE 4096                  // floats per staging piece (1024 float4: four per thread)
+#define ML_BIAS 4096                   // floats of the bias region behind the two slab buffers (every GEMM's padded bias)
 
 typedef float ml_f32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef SDA_ML_TRACE                    // tooling (tools/mlp_trace.py): per-phase cycle sums of workgroup 0 / thread 0
-__device__ long long ml_trace[16];
-#define ML_T0() long long ml_tl = __builtin_readcyclecounter()
-#define ML_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long n_ = __builtin_readcyclecounter(); ml_trace[k] += n_ - ml_tl; ml_tl = n_; } } while (0)
+#ifdef SDA_ML_TRACE                    // tooling (tools/mlp_trace.py): per-phase cycle sums of workgroup 0 / wave 0, kept in scalar registers
+__device__ long long ml_trace[16];     // and written once at the kernel's end (a stamp that touches memory drains the loads in flight)
+#define ML_T0() long long ml_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ml_tl = __builtin_readcyclecounter()
+#define ML_STAMP(k) do { const long long n_ = __builtin_readcyclecounter(); ml_acc_[k] += n_ - ml_tl; ml_tl = n_; } while (0)
+#define ML_DUMP() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) ml_trace[k_] += ml_acc_[k_]; } while (0)
 extern "C" int sda_ml_trace_read(long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ml_trace), sizeof(long long) * 16) != hipSuccess) return SDA_E_BADARG;
     if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ml_trace), z, sizeof(z)); }
@@ -40,6 +42,7 @@ extern "C" int sda_ml_trace_read(long long* out, int reset) {
 #else
 #define ML_T0() do {} while (0)
 #define ML_STAMP(k) do {} while (0)
+#define ML_DUMP() do {} while (0)
 #endif
 
 // padded sizes: an output width -> 16 or 128 features (1 or 8 D fragments); a contraction length -> 16 / 64 / 128 (1 / 4 / 8 K quads)
@@ -56,26 +59,32 @@ struct MlCtx {
 
 // copies pieces [first, first + n) x 256 float4 of the next slab global -> LDS (16-byte loads, then 16-byte stores: no vector ALU);
 // issue() and commit() bracket the multiplies the copy hides behind
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ml_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, 0x7fffffff, 0x00020000);
+}
 struct MlStage {
-    const ml_f32x4* src; ml_f32x4* dst;                    // (both already offset by the thread id)
+    __amdgpu_buffer_rsrc_t src; unsigned toff;             // the slab as a buffer resource + the thread's byte offset: the piece and register
+                                                           // offsets go in the scalar offset operand (a per-thread 64-bit pointer cost 8 VALU per quad)
+    ml_f32x4* dst;                                         // (already offset by the thread id)
     int npieces;                                           // whole pieces of 1024 float4 (slabs are padded to that in memory)
-    ml_f32x4 v0[4], v1[4];                                 // two register sets: a piece is committed one K quad after its loads were issued
-    // (SET is a compile-time constant: a run-time index into the sets would move them to scratch.  No bounds checks, no per-load index
-    // arithmetic: the first version's clamps and compares were ~20 VALU instructions per piece -- on a SIMD whose VALU the MFMAs own)
-    template <int SET>
-    __device__ __forceinline__ void issue(int piece) {
-        const ml_f32x4* p = src + piece * 1024;
+    // A piece's four registers are LOCAL to the multiply that stages it (`sv[piece]` in ml_mm), never members that live across multiplies:
+    // the loads sit under a run-time condition (this quad has a piece or not), and a register that carries an older value into that
+    // condition comes out of it as a phi -- 16 v_mov_b64 per K quad on a SIMD whose vector ALU the MFMAs own.  Undefined on the other path,
+    // it is just the load's destination.  (No bounds checks or per-load index arithmetic either; issuing ALL of a slab's loads up front and
+    // committing four quads later measured slower: 16 loads in flight per lane.)
+    __device__ __forceinline__ void issue(ml_f32x4 (&v)[4], int piece) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const ml_f32x4 t = p[256 * i];
-            if (SET) v1[i] = t; else v0[i] = t;
-        }
+        for (int i = 0; i < 4; ++i)
+            v[i] = __builtin_bit_cast(ml_f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, toff, piece * 16384 + 4096 * i, 0));
     }
-    template <int SET>
-    __device__ __forceinline__ void commit(int piece) {
-        ml_f32x4* p = dst + piece * 1024;
+    // The LDS stores are inline asm: a conditional LDS instruction the compiler can see makes it lose count of what is outstanding -- it
+    // then waits lgkmcnt(0) in front of every quad's MFMAs.  Hidden from it, the count it keeps (the eight A reads) stays exact: hidden
+    // stores only add to what is outstanding, so its waits are at worst early; the slab is read only behind the hand-off barrier, whose
+    // s_waitcnt lgkmcnt(0) covers the stores.
+    __device__ __forceinline__ void commit(const ml_f32x4 (&v)[4], int piece) const {
+        const unsigned a = (unsigned)(uintptr_t)(dst + piece * 1024);      // (LDS byte address: the low 32 bits of the generic pointer)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[256 * i] = SET ? v1[i] : v0[i];
+        for (int i = 0; i < 4; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(v[i]), "n"(4096 * i) : "memory");
     }
 };
 
@@ -89,50 +98,70 @@ __device__ __forceinline__ void ml_static_for(F&& f) {
 
 // acc[m] = sum_s A(m, s) h[s >> 2][s & 3] over the KQ K quads; A from the LDS slab `wl` ([m][sq][lane][4]).  The next slab is staged in
 // pieces of 1024 float4 between the K quads (`npieces` in all; more pieces than quads: the rest follow the last one).
+#ifndef SDA_ML_VAR
+#define SDA_ML_VAR 0      // (tooling: 1 = no slab commits, 2 = no A reads, 4 = no slab loads -- timing only, results are wrong)
+#endif
 template <int MF, int KQ>
 __device__ __forceinline__ void ml_mm(const float* wl, const ml_f32x4 (&h)[8], ml_f32x4 (&acc)[8], const ml_f32x4 (&cinit)[8], MlStage& st,
-                                      const MlCtx& c) {
+                                      const MlCtx& c, float* sp, const ml_f32x4 (&sreg)[8]) {
     const ml_f32x4* wa = reinterpret_cast<const ml_f32x4*>(wl) + c.lane;
     const int npieces = st.npieces;
     ml_f32x4 A[2][MF];
+    ml_f32x4 sv[KQ][4];                                    // (staging registers of piece sq: live from quad sq to quad sq + 1 only)
 #pragma unroll
     for (int m = 0; m < MF; ++m) A[0][m] = wa[(m * KQ) * 64];
     ml_static_for<0, KQ>([&](auto SQ_) {
         constexpr int sq = decltype(SQ_)::value;
-        // (piece sq - 1 was issued a whole K quad ago)
-        if constexpr (sq >= 1) { if (sq - 1 < npieces) st.template commit<(sq + 1) & 1>(sq - 1); }
-        if (sq < npieces) st.template issue<sq & 1>(sq);
-        if (sq + 1 < KQ) {
+        // The NEXT quad's A fragments are requested first (a whole quad of MFMAs, 1024 cycles, to arrive; left to itself the scheduler
+        // sinks them behind the 27th MFMA and the next quad opens on their latency).  The staging -- commit the piece loaded a quad ago,
+        // load this quad's -- sits in the MIDDLE of the quad's MFMAs: the LDS counter retires in order and the compiler does not see the
+        // commit's stores, so its wait for these A fragments at the top of the next quad also covers the stores -- half a quad old by then.
+        if (sq + 1 < KQ && !(SDA_ML_VAR & 2)) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) A[(sq + 1) & 1][m] = wa[(m * KQ + sq + 1) * 64];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_sched_barrier(0);
+        auto mfmas = [&](int r) {
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
                 // (the accumulators start from `cinit` -- the bias -- instead of zero: no add in the epilogue)
                 const ml_f32x4 cin = (sq == 0 && r == 0) ? cinit[m] : acc[m];
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[sq & 1][m][r], h[sq][r], cin, 0, 0, 0);
             }
+        };
+        mfmas(0); mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+#if !(SDA_ML_VAR & 1)
+        if constexpr (sq >= 1) { if (sq - 1 < npieces) st.commit(sv[sq - 1], sq - 1); }
+#endif
+#if !(SDA_ML_VAR & 4)
+        if (sq < npieces) st.issue(sv[sq], sq);
+#endif
+        // one 16-byte store of a saved stream (the block input or the pre-activation, for the VJP) per quad: in a burst in the epilogue
+        // the 16 stores per lane queue behind the CU's 64 B/clk store path with nothing else for the wave to do (~11 000 cycles of a
+        // tile's 172 000, and the waves reach the hand-off barrier apart); one per 32 MFMAs never queues
+        if constexpr (MF == 8 && KQ == 8) { if (sp) *reinterpret_cast<ml_f32x4*>(sp + 16 * sq) = sreg[sq]; }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(2); mfmas(3);
         __builtin_amdgcn_sched_barrier(0);
     });
-    if (KQ - 1 < npieces) st.template commit<(KQ - 1) & 1>(KQ - 1);
-    for (int p = KQ; p < npieces; ++p) { st.template issue<0>(p); st.template commit<0>(p); }
+    if (KQ - 1 < npieces) st.commit(sv[KQ - 1], KQ - 1);
+    for (int p = KQ; p < npieces; ++p) { ml_f32x4 t[4]; st.issue(t, p); st.commit(t, p); }
 #pragma unroll
     for (int m = MF; m < 8; ++m) acc[m] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 __device__ __forceinline__ void ml_gemm(const float* wl, int in_f, int out_f, const ml_f32x4 (&h)[8], ml_f32x4 (&acc)[8],
-                                        const ml_f32x4 (&cinit)[8], MlStage& st, const MlCtx& c) {
+                                        const ml_f32x4 (&cinit)[8], MlStage& st, const MlCtx& c, float* sp, const ml_f32x4 (&sreg)[8]) {
     const int mf = ml_mf(out_f), kq = ml_kq(in_f);
     if (mf == 8) {
-        if (kq == 8) ml_mm<8, 8>(wl, h, acc, cinit, st, c);
-        else if (kq == 4) ml_mm<8, 4>(wl, h, acc, cinit, st, c);
-        else ml_mm<8, 1>(wl, h, acc, cinit, st, c);
+        if (kq == 8) ml_mm<8, 8>(wl, h, acc, cinit, st, c, sp, sreg);      // (the only shape that takes a save stream: callers pass
+        else if (kq == 4) ml_mm<8, 4>(wl, h, acc, cinit, st, c, nullptr, sreg);   //  sp only for 128 -> 128)
+        else ml_mm<8, 1>(wl, h, acc, cinit, st, c, nullptr, sreg);
     } else {
-        if (kq == 8) ml_mm<1, 8>(wl, h, acc, cinit, st, c);
-        else if (kq == 4) ml_mm<1, 4>(wl, h, acc, cinit, st, c);
-        else ml_mm<1, 1>(wl, h, acc, cinit, st, c);
+        if (kq == 8) ml_mm<1, 8>(wl, h, acc, cinit, st, c, nullptr, sreg);
+        else if (kq == 4) ml_mm<1, 4>(wl, h, acc, cinit, st, c, nullptr, sreg);
+        else ml_mm<1, 1>(wl, h, acc, cinit, st, c, nullptr, sreg);
     }
 }
 
@@ -205,11 +234,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
     ML_T0();
     MlStage st;
     // slab 0 -> buffer 0
-    st.src = reinterpret_cast<const ml_f32x4*>(d.w + d.w_off[0]) + c.tid;
+    st.src = ml_rsrc(d.w + d.w_off[0]); st.toff = 16u * c.tid;
     st.dst = reinterpret_cast<ml_f32x4*>(ml_lds) + c.tid;
     st.npieces = ml_slab_floats(d.in_f[0], d.out_f[0]) / ML_PIECE;
-    for (int p = 0; p < st.npieces; ++p) { st.template issue<0>(p); st.template commit<0>(p); }
-    ml_f32x4 h[8], a[8], acc[8];
+    for (int p = 0; p < st.npieces; ++p) { ml_f32x4 t[4]; st.issue(t, p); st.commit(t, p); }
+    // every GEMM's bias -> LDS, once (read per GEMM as the C operand of its first MFMAs: from global memory each first MFMA waited a
+    // full L2 round trip -- 14 x ~2 000 cycles of a tile's 120 000 in the GEMM phase)
+    float* const bl = ml_lds + 2 * ML_SLAB;
+    {
+        const int nb = d.b_off[d.ngemm - 1] + 16 * ml_mf(d.out_f[d.ngemm - 1]);
+        for (int i = c.tid; i < nb; i += 256) bl[i] = d.bias[i];
+    }
+    ml_f32x4 h[8], a[8], acc[8], zs[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) zs[m] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (WIN) {
         // row (b, i): features [0, WC) = x[b][i .. i + 2k][:] -- WC consecutive floats of the trajectory --, then the time embedding
         const MlWinRow wr = ml_win_row(w, c);
@@ -234,14 +272,14 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
     for (int g = 0; g < d.ngemm; ++g) {
         const float* wl = ml_lds + (g & 1) * ML_SLAB;
         const bool last = g + 1 == d.ngemm;
-        st.src = reinterpret_cast<const ml_f32x4*>(d.w + (last ? 0 : d.w_off[g + 1])) + c.tid;
+        st.src = ml_rsrc(d.w + (last ? 0 : d.w_off[g + 1])); st.toff = 16u * c.tid;
         st.dst = reinterpret_cast<ml_f32x4*>(ml_lds + ((g + 1) & 1) * ML_SLAB) + c.tid;
         st.npieces = last ? 0 : ml_slab_floats(d.in_f[g + 1], d.out_f[g + 1]) / ML_PIECE;
         const int mf = ml_mf(d.out_f[g]), cw = d.in_f[g];
         // the bias is the C operand of the GEMM's first MFMAs: loaded here, long before it is needed
         ml_f32x4 bias[8];
         {
-            const float* bg = d.bias + d.b_off[g] + 4 * c.kq;
+            const float* bg = bl + d.b_off[g] + 4 * c.kq;
 #pragma unroll
             for (int m = 0; m < 8; ++m) bias[m] = m < mf ? *reinterpret_cast<const ml_f32x4*>(bg + 16 * m) : ml_f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -282,10 +320,20 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
             }
             ML_STAMP(3);                                   // a_save, LayerNorm
         }
-        if (d.kind[g] == 0) ml_gemm(wl, d.in_f[g], d.out_f[g], a, acc, bias, st, c);
-        else ml_gemm(wl, d.in_f[g], d.out_f[g], h, acc, bias, st, c);
+        ML_STAMP(1);                                       // GEMM set-up (stage descriptor, bias fragments)
+        // the save streams ride the 128 -> 128 multiplies (one store per K quad, see ml_mm): the block input under the block's first
+        // multiply, the pre-activation -- a copy, the accumulators are rewritten -- under its second; other widths store in the epilogue
+        const bool ride = d.z_save && cw == 128 && c.rowok;
+        if (d.kind[g] == 0) ml_gemm(wl, d.in_f[g], d.out_f[g], a, acc, bias, st, c, nullptr, a);
+        else if (d.kind[g] == 1)
+            ml_gemm(wl, d.in_f[g], d.out_f[g], h, acc, bias, st, c,
+                    ride ? d.a_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq : nullptr, a);
+        else
+            ml_gemm(wl, d.in_f[g], d.out_f[g], h, acc, bias, st, c,
+                    ride ? d.z_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq : nullptr, zs);
+        ML_STAMP(2);                                       // GEMM (+ staging)
         __syncthreads();                                   // slab hand-off: the next slab is complete, this one is free
-        ML_STAMP(2);                                       // GEMM (+ staging, + barrier)
+        ML_STAMP(5);                                       // hand-off barrier
         if (d.kind[g] == 0) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) a[m] = acc[m];
@@ -294,16 +342,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
             // the saves (block input a, pre-activation z) go out HERE, behind the GEMM whose slab staging has just completed: vmcnt
             // retires in order, so a store issued in front of staging loads makes the wait for those loads a wait for the store's
             // round trip to HBM (the block input written before the GEMM cost the forward ~20 %)
-            if (d.z_save && c.rowok) {
-                float* zs = d.z_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq;
+            if (d.z_save && c.rowok && d.out_f[g] != 128) {
+                float* zp = d.z_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq;
                 float* as = d.a_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq;
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
                     if (m < mf) {
-                        *reinterpret_cast<ml_f32x4*>(zs + 16 * m) = acc[m];
+                        *reinterpret_cast<ml_f32x4*>(zp + 16 * m) = acc[m];
                         *reinterpret_cast<ml_f32x4*>(as + 16 * m) = a[m];
                     }
             }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) zs[m] = acc[m];
             auto epi = [&](auto SILU_) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
@@ -355,6 +405,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
     } else {
         ml_store_rows(d.out, d.out_ld, d.out_f[d.ngemm - 1], c, a);
     }
+    ML_STAMP(6);                                           // output
+    ML_DUMP();
 }
 
 // ------------------------------------------------------------------------------------------------------------ input VJP
@@ -367,10 +419,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, cons
     ml_ctx(c, d);
     const int gl = d.ngemm - 1;
     MlStage st;
-    st.src = reinterpret_cast<const ml_f32x4*>(d.w + d.w_off[gl]) + c.tid;
+    st.src = ml_rsrc(d.w + d.w_off[gl]); st.toff = 16u * c.tid;
     st.dst = reinterpret_cast<ml_f32x4*>(ml_lds) + c.tid;
     st.npieces = ml_slab_floats(d.out_f[gl], d.in_f[gl]) / ML_PIECE;
-    for (int p = 0; p < st.npieces; ++p) { st.template issue<0>(p); st.template commit<0>(p); }
+    for (int p = 0; p < st.npieces; ++p) { ml_f32x4 t[4]; st.issue(t, p); st.commit(t, p); }
     ml_f32x4 h[8], gacc[8], acc[8], zero[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) zero[m] = ml_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -399,7 +451,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, cons
     for (int g = gl; g >= 0; --g, buf ^= 1) {
         const float* wl = ml_lds + buf * ML_SLAB;
         const bool last = g == 0;
-        st.src = reinterpret_cast<const ml_f32x4*>(d.w + (last ? 0 : d.w_off[g - 1])) + c.tid;
+        st.src = ml_rsrc(d.w + (last ? 0 : d.w_off[g - 1])); st.toff = 16u * c.tid;
         st.dst = reinterpret_cast<ml_f32x4*>(ml_lds + (buf ^ 1) * ML_SLAB) + c.tid;
         st.npieces = last ? 0 : ml_slab_floats(d.out_f[g - 1], d.in_f[g - 1]) / ML_PIECE;
         if (d.kind[g] == 2) --rb;
@@ -418,8 +470,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, cons
             }
         }
         // the multiply's input: the cotangent g itself (Linear; a block's second half) or q (its first half)
-        if (d.kind[g] == 1) ml_gemm(wl, d.out_f[g], d.in_f[g], h, acc, zero, st, c);
-        else ml_gemm(wl, d.out_f[g], d.in_f[g], gacc, acc, zero, st, c);
+        if (d.kind[g] == 1) ml_gemm(wl, d.out_f[g], d.in_f[g], h, acc, zero, st, c, nullptr, zero);
+        else ml_gemm(wl, d.out_f[g], d.in_f[g], gacc, acc, zero, st, c, nullptr, zero);
         __syncthreads();
         if (d.kind[g] == 0) {
 #pragma unroll
@@ -488,6 +540,7 @@ static int mlp_check(const sda_mlp_desc* d, bool bwd, bool win) {
         if ((d->w_off[g] & 3) || (d->b_off[g] & 3)) return SDA_E_BADARG;
     }
     if ((reinterpret_cast<uintptr_t>(d->w) & 15) || (!bwd && (reinterpret_cast<uintptr_t>(d->bias) & 15))) return SDA_E_BADARG;
+    if (!bwd && d->b_off[d->ngemm - 1] + 16 * ml_mf(d->out_f[d->ngemm - 1]) > ML_BIAS) return SDA_E_UNSUPPORTED;
     const bool saves = d->a_save && d->z_save && d->mean_save && d->rstd_save;
     if (nres > 0) {
         if (bwd && !saves) return SDA_E_BADARG;
@@ -523,7 +576,7 @@ static int mlp_launch(const sda_mlp_desc* d, const sda_mlp_win* w, hipStream_t s
     if (WIN && (rc = mlp_win_check(d, w, BWD)) != SDA_OK) return rc;
     const int64_t tiles = ((int64_t)d->rows + 63) / 64;
     if (tiles > 0x7fffffffLL) return SDA_E_UNSUPPORTED;
-    constexpr int lds = 2 * ML_SLAB * 4;
+    constexpr int lds = (2 * ML_SLAB + ML_BIAS) * 4;
     static bool raised[SDA_MAX_DEVICES];
     const void* kern = BWD ? reinterpret_cast<const void*>(mlp_bwd_kernel<WIN>) : reinterpret_cast<const void*>(mlp_fwd_kernel<WIN>);
     const int rr = sda_raise_dyn_lds(kern, lds, raised);

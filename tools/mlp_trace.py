@@ -22,8 +22,8 @@ N = 20
 for _ in range(N): net(x)
 torch.cuda.synchronize()
 lib.sda_ml_trace_read(buf, 0)
-names = ['first slab + input rows', '-', 'GEMM (MFMA + slab staging + hand-off barrier)', 'a_save + LayerNorm', 'epilogue (bias / z_save / act / residual)']
-tot = sum(buf[i] for i in range(5)) / N
+names = ['first slab + input rows', 'GEMM set-up (stage descriptor, bias fragments)', 'GEMM (MFMAs, A reads, slab staging)', 'LayerNorm', 'epilogue (saves / act / residual)', 'slab hand-off barrier', 'output rows']
+tot = sum(buf[i] for i in range(7)) / N
 for i, n in enumerate(names):
     print(f'{n:46s} {buf[i] / N:10.0f} cycles  {100 * buf[i] / N / tot:5.1f} %')
 print(f'{"sum":46s} {tot:10.0f} cycles (MFMA floor of a 64-row tile: ~87 000)')
