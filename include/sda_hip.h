@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 7
+#define SDA_ABI_VERSION 8
 
 enum {
     SDA_OK = 0,
@@ -122,6 +122,11 @@ typedef struct sda_conv_desc {
      * fusion, no epilogue operand): 7 of the 16 Winograd positions have weight zero in the cell sum and are never multiplied.
      * Anything else: SDA_E_UNSUPPORTED (run the plain launch and pool in the reader, sda_ln_bwd's pool arguments). */
     int32_t pool_h, pool_w;
+    /* optional (may be NULL): the w_wino4 weights re-packed for the zero-position kernels (sda_pack_conv_weight_wino4_zp) -- per
+     * (K stage, 96-cout tile) the 9 live Winograd positions only, 28 KiB instead of the 36 KiB of the six position pairs that hold
+     * them.  With it the 2 x 2 up-sampled / pooled launches above run their zero-position form; without it the up-sampled launch
+     * runs the full kernel (same result bit for bit) and the pooled launch is SDA_E_UNSUPPORTED. */
+    const float* w_wino4_zp;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
@@ -268,6 +273,13 @@ int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, 
 /* U for the second-generation Winograd kernel: dst[k_pad/8][16][m_pad/16][64][2], k_pad % 8 == 0, m_pad % 96 == 0. */
 int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                                int m_pad, void* stream);
+/* The zero-position packing of a sda_pack_conv_weight_wino4 buffer (sda_conv_desc.w_wino4_zp): dst holds
+ * sda_wino4_zp_floats(k_pad, m_pad) = (k_pad / 8) * (m_pad / 96) * 7168 floats, [K stage][cout tile][7168]: the three position pairs
+ * whose two positions are both live (6 x 256 float4 each), the live halves of the pairs (2, 3) and (6, 7) interleaved into one such block,
+ * the live half of pair (14, 15) as 6 x 256 float2, zero padding to 28 KiB -- the order the kernel's LDS stage buffer has, so that a
+ * helper wave copies seven linear 1-KiB pieces.  Values are copied, not recomputed: the kernels stay bit-identical to the full ones. */
+int sda_pack_conv_weight_wino4_zp(const float* w_wino4, int k_pad, int m_pad, float* dst, void* stream);
+int64_t sda_wino4_zp_floats(int k_pad, int m_pad);
 
 /* ------------------------------------------------------------------------------------------
  * zuko.nn.LayerNorm(dim=-(spatial+1)) statistics: per pixel, over channels, of (x + mod).

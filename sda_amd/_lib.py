@@ -53,6 +53,7 @@ class ConvDesc(Structure):
         ('out_sn', c_int64), ('out_sc', c_int64), ('out_sy', c_int64), ('out_sx', c_int64),
         ('w_wino4', c_fp),
         ('pool_h', ctypes.c_int32), ('pool_w', ctypes.c_int32),
+        ('w_wino4_zp', c_fp),
     ]
 
 
@@ -174,6 +175,8 @@ SIGNATURES = {
     'sda_pack_conv_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_pack_conv_weight_wino': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
     'sda_pack_conv_weight_wino4': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_void_p]),
+    'sda_pack_conv_weight_wino4_zp': (c_int, [c_fp, c_int, c_int, c_fp, c_void_p]),
+    'sda_wino4_zp_floats': (c_int64, [c_int, c_int]),
     'sda_ln_stats': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_float, c_int, c_fp, c_fp, c_void_p]),
     'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
     'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,

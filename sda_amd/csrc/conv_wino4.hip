@@ -47,6 +47,9 @@
 #define W4_NSLOT 3                     // ceil(18 * 10 / 64) halo positions per lane and channel
 #define W4_UPP (6 * 64 * 4)            // floats per position PAIR in a U buffer: [cout fragment 6][lane 64][h 2][k4 2]
 #define W4_UBUF (8 * W4_UPP)           // 12288 floats = 48 KiB
+#define W4_UZP 7168                    // floats of a stage's U slab in the zero-position packing (sda_pack_conv_weight_wino4_zp): the full pairs
+                                       // 0 / 2 / 6 at 0 / 1536 / 3072, the live halves of pairs 1 and 3 interleaved at 4608, pair 7's at 6144
+                                       // (float2 per lane), zero padding from 6912 -- 28 KiB, seven 1-KiB pieces per helper wave
 #define W4_VKQ 128                     // floats per kq plane of V: [k4 2][tile 32][h 2]
 #define W4_VPP (4 * W4_VKQ)            // floats per position pair in a V buffer
 #define W4_VBUF (8 * W4_VPP)           // 4096 floats = 16 KiB
@@ -86,6 +89,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
     // pooled output (2 x 2 cell sums at half resolution): plain launches without an epilogue operand only
     if (d->pool_h > 1 || d->pool_w > 1) {
+        if (!d->w_wino4_zp || (reinterpret_cast<uintptr_t>(d->w_wino4_zp) & 15)) return SDA_E_UNSUPPORTED;
         if (d->pool_h != 2 || d->pool_w != 2 || d->mod || d->ln_mean || d->act_in != SDA_ACT_NONE || d->res || d->dact_z || d->cctx ||
             (reinterpret_cast<uintptr_t>(d->out) & 3))
             return SDA_E_UNSUPPORTED;
@@ -483,26 +487,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 12 KiB = 12 wave-wide dwordx4 (one per cout fragment and pair)
         f32x4 ureg[12];
-        // ZP: the pairs 4, 5 (positions 8 .. 11) are never multiplied -- the six live pairs are dealt out as 9 fragments per helper:
-        // one whole pair zp_full and three cout fragments (zp_mo ..) of the pair zp_half
-        const int zp_full = pw == 0 ? 0 : (pw == 1 ? 2 : (pw == 2 ? 3 : 7));
-        const int zp_half = pw < 2 ? 1 : 6, zp_mo = 3 * (pw & 1);
+        // ZP: 9 of the 16 positions are multiplied; the slab comes position-packed (W4_UZP: 28 KiB instead of the 36 KiB of the six pairs
+        // that hold a live position) and in the stage buffer's own order -- helper pw copies the linear pieces 7 pw .. 7 pw + 6.  The
+        // up-sampled / pooled layers are vector-memory bound on the helper side (two workgroups' U, halo and operand loads share the CU's
+        // 64 B/clk address path): dropping three of the former nine loads per helper measured -16.5 / -19 % per layer
+        // (profiles/r04_zp_packed_u.txt).
         auto u_load = [&](const W4Cur& t) {
             const int64_t pstride = (int64_t)g.mtiles * 1024;         // bytes between position pairs
             if constexpr (ZPOS) {
-                const char* base = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8) * g.mtiles + 6 * t.ct) * 256);
-                const char* sp = base + zp_full * pstride;
-                const char* sq = sp + 3072;
-                const char* sh = base + zp_half * pstride + zp_mo * 1024;
-                w4_ld4<0>(ureg[0], sp, lane16);
-                w4_ld4<1024>(ureg[1], sp, lane16);
-                w4_ld4<2048>(ureg[2], sp, lane16);
-                w4_ld4<0>(ureg[3], sq, lane16);
-                w4_ld4<1024>(ureg[4], sq, lane16);
-                w4_ld4<2048>(ureg[5], sq, lane16);
-                w4_ld4<0>(ureg[6], sh, lane16);
-                w4_ld4<1024>(ureg[7], sh, lane16);
-                w4_ld4<2048>(ureg[8], sh, lane16);
+                const char* b0 = reinterpret_cast<const char*>(d.w_wino4_zp + ((int64_t)t.st * g.n_ct + t.ct) * W4_UZP) + pw * 7168;
+                const char* b1 = b0 + 3072;
+                const char* b2 = b0 + 6144;
+                w4_ld4<0>(ureg[0], b0, lane16);
+                w4_ld4<1024>(ureg[1], b0, lane16);
+                w4_ld4<2048>(ureg[2], b0, lane16);
+                w4_ld4<0>(ureg[3], b1, lane16);
+                w4_ld4<1024>(ureg[4], b1, lane16);
+                w4_ld4<2048>(ureg[5], b1, lane16);
+                w4_ld4<0>(ureg[6], b2, lane16);
                 return;
             }
             const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
@@ -525,12 +527,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     W4_PIN_EPI()
         auto u_store = [&](float* ub) {
             if constexpr (ZPOS) {
-                float* df = ub + zp_full * W4_UPP + lane * 4;
-                float* dh = ub + zp_half * W4_UPP + zp_mo * 256 + lane * 4;
+                float* dz = ub + pw * 1792 + lane * 4;
 #pragma unroll
-                for (int m = 0; m < 6; ++m) *reinterpret_cast<f32x4*>(df + m * 256) = ureg[m];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) *reinterpret_cast<f32x4*>(dh + m * 256) = ureg[6 + m];
+                for (int m = 0; m < 7; ++m) *reinterpret_cast<f32x4*>(dz + m * 256) = ureg[m];
                 return;
             }
             float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
@@ -650,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         W4_TRACE_DECL;
         constexpr int NHL = 2 * NSL + (LN ? 2 * NSL : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
-        constexpr int NUL = ZPOS ? 9 : 12, NPF = EPI ? 4 : 1;   // loads per helper's share of the U slab / per prefetch (EPI: operand loads)
+        constexpr int NUL = ZPOS ? 7 : 12, NPF = EPI ? 4 : 1;   // loads per helper's share of the U slab / per prefetch (EPI: operand loads)
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;
@@ -785,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     // for position p = 5 = (xi, nu) = (1, 1): A^T e_11 A is the all-ones 2 x 2 block, so a bias placed there comes out of the
     // inverse transform added to every output pixel (no zero-fill and no bias adds in the epilogue).
     f32x4 av[2][3];
+    f32x2 av7[3];                                          // (ZP: step 7's A operands, position 15 alone)
     f32x2 bv[2][2];                                        // [buffer][k4] -> (h = 0, h = 1)
     auto fetch = [&](int qq, int s, int buf) {
         const float* ua = ubuf + (qq & 1) * W4_UBUF + ard;
@@ -794,6 +794,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         typedef const volatile f32x2 __attribute__((address_space(3))) * lds_cv2;
         bv[buf][0] = *(lds_cv2)(va + s * W4_VPP);
         bv[buf][1] = *(lds_cv2)(va + s * W4_VPP + 64);
+        if constexpr (ZPOS) {
+            // the position-packed slab (W4_UZP): steps 0 / 2 / 6 read their pair, steps 1 and 3 the block that interleaves their live
+            // positions 3 and 7 ((k4 0, k4 1) of position 3, then of position 7: step 3 finds its operands where a full pair has them),
+            // step 7 the 8-byte values of position 15
+            if (s == 7) {
+                const float* u7 = ubuf + (qq & 1) * W4_UBUF + 6144 + (ard >> 1);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) av7[m] = *reinterpret_cast<const f32x2*>(u7 + m * 128);
+            } else {
+                const int off = s == 0 ? 0 : (s == 2 ? 1536 : (s == 6 ? 3072 : 4608));
+#pragma unroll
+                for (int m = 0; m < 3; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + off + m * 256);
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + s * W4_UPP + m * 256);
     };
@@ -827,7 +842,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                         f32x4 c;
                         if (FIRST && k4 == 0) c = (p == 5) ? binit[m] : f32x4{0.f, 0.f, 0.f, 0.f};
                         else c = acc[p][m];
-                        acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][m][2 * h + k4], bv[s & 1][k4][h], c, 0, 0, 0);
+                        const float aop = (ZPOS && s == 7) ? av7[m][k4] : ((ZPOS && s == 1) ? av[s & 1][m][k4] : av[s & 1][m][2 * h + k4]);
+                        acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bv[s & 1][k4][h], c, 0, 0, 0);
                     }
             // pin the software pipeline: the four LDS reads of the NEXT step are spread between this step's MFMAs (a read
             // issued right behind an MFMA costs the stream nothing, a group of four ~12 cycles) -- except in step 6, whose
@@ -1108,8 +1124,8 @@ static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
 // configuration: LayerNorm loader + skip operand through the helpers), 0 = the full kernels
 static int wino4_zp(const sda_conv_desc* d, const Wino4Geom& g) {
     static const bool zp_on = !(getenv("SDA_W4_ZP") && atoi(getenv("SDA_W4_ZP")) == 0);
-    if (d->pool_h > 1 || d->pool_w > 1) return 2;
-    return (zp_on && d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2 && wino4_epm(d, g) == 1) ? 1 : 0;
+    if (d->pool_h > 1 || d->pool_w > 1) return 2;                                               // (the plan requires w_wino4_zp)
+    return (zp_on && d->w_wino4_zp && !(reinterpret_cast<uintptr_t>(d->w_wino4_zp) & 15) && d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2 && wino4_epm(d, g) == 1) ? 1 : 0;
 }
 
 int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t stream) {
@@ -1250,5 +1266,45 @@ extern "C" int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_wino4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transpose, cin_keep,
                        dst, k_pad, m_pad);
+    return sda_launch_status();
+}
+
+// ---- the zero-position packing of a w_wino4 buffer (W4_UZP above; sda_hip.h: sda_pack_conv_weight_wino4_zp): values are copied
+__global__ void pack_wino4_zp_kernel(const float* __restrict__ src, float* __restrict__ dst, int nstage, int n_ct) {
+    const int64_t total = (int64_t)nstage * n_ct * W4_UZP;
+    const int mtiles = 6 * n_ct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % W4_UZP);
+        const int64_t blk = i / W4_UZP;
+        const int ct = (int)(blk % n_ct), st = (int)(blk / n_ct);
+        auto at = [&](int pair, int m, int lane, int e) {
+            return src[((((int64_t)st * 8 + pair) * mtiles + 6 * ct + m) * 64 + lane) * 4 + e];
+        };
+        float v = 0.f;
+        if (j < 4608) {                                    // full pairs 0, 2, 6
+            const int fi = j / 1536, r = j % 1536;
+            v = at(fi == 0 ? 0 : (fi == 1 ? 2 : 6), r / 256, (r % 256) / 4, r & 3);
+        } else if (j < 6144) {                             // positions 3 | 7: the h = 1 halves of pairs 1 and 3
+            const int r = j - 4608, e = r & 3;
+            v = e < 2 ? at(1, r / 256, (r % 256) / 4, 2 + e) : at(3, r / 256, (r % 256) / 4, e);
+        } else if (j < 6912) {                             // position 15: the h = 1 half of pair 7
+            const int r = j - 6144;
+            v = at(7, r / 128, (r % 128) / 2, 2 + (r & 1));
+        }
+        dst[i] = v;
+    }
+}
+
+extern "C" int64_t sda_wino4_zp_floats(int k_pad, int m_pad) {
+    if (k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
+    return (int64_t)(k_pad / 8) * (m_pad / W4_BM) * W4_UZP;
+}
+
+extern "C" int sda_pack_conv_weight_wino4_zp(const float* w_wino4, int k_pad, int m_pad, float* dst, void* stream) {
+    if (!w_wino4 || !dst || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
+    const int64_t total = sda_wino4_zp_floats(k_pad, m_pad);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_wino4_zp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_wino4, dst, k_pad / 8, m_pad / W4_BM);
     return sda_launch_status();
 }

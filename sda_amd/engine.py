@@ -182,6 +182,7 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
         for t in (dact_z, res):
             if t is not None and tuple(t.stride()) != out_strides:
                 raise SdaHipError('conv epilogue operands must share the layout of the output view')
+    zp = pk.wino4_zp() if (tuple(up) == (2, 2) or tuple(pool) == (2, 2)) and hasattr(pk, 'wino4_zp') else None
     d = make_conv_desc(**src, w_ptr=pk.packed.data_ptr(), cin_pad=pk.k_pad, cout_pad=pk.m_pad, cout=pk.m_real,
                        kh=pk.kh, kw=pk.kw, out_ptr=out.data_ptr(), ho=ho, wo=wo, mt=pk.mt,
                        stride_h=stride[0], stride_w=stride[1], circular=circular, up_h=up[0], up_w=up[1],
@@ -195,7 +196,7 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        res_ptr=None if res is None else res.data_ptr(),
                        w_wino_ptr=None if getattr(pk, 'wino', None) is None else pk.wino.data_ptr(),
                        w_wino4_ptr=None if getattr(pk, 'wino4', None) is None else pk.wino4.data_ptr(),
-                       pad=pad, out_strides=out_strides, pool=pool)
+                       pad=pad, out_strides=out_strides, pool=pool, w_wino4_zp_ptr=None if zp is None else zp.data_ptr())
     if pool != (1, 1):
         return d if ops.conv_pooled(d) else None
     if parity4_w is not None:

@@ -59,7 +59,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
                    stride_h=1, stride_w=1, circular=False, up_h=1, up_w=1, zins_h=1, zins_w=1,
                    ctx_ptr=None, cctx=0, ctx_sn=0, mod_ptr=None, mod_sn=0, ln_mean_ptr=None, ln_rstd_ptr=None,
                    act_in=0, bias_ptr=None, dact_z_ptr=None, act_d=0, res_ptr=None, w_wino_ptr=None,
-                   w_wino4_ptr=None, pad=None, out_strides=(0, 0, 0, 0), pool=(1, 1)) -> ConvDesc:
+                   w_wino4_ptr=None, pad=None, out_strides=(0, 0, 0, 0), pool=(1, 1), w_wino4_zp_ptr=None) -> ConvDesc:
     d = ConvDesc()
     d.x = x_ptr
     d.x_sn_outer, d.x_sn_inner, d.n_inner, d.x_n_off = x_sn_outer, x_sn_inner, n_inner, x_n_off
@@ -84,6 +84,7 @@ def make_conv_desc(*, x_ptr, n, cx, hs, ws, x_sc, x_sy, x_sx, x_sn_outer, x_sn_i
     d.pad_h, d.pad_w = (0, 0) if pad is None else pad
     d.out_sn, d.out_sc, d.out_sy, d.out_sx = out_strides
     d.pool_h, d.pool_w = pool
+    d.w_wino4_zp = w_wino4_zp_ptr
     return d
 
 
@@ -253,6 +254,20 @@ class PackedConv:
             _lib.check(_lib.load().sda_pack_conv_weight_wino4(w.data_ptr(), cout, cin, int(transpose), keep,
                                                               self.wino4.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino4')
+        # ... and its zero-position packing (sda_pack_conv_weight_wino4_zp: the 9 live Winograd positions of a 2 x 2 up-sampled / pooled
+        # launch, 28 KiB per K stage and cout tile instead of 36) -- made here, not on first use: a launch must not allocate (its operands
+        # may be views of freed temporaries the allocator would hand out again; a step may be under graph capture)
+        self._wino4_zp = None
+        if self.wino4 is not None:
+            lib = _lib.load()
+            self._wino4_zp = torch.empty(int(lib.sda_wino4_zp_floats(self.k_pad, self.m_pad)), device=w.device, dtype=torch.float32)
+            _lib.check(lib.sda_pack_conv_weight_wino4_zp(self.wino4.data_ptr(), self.k_pad, self.m_pad, self._wino4_zp.data_ptr(), _stream()),
+                       'sda_pack_conv_weight_wino4_zp')
+
+    def wino4_zp(self) -> Optional[Tensor]:
+        """The zero-position packing of `wino4` (None without it): what the up-sampling tails (sda/nn.py:161-169 of the reference) and
+        their VJPs multiply with."""
+        return self._wino4_zp
 
 
 # ------------------------------------------------------------------------------------------ fused 1-D residual block

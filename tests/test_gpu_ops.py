@@ -139,7 +139,8 @@ def test_conv_even_kernel_explicit_pad_strided_output(dev, circular, shape, kern
     resd = res.to(dev)
     pk = ops.PackedConv(w.to(dev), None)
     view = big[:, :, 1::2, 0::2]
-    launch_conv(pk, planar_source(x.to(dev)), view, h, w_, circular=circular, pad=(0, 0), res=resd[:, :, 1::2, 0::2])
+    xd = x.to(dev)                                     # (held: planar_source keeps addresses, not tensors)
+    launch_conv(pk, planar_source(xd), view, h, w_, circular=circular, pad=(0, 0), res=resd[:, :, 1::2, 0::2])
     torch.cuda.synchronize()
     assert_close(view.cpu(), ref + res[:, :, 1::2, 0::2], TOL)
     untouched = torch.ones(2 * h, 2 * w_, dtype=torch.bool)
@@ -581,7 +582,8 @@ def test_stride2_vjp_one_launch_random_shapes(dev):
         out = torch.full((n, cin, h, w_), float('nan'), device=dev)
         v00 = out[:, :, 0::2, 0::2]
         res = None if skip is None else skip.to(dev)[:, :, 0::2, 0::2]
-        d = launch_conv(classes[0][2], planar_source(g.to(dev)), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3],
+        gd = g.to(dev)
+        d = launch_conv(classes[0][2], planar_source(gd), v00, v00.shape[2], v00.shape[3], circular=circular, pad=classes[0][3],
                         res=res, parity4_w=w4)
         assert d is not None, (case, n, cin, cout, h, w_)
         want = gref if skip is None else gref + skip
@@ -702,7 +704,8 @@ def test_zero_position_kernels_random_shapes(dev):
         g = torch.randn_like(y)
         gref, = torch.autograd.grad(y, a, g)
         pooled = torch.full((n, cout, h // 2, w_ // 2), float('nan'), device=dev)
-        d = launch_conv(_ConvCache(conv.to(dev)).bwd(), planar_source(g.to(dev)), pooled, h, w_, circular=circular, pool=(2, 2))
+        gd, cc = g.to(dev), _ConvCache(conv.to(dev))      # (held: planar_source keeps addresses, not tensors)
+        d = launch_conv(cc.bwd(), planar_source(gd), pooled, h, w_, circular=circular, pool=(2, 2))
         assert d is not None and ops.conv_path(d) == 5, f'case {case}: pooled launch not served'
         assert_close(pooled.cpu(), gref, TOL, what=f'case {case}: pooled VJP')
 

@@ -66,7 +66,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         # ---- the hand-counted waits.  Loads per halo set / U slab quarter / prefetch as in the kernel source:
         nsl = 1 if zp == 1 else 3                        # halo slots per lane (up-sampled source: one source pixel per lane)
         nhl = 2 * nsl + (2 * nsl if ln else 0) + (2 if mod else 0)
-        nul = 9 if zp else 12                            # zero-position kernels: the six live position pairs, 9 fragments per helper
+        nul = 7 if zp else 12                            # zero-position kernels: the position-packed slab, seven 1-KiB pieces per helper
         npf = 4 if epm == 1 else 1
         npf_text = 28 if epm == 1 else 2                # EPI: 6 window slots x 4 + 4 dummies; else: the two arms of one branch
         wait_u, wait_halo = nhl + npf, min(63, 2 * (nhl + npf + nul) + nul)

@@ -65,7 +65,8 @@ def run_case(n, cin, cout, h, w_, circular, mod, ln, silu, up, dact, res, bias, 
     dopts = {}
     for k, v in opts.items():
         dopts[k] = tuple(t.to(dev).contiguous() for t in v) if k == 'ln' else (v.to(dev).contiguous() if torch.is_tensor(v) else v)
-    desc = launch_conv(pk, planar_source(x.to(dev)), out, h, w_, circular=circular, bias=pk.bias, **dopts)
+    xd = x.to(dev)
+    desc = launch_conv(pk, planar_source(xd), out, h, w_, circular=circular, bias=pk.bias, **dopts)
     torch.cuda.synchronize()
     path = ops.conv_path(desc)
     got = out.cpu().double()
