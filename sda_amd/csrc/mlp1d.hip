@@ -165,6 +165,15 @@ __device__ __forceinline__ void ml_gemm(const float* wl, int in_f, int out_f, co
     }
 }
 
+// a GEMM's descriptor entries.  They are read from the kernel-argument segment by a run-time index -- scalar loads, ~300 cycles each time
+// the loop needs them right away; the loops keep the current and the next GEMM's in registers and fetch the one after next's while a GEMM
+// multiplies (14 GEMMs per tile: ~10 000 of a tile's 168 000 cycles were this set-up)
+struct MlMeta { int kind, in_f, out_f, b_off, w_off; };
+__device__ __forceinline__ MlMeta ml_meta(const sda_mlp_desc& d, int g) {
+    g = g < 0 ? 0 : (g >= d.ngemm ? d.ngemm - 1 : g);
+    return MlMeta{d.kind[g], d.in_f[g], d.out_f[g], d.b_off[g], d.w_off[g]};
+}
+
 __device__ __forceinline__ void ml_ctx(MlCtx& c, const sda_mlp_desc& d) {
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.kq = c.lane >> 4; c.li = c.lane & 15;
     c.row = (int64_t)blockIdx.x * 64 + 16 * c.wave + c.li;
@@ -269,21 +278,23 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
     ML_STAMP(0);                                           // first slab + input rows
     const bool silu = d.act == SDA_ACT_SILU;
     int rb = 0;                                            // residual-block counter (index into the saves)
+    MlMeta mc = ml_meta(d, 0), mn = ml_meta(d, 1);
     for (int g = 0; g < d.ngemm; ++g) {
+        const MlMeta mm = ml_meta(d, g + 2);
         const float* wl = ml_lds + (g & 1) * ML_SLAB;
         const bool last = g + 1 == d.ngemm;
-        st.src = ml_rsrc(d.w + (last ? 0 : d.w_off[g + 1])); st.toff = 16u * c.tid;
+        st.src = ml_rsrc(d.w + (last ? 0 : mn.w_off)); st.toff = 16u * c.tid;
         st.dst = reinterpret_cast<ml_f32x4*>(ml_lds + ((g + 1) & 1) * ML_SLAB) + c.tid;
-        st.npieces = last ? 0 : ml_slab_floats(d.in_f[g + 1], d.out_f[g + 1]) / ML_PIECE;
-        const int mf = ml_mf(d.out_f[g]), cw = d.in_f[g];
+        st.npieces = last ? 0 : ml_slab_floats(mn.in_f, mn.out_f) / ML_PIECE;
+        const int mf = ml_mf(mc.out_f), cw = mc.in_f;
         // the bias is the C operand of the GEMM's first MFMAs: loaded here, long before it is needed
         ml_f32x4 bias[8];
         {
-            const float* bg = bl + d.b_off[g] + 4 * c.kq;
+            const float* bg = bl + mc.b_off + 4 * c.kq;
 #pragma unroll
             for (int m = 0; m < 8; ++m) bias[m] = m < mf ? *reinterpret_cast<const ml_f32x4*>(bg + 16 * m) : ml_f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (d.kind[g] == 1) {
+        if (mc.kind == 1) {
             // ---- residual block, first half: save a; h = LN(a)
             const float inv_c = 1.f / (float)cw, inv_v = 1.f / (float)(d.unbiased ? cw - 1 : cw);
             float mean, rstd;
@@ -324,25 +335,25 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
         // the save streams ride the 128 -> 128 multiplies (one store per K quad, see ml_mm): the block input under the block's first
         // multiply, the pre-activation -- a copy, the accumulators are rewritten -- under its second; other widths store in the epilogue
         const bool ride = d.z_save && cw == 128 && c.rowok;
-        if (d.kind[g] == 0) ml_gemm(wl, d.in_f[g], d.out_f[g], a, acc, bias, st, c, nullptr, a);
-        else if (d.kind[g] == 1)
-            ml_gemm(wl, d.in_f[g], d.out_f[g], h, acc, bias, st, c,
+        if (mc.kind == 0) ml_gemm(wl, mc.in_f, mc.out_f, a, acc, bias, st, c, nullptr, a);
+        else if (mc.kind == 1)
+            ml_gemm(wl, mc.in_f, mc.out_f, h, acc, bias, st, c,
                     ride ? d.a_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq : nullptr, a);
         else
-            ml_gemm(wl, d.in_f[g], d.out_f[g], h, acc, bias, st, c,
+            ml_gemm(wl, mc.in_f, mc.out_f, h, acc, bias, st, c,
                     ride ? d.z_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq : nullptr, zs);
         ML_STAMP(2);                                       // GEMM (+ staging)
         __syncthreads();                                   // slab hand-off: the next slab is complete, this one is free
         ML_STAMP(5);                                       // hand-off barrier
-        if (d.kind[g] == 0) {
+        if (mc.kind == 0) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) a[m] = acc[m];
-        } else if (d.kind[g] == 1) {
+        } else if (mc.kind == 1) {
             // z = W1 LN(a) + b1 (saved); h = act(z)
             // the saves (block input a, pre-activation z) go out HERE, behind the GEMM whose slab staging has just completed: vmcnt
             // retires in order, so a store issued in front of staging loads makes the wait for those loads a wait for the store's
             // round trip to HBM (the block input written before the GEMM cost the forward ~20 %)
-            if (d.z_save && c.rowok && d.out_f[g] != 128) {
+            if (d.z_save && c.rowok && mc.out_f != 128) {
                 float* zp = d.z_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq;
                 float* as = d.a_save + (int64_t)rb * d.save_stride + c.row * d.save_ld + 4 * c.kq;
 #pragma unroll
@@ -368,6 +379,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const sda_mlp_desc d, cons
             ++rb;
         }
         ML_STAMP(4);                                       // epilogue
+        mc = mn; mn = mm;
     }
     if constexpr (WIN) {
         // fold (score.py:155-164) + eps = (cx0 + cx1 sigma) x + cn s + the likelihood cotangent, as sda_net1d_fwd_fused's epilogue
@@ -448,35 +460,37 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, cons
     int rb = 0;
     for (int g = 0; g < d.ngemm; ++g) rb += d.kind[g] == 2;
     int buf = 0;
+    MlMeta mc = ml_meta(d, gl), mn = ml_meta(d, gl - 1);
     for (int g = gl; g >= 0; --g, buf ^= 1) {
+        const MlMeta mm = ml_meta(d, g - 2);
         const float* wl = ml_lds + buf * ML_SLAB;
         const bool last = g == 0;
-        st.src = ml_rsrc(d.w + (last ? 0 : d.w_off[g - 1])); st.toff = 16u * c.tid;
+        st.src = ml_rsrc(d.w + (last ? 0 : mn.w_off)); st.toff = 16u * c.tid;
         st.dst = reinterpret_cast<ml_f32x4*>(ml_lds + (buf ^ 1) * ML_SLAB) + c.tid;
-        st.npieces = last ? 0 : ml_slab_floats(d.out_f[g - 1], d.in_f[g - 1]) / ML_PIECE;
-        if (d.kind[g] == 2) --rb;
+        st.npieces = last ? 0 : ml_slab_floats(mn.out_f, mn.in_f) / ML_PIECE;
+        if (mc.kind == 2) --rb;
         // what the epilogue reads from the forward: issued before the multiply
-        const int cw = d.in_f[g], nm = ml_mf(cw);
+        const int cw = mc.in_f, nm = ml_mf(cw);
         const int64_t srow = c.rowok ? c.row : 0;
         ml_f32x4 sv[8];                                    // kind 2: z; kind 1: the block input a
         float mean = 0.f, rs = 0.f;
-        if (d.kind[g] != 0) {
-            const float* sp = (d.kind[g] == 2 ? d.z_save : d.a_save) + (int64_t)rb * d.save_stride + srow * d.save_ld + 4 * c.kq;
+        if (mc.kind != 0) {
+            const float* sp = (mc.kind == 2 ? d.z_save : d.a_save) + (int64_t)rb * d.save_stride + srow * d.save_ld + 4 * c.kq;
 #pragma unroll
             for (int m = 0; m < 8; ++m) sv[m] = m < nm ? *reinterpret_cast<const ml_f32x4*>(sp + 16 * m) : ml_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (d.kind[g] == 1) {
+            if (mc.kind == 1) {
                 mean = d.mean_save[(int64_t)rb * d.stat_stride + srow];
                 rs = d.rstd_save[(int64_t)rb * d.stat_stride + srow];
             }
         }
         // the multiply's input: the cotangent g itself (Linear; a block's second half) or q (its first half)
-        if (d.kind[g] == 1) ml_gemm(wl, d.out_f[g], d.in_f[g], h, acc, zero, st, c, nullptr, zero);
-        else ml_gemm(wl, d.out_f[g], d.in_f[g], gacc, acc, zero, st, c, nullptr, zero);
+        if (mc.kind == 1) ml_gemm(wl, mc.out_f, mc.in_f, h, acc, zero, st, c, nullptr, zero);
+        else ml_gemm(wl, mc.out_f, mc.in_f, gacc, acc, zero, st, c, nullptr, zero);
         __syncthreads();
-        if (d.kind[g] == 0) {
+        if (mc.kind == 0) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) gacc[m] = acc[m];
-        } else if (d.kind[g] == 2) {
+        } else if (mc.kind == 2) {
             // q = W2^T g, x act'(z)   (features beyond the width: acc = 0 there, so q = 0 x act'(0) = 0)
             auto dact = [&](auto SILU_) {
 #pragma unroll
@@ -515,6 +529,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const sda_mlp_desc d, cons
             if (cw == 128) lnb(std::true_type{});
             else lnb(std::false_type{});
         }
+        mc = mn; mn = mm;
     }
     if constexpr (WIN) {
         // the window part of the input gradient, 16 floats per row (the embedding's part is not formed); sda_mc_finish sums the overlaps
