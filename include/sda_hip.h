@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 8
+#define SDA_ABI_VERSION 9
 
 enum {
     SDA_OK = 0,
@@ -488,6 +488,35 @@ int sda_assignment_cost(const float* cost, int n, double* total, int* col_of_row
  *       unequal sample counts): *total = min_P <P, cost>, an integral min-cost flow after scaling by m n.  cost: m x n row-major,
  *       finite and >= 0. */
 int sda_transport_cost(const float* cost, int m, int n, double* total);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D convolutions: `UNet(spatial=3)` (sda/nn.py:114-118 picks nn.Conv3d; heads / residual blocks / tails as nn.py:148-206).
+ * One gather kernel (implicit GEMM on v_mfma_f32_16x16x4_f32, B operand read from the planar tensor) for every launch of the
+ * forward pass and of the input VJP.  Per axis a (d, h, w order):  v = o * stride[a] + tap - pad[a];  circular: v mod V,
+ * zeros: taps outside [0, V) contribute nothing;  up[a] > 1: source = v / up[a]  (nn.Upsample(nearest) in the loader,
+ * nn.py:164);  dil[a] > 1: source = v / dil[a] iff dil[a] divides v  (zero insertion: the transposed stride-2 convolution,
+ * backward of nn.py:152-159).  V = in * up (or, zero-inserted: in * dil circular / (in - 1) * dil + 1 zeros).
+ * Epilogue: + bias[cout]; then x act'(z) if z else act(.); then + res.   x: [n][cin][in_size d,h,w], out / z / res:
+ * [n][cout][out_size d,h,w], all contiguous.  w: sda_pack_conv3d_weight's layout (transpose = 1: the VJP operator --
+ * taps flipped, cin <-> cout; `cin` / `cout` of the descriptor are then the operator's own).
+ *   sda_pool3d_sum: adjoint of nearest up-sampling -- out[nc][d][h][w] = sum over the fd x fh x fw cell of g.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sda_conv3d_desc {
+    const float* x;
+    const float* w;
+    const float* bias;      /* NULL: none */
+    const float* z;         /* NULL: apply act; else multiply by act'(z) */
+    const float* res;       /* NULL: none */
+    float* out;
+    int32_t n, cin, cout;
+    int32_t in_size[3], out_size[3];
+    int32_t k[3], pad[3], stride[3], up[3], dil[3];
+    int32_t circular, act;
+} sda_conv3d_desc;
+int sda_conv3d(const sda_conv3d_desc* d, void* stream);
+int64_t sda_conv3d_packed_floats(int cout, int cin, int kd, int kh, int kw, int transpose);
+int sda_pack_conv3d_weight(const float* w, int cout, int cin, int kd, int kh, int kw, int transpose, float* dst, void* stream);
+int sda_pool3d_sum(const float* g, int64_t nc, int d, int h, int w, int fd, int fh, int fw, float* out, void* stream);
 
 #ifdef __cplusplus
 }

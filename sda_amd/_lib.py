@@ -57,6 +57,17 @@ class ConvDesc(Structure):
     ]
 
 
+class Conv3dDesc(Structure):
+    """Mirror of `struct sda_conv3d_desc` (include/sda_hip.h)."""
+    _fields_ = [
+        ('x', c_fp), ('w', c_fp), ('bias', c_fp), ('z', c_fp), ('res', c_fp), ('out', c_fp),
+        ('n', c_int32), ('cin', c_int32), ('cout', c_int32),
+        ('in_size', c_int32 * 3), ('out_size', c_int32 * 3),
+        ('k', c_int32 * 3), ('pad', c_int32 * 3), ('stride', c_int32 * 3), ('up', c_int32 * 3), ('dil', c_int32 * 3),
+        ('circular', c_int32), ('act', c_int32),
+    ]
+
+
 # name -> (restype, argtypes); exactly the symbols include/sda_hip.h declares
 class Block1dDesc(Structure):
     """Mirror of `struct sda_block1d_desc` (include/sda_hip.h)."""
@@ -220,6 +231,10 @@ SIGNATURES = {
     'sda_mmd_kernel_sums': (c_int, [c_fp, c_int64, c_void_p, c_int, c_void_p]),
     'sda_assignment_cost': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'sda_transport_cost': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'sda_conv3d': (c_int, [POINTER(Conv3dDesc), c_void_p]),
+    'sda_conv3d_packed_floats': (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    'sda_pack_conv3d_weight': (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
+    'sda_pool3d_sum': (c_int, [c_fp, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_void_p]),
 }
 
 _lib = None

@@ -11,7 +11,10 @@ experiments/lorenz/eval.py:42); this module is what a data-parallel launch of ``
     conv_small1d / staged-kernel choice depend on the LOCAL batch, and each variant sums in its own order.  The tests' shapes
     stay on one side of every threshold; in general expect agreement to ~1e-6 relative, not equality.)
   * the final gather.
-``DPSGaussianScore`` couples the batch through one scalar (score.py:339-342) and is therefore replicas-only.
+``DPSGaussianScore`` couples the batch through one scalar (``err`` summed over every sample, score.py:339-342): the one real
+exchange step on the path.  ``sample_sharded`` gives such a score its shard and process group, and each evaluation all-reduces
+that scalar (4 bytes per rank; RCCL on the GPU) -- a sharded DPS run then equals the single-process run like every other score.
+Every rank must hold at least one trajectory then (``batch >= world_size``), so that all ranks enter every all-reduce.
 """
 from typing import Optional, Tuple
 
@@ -108,17 +111,37 @@ def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64,
     any rank's shard, which is how the one-GPU test checks that the shards of a 2-rank job concatenate to the 1-rank job
     (bit for bit at the tests' sizes; up to fp32 round-off when shard and whole batch select different kernel variants, see
     the module docstring)."""
-    if rank is None or world_size is None:
-        rank, world_size = world()
-    else:
+    emulated = not (rank is None or world_size is None)
+    if emulated:
         gather = False
+    else:
+        rank, world_size = world()
     lo, hi = shard_range(batch, rank, world_size)
     event = tuple(sde.shape)
+    coupled = _batch_coupled(sde)
+    if coupled and emulated and world_size > 1:
+        raise ValueError('DPSGaussianScore sums its error over the whole batch (score.py:339): an emulated rank has no peers '
+                         'to all-reduce with; run it under a process group')
+    if coupled and batch < world_size:
+        raise ValueError(f'a batch-coupled score needs every rank in every all-reduce: batch {batch} < world size {world_size}')
     sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, world_size)
     if corrections > 0:
         sde.noise_source = KeyedNoise((lo, hi), event, seed + 1, corrections, sde.device.device)
+    use_graph = sde.use_graph
+    for m in coupled:
+        m.shard = (lo, hi, batch, dist.group.WORLD if world_size > 1 else None)
+    if coupled and world_size > 1:
+        sde.use_graph = False            # (a collective per evaluation: the step is launched eagerly, not replayed)
     try:
         local = sde.sample((hi - lo,), c=c, steps=steps, corrections=corrections, tau=tau)
     finally:
-        sde.initial_noise, sde.noise_source = None, None
+        sde.initial_noise, sde.noise_source, sde.use_graph = None, None, use_graph
+        for m in coupled:
+            m.shard = None
     return all_gather_samples(local, batch) if gather else local
+
+
+def _batch_coupled(sde) -> list:
+    """The score modules under ``sde`` whose evaluation couples the samples of a batch (``DPSGaussianScore``)."""
+    from .score import DPSGaussianScore
+    return [m for m in sde.modules() if isinstance(m, DPSGaussianScore)]

@@ -520,12 +520,30 @@ class DPSGaussianScore(nn.Module):
     r"""Diffusion posterior sampling guidance for p(y|x) = N(y | A(x), Sigma)  (score.py:305-344).
     Returns :math:`-\sigma(t) s(x(t), t | y)`.  Note ``err`` is summed over the whole batch, as in the reference."""
 
+    #: set by ``parallel.sample_sharded`` for the duration of a sharded run: ``(lo, hi, batch, process_group)`` -- the rows
+    #: of the global batch this rank holds.  ``err`` (score.py:339) is a sum over the WHOLE batch, the one real exchange
+    #: step on the path: one scalar all-reduce per evaluation keeps a sharded run equal to the single-process one.
+    shard: Optional[tuple] = None
+
     def __init__(self, y: Tensor, A: Callable[[Tensor], Tensor], sde: VPSDE, zeta: float = 1.0):
         super().__init__()
         self.register_buffer('y', y)
         self.A = A
         self.sde = sde
         self.zeta = zeta
+
+    def _observed(self, ax: Tensor) -> Tensor:
+        """A per-sample observation (leading axis = the global batch) follows this rank's rows; a shared one broadcasts."""
+        sh = self.shard
+        if sh is not None and self.y.dim() == ax.dim() and self.y.shape[0] == sh[2] and ax.shape[0] == sh[1] - sh[0]:
+            return self.y[sh[0]:sh[1]]
+        return self.y
+
+    def _batch_total(self, err: Tensor) -> Tensor:
+        if self.shard is not None and self.shard[3] is not None:
+            import torch.distributed as dist
+            dist.all_reduce(err, op=dist.ReduceOp.SUM, group=self.shard[3])
+        return err
 
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
         # (the reference's signature is (x, t); ``c`` is accepted and ignored so that VPSDE.sample, which always
@@ -539,8 +557,8 @@ class DPSGaussianScore(nn.Module):
         if lin is not None:
             # d/dx_hat sum (y - A x_hat)^2 = -2 J_A^T (y - A x_hat): no autograd through an operator with a hand-written VJP
             ax, a_vjp = lin(xhat)
-            res = self.y - ax
-            err = res.square().sum()
+            res = self._observed(ax) - ax
+            err = self._batch_total(res.square().sum())
             cot = res * -2.0
             if cot.shape != ax.shape:
                 cot = cot.sum_to_size(ax.shape)
@@ -548,8 +566,10 @@ class DPSGaussianScore(nn.Module):
         else:
             with torch.enable_grad():
                 xhat.requires_grad_(True)
-                err = (self.y - self.A(xhat)).square().sum()
+                ax = self.A(xhat)
+                err = (self._observed(ax) - ax).square().sum()
             ghat, = torch.autograd.grad(err, xhat)
+            err = self._batch_total(err.detach().clone())
         ghat = (ghat * (-self.zeta / err.detach().sqrt())).contiguous()      # d/dxhat of the DPS potential
         out = torch.empty_like(eps_d)
         ops.guided_combine(eps_d, ghat, vjp(ghat).contiguous(), mu, sigma, out)

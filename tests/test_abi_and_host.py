@@ -29,11 +29,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in sda_hip.h but not exported'
     assert set(declared) == set(_lib.SIGNATURES), (set(declared) ^ set(_lib.SIGNATURES))
-    assert lib.sda_abi_version() == 8
+    assert lib.sda_abi_version() == 9
 
 
 @pytest.mark.parametrize('mirror,ctype', [('ConvDesc', 'sda_conv_desc'), ('Block1dDesc', 'sda_block1d_desc'),
-                                          ('Net1dDesc', 'sda_net1d_desc'), ('Net1dFuse', 'sda_net1d_fuse'), ('MlpDesc', 'sda_mlp_desc'), ('MlpWin', 'sda_mlp_win')])
+                                          ('Net1dDesc', 'sda_net1d_desc'), ('Net1dFuse', 'sda_net1d_fuse'), ('MlpDesc', 'sda_mlp_desc'), ('MlpWin', 'sda_mlp_win'), ('Conv3dDesc', 'sda_conv3d_desc')])
 def test_desc_layouts_match_c(tmp_path, mirror, ctype):
     """sizeof/offsetof of the ctypes mirrors == what gcc sees in the header."""
     from sda_amd import _lib

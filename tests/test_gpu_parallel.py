@@ -119,3 +119,61 @@ def test_midsize_sharded_rows_are_independent_of_their_group(dev):
     whole = P.sample_sharded(sde, 3, rank=0, world_size=1, **kw)
     shards = [P.sample_sharded(sde, 3, rank=r, world_size=2, **kw) for r in range(2)]
     assert torch.equal(torch.cat(shards), whole)
+
+
+def _dps_sde(dev, event=(5, 2, 8, 8), fused_adjoint=True):
+    from sda_amd import observe as Ob
+    from sda_amd.score import DPSGaussianScore, VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    torch.manual_seed(0)
+    sub = Ob.Subsample((slice(None, None, 2), slice(None), slice(None, None, 2), slice(None, None, 2)))
+    A = sub if fused_adjoint else (lambda x: x[..., ::2, :, ::2, ::2])     # hand-written adjoint / autograd through A
+    y = torch.randn(sub(torch.empty((1,) + event, device=dev)).shape)
+    return VPSDE(DPSGaussianScore(y, A=A, sde=VPSDE(net, shape=()), zeta=0.7), shape=event).to(dev)
+
+
+def _dps_rank(rank, ws, port, ret):
+    import os
+    import torch.distributed as dist
+    from sda_amd import parallel as P
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=ws)      # (both ranks on cuda:0; RCCL wants one GPU per rank)
+    try:
+        dev = torch.device('cuda:0')
+        kw = dict(steps=4, corrections=1, tau=0.5, seed=6)
+        worst = 0.0
+        for fused in (True, False):
+            sde = _dps_sde(dev, fused_adjoint=fused)
+            got = P.sample_sharded(sde, 5, **kw)                   # one scalar all-reduce per score evaluation + the gather
+            alone = P.sample_sharded(sde, 5, rank=0, world_size=1, **kw)
+            assert got.shape == alone.shape == (5, 5, 2, 8, 8) and torch.isfinite(alone).all()
+            worst = max(worst, ((got - alone).abs().max() / alone.abs().max()).item())
+            lo, hi = P.shard_range(5, rank, ws)
+            sde.initial_noise = P.sharded_initial_noise(5, (5, 2, 8, 8), 6, rank, ws)
+            sde.noise_source = P.KeyedNoise((lo, hi), (5, 2, 8, 8), 7, 1, dev)
+            replica = sde.sample((hi - lo,), steps=4, corrections=1, tau=0.5)      # uncoupled: its own shard's error norm
+            sde.initial_noise = sde.noise_source = None
+            assert ((replica - alone[lo:hi]).abs().max() / alone.abs().max()).item() > 1e-3
+        ret[rank] = worst
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dps_sharded_over_two_ranks_equals_single_process(dev):
+    """DPSGaussianScore's error norm is a sum over the WHOLE batch (sda/score.py:339-342): the one exchange step on the path.
+    Two ranks (gloo, both on this GPU) all-reduce that scalar in every evaluation and reproduce the single-process run;
+    two uncoupled replicas do not."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() * 7 + 3) % 2000
+    procs = [ctx.Process(target=_dps_rank, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert ret[0] <= 2e-5 and ret[1] <= 2e-5, dict(ret)

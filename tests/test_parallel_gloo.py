@@ -40,6 +40,20 @@ def _tiny_guided_sde():
     return VPSDE(gs, shape=(5, 2, 8, 8))
 
 
+def _tiny_dps_sde(per_sample_y: bool, batch: int):
+    """DPSGaussianScore: its error norm is summed over the WHOLE batch (score.py:339) -- the one collective on the path."""
+    from sda_amd.score import DPSGaussianScore, VPSDE
+    from tests.util import build_mcscore2d_tiny, load_golden
+    g, grp = load_golden('mcscore2d_tiny')
+    net = build_mcscore2d_tiny()
+    net.load_state_dict(grp['sd'])
+    A = lambda x: x[..., ::2, :, ::2, ::2]
+    y = g['y_obs'][:1]
+    if per_sample_y:                                   # one observation per trajectory: follows the rows of a shard
+        y = torch.cat([y * (1 + 0.25 * i) for i in range(batch)])
+    return VPSDE(DPSGaussianScore(y, A=A, sde=VPSDE(net, shape=()), zeta=0.7), shape=(5, 2, 8, 8))
+
+
 def _worker(rank, ws, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(2)
@@ -68,6 +82,27 @@ def _worker(rank, ws, port, ret):
         assert torch.equal(got, alone), (got - alone).abs().max()
         mine = P.sample_sharded(sde, 3, steps=2, corrections=1, tau=0.5, seed=4, gather=False)
         assert torch.equal(mine, alone[P.shard_range(3, rank, ws)[0]:P.shard_range(3, rank, ws)[1]])
+        # DPS guidance couples the batch through one scalar: sharded = one all-reduce per evaluation, and the result still
+        # equals the single-process run (up to the summation order of that scalar)
+        for per_sample in (False, True):
+            dps = _tiny_dps_sde(per_sample, 3)
+            got = P.sample_sharded(dps, 3, steps=2, corrections=1, tau=0.5, seed=4)
+            alone = P.sample_sharded(dps, 3, steps=2, corrections=1, tau=0.5, seed=4, rank=0, world_size=1)
+            assert got.shape == alone.shape == (3, 5, 2, 8, 8)
+            assert all(m.shard is None for m in P._batch_coupled(dps))
+            close = lambda a, b: (a - b).abs().max() <= 2e-5 * b.abs().max()        # (max-norm: 2 steps from t = 1 are large)
+            assert close(got, alone), ((got - alone).abs().max(), alone.abs().max())
+            # ... and NOT the result of two uncoupled replicas (each normalising by its own shard's error)
+            if per_sample:
+                continue
+            lo, hi = P.shard_range(3, rank, ws)
+            dps.initial_noise = P.sharded_initial_noise(3, (5, 2, 8, 8), 4, rank, ws)
+            dps.noise_source = P.KeyedNoise((lo, hi), (5, 2, 8, 8), 5, 1, 'cpu')
+            replica = dps.sample((hi - lo,), steps=2, corrections=1, tau=0.5)
+            dps.initial_noise = dps.noise_source = None
+            assert not close(replica, alone[lo:hi])
+        with pytest.raises(ValueError, match='emulated rank'):
+            P.sample_sharded(_tiny_dps_sde(False, 3), 3, steps=1, rank=0, world_size=2)
         ret[rank] = True
     finally:
         mpatch.undo()
