@@ -496,6 +496,7 @@ int sda_transport_cost(const float* cost, int m, int n, double* total);
  * zeros: taps outside [0, V) contribute nothing;  up[a] > 1: source = v / up[a]  (nn.Upsample(nearest) in the loader,
  * nn.py:164);  dil[a] > 1: source = v / dil[a] iff dil[a] divides v  (zero insertion: the transposed stride-2 convolution,
  * backward of nn.py:152-159).  V = in * up (or, zero-inserted: in * dil circular / (in - 1) * dil + 1 zeros).
+ * Loader: act_in(x) on the gathered values (padding stays zero).
  * Epilogue: + bias[cout]; then x act'(z) if z else act(.); then + res.   x: [n][cin][in_size d,h,w], out / z / res:
  * [n][cout][out_size d,h,w], all contiguous.  w: sda_pack_conv3d_weight's layout (transpose = 1: the VJP operator --
  * taps flipped, cin <-> cout; `cin` / `cout` of the descriptor are then the operator's own).
@@ -512,6 +513,7 @@ typedef struct sda_conv3d_desc {
     int32_t in_size[3], out_size[3];
     int32_t k[3], pad[3], stride[3], up[3], dil[3];
     int32_t circular, act;
+    int32_t act_in;         /* activation applied to x by the loader (the conv behind the block's activation, nn.py:139) */
 } sda_conv3d_desc;
 int sda_conv3d(const sda_conv3d_desc* d, void* stream);
 int64_t sda_conv3d_packed_floats(int cout, int cin, int kd, int kh, int kw, int transpose);

@@ -115,7 +115,7 @@ def _conv(x: Tensor, w: Tensor, b: Tensor, spatial: int, stride: int, padding_mo
     """nn.ConvNd with padding=k//2 and the given padding mode (nn.py:126-129)."""
     ks = w.shape[2:]
     pads = [k // 2 for k in ks]
-    conv = {1: F.conv1d, 2: F.conv2d}[spatial]
+    conv = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[spatial]            # (nn.py:114-118)
     if padding_mode == 'zeros':
         return conv(x, w, b, stride=stride, padding=pads)
     if padding_mode != 'circular':
@@ -168,9 +168,9 @@ def unet_forward(sd: StateDict, prefix: str, cfg: UNetConfig, x: Tensor, y: Tens
         if lvl > 0:
             tp = f'{prefix}tails.{j}.2.'
             h = layer_norm(x, dim=-(cfg.spatial + 1))
-            h = h.repeat_interleave(cfg.stride, dim=-1)
-            if cfg.spatial == 2:
-                h = h.repeat_interleave(cfg.stride, dim=-2)
+            strides = (cfg.stride,) * cfg.spatial if isinstance(cfg.stride, int) else tuple(cfg.stride)
+            for ax, st in enumerate(strides):               # nn.Upsample(scale_factor=strides, mode='nearest'), nn.py:164
+                h = h.repeat_interleave(st, dim=ax - cfg.spatial)
             h = _conv(h, sd[tp + 'weight'], sd[tp + 'bias'], cfg.spatial, 1, cfg.padding_mode)
             x = h + skips.pop()
         else:

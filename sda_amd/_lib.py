@@ -64,7 +64,7 @@ class Conv3dDesc(Structure):
         ('n', c_int32), ('cin', c_int32), ('cout', c_int32),
         ('in_size', c_int32 * 3), ('out_size', c_int32 * 3),
         ('k', c_int32 * 3), ('pad', c_int32 * 3), ('stride', c_int32 * 3), ('up', c_int32 * 3), ('dil', c_int32 * 3),
-        ('circular', c_int32), ('act', c_int32),
+        ('circular', c_int32), ('act', c_int32), ('act_in', c_int32),
     ]
 
 

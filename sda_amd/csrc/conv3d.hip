@@ -8,7 +8,7 @@
 //     up  > 1 : source = v / up                 (nearest-neighbour up-sampling in the loader: the tails, nn.py:161-169)
 //     dil > 1 : source = v / dil  iff dil | v   (zero insertion: the transposed stride-`dil` convolution of a head's VJP)
 // The transposed convolutions take the flipped, (cin <-> cout)-swapped weights (packed by sda_pack_conv3d_weight).
-// Epilogue: + bias, then either act(.) or x act'(z), then + res.  LayerNorm is applied by sda_ln_apply before the launch and
+// Loader: optional activation of the gathered values.  Epilogue: + bias, then either act(.) or x act'(z), then + res.  LayerNorm is applied by sda_ln_apply before the launch and
 // differentiated by sda_ln_bwd after it (both treat the three spatial axes as one plane).
 //
 // Tile: a wavefront owns 16 consecutive output positions x 64 output channels (four 16x16 accumulators);
@@ -33,7 +33,7 @@ __device__ __forceinline__ int c3_src(const AxisMap& a, int o, int tap, int circ
 struct Conv3dArgs {
     const float* x; const float* w; const float* bias; const float* z; const float* res; float* out;
     AxisMap ad, ah, aw;
-    int n, cin, cout, ciq, mblocks, circular, act;
+    int n, cin, cout, ciq, mblocks, circular, act, act_in;
 };
 
 __global__ __launch_bounds__(256) void conv3d_kernel(Conv3dArgs g) {
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void conv3d_kernel(Conv3dArgs g) {
                 const float* wt = g.w + ((int64_t)tap * g.ciq * g.mblocks + mb0) * 64 + lane;
                 for (int q = 0; q < g.ciq; ++q) {
                     const int ci = q * 4 + kg;
-                    const float b = (ok && ci < g.cin) ? xs[(int64_t)ci * plane] : 0.f;
+                    float b = 0.f;
+                    if (ok && ci < g.cin) { b = xs[(int64_t)ci * plane]; if (g.act_in) b = sda_act(g.act_in, b); }
                     const float* wq = wt + (int64_t)q * g.mblocks * 64;
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -110,7 +111,7 @@ extern "C" int sda_conv3d(const sda_conv3d_desc* d, void* stream_) {
     if ((rc = c3_axis(&g.ah, d->in_size[1], d->out_size[1], d->k[1], d->pad[1], d->stride[1], d->up[1], d->dil[1], d->circular))) return rc;
     if ((rc = c3_axis(&g.aw, d->in_size[2], d->out_size[2], d->k[2], d->pad[2], d->stride[2], d->up[2], d->dil[2], d->circular))) return rc;
     g.n = d->n; g.cin = d->cin; g.cout = d->cout; g.ciq = (d->cin + 3) / 4; g.mblocks = (d->cout + 15) / 16;
-    g.circular = d->circular ? 1 : 0; g.act = d->act;
+    g.circular = d->circular ? 1 : 0; g.act = d->act; g.act_in = d->act_in;
     const int64_t P = (int64_t)g.ad.out * g.ah.out * g.aw.out;
     const int64_t gx = (P + 63) / 64;
     if (gx > 0x7fffffff || d->n > 65535 || (g.mblocks + 3) / 4 > 65535) return SDA_E_UNSUPPORTED;

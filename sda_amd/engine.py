@@ -231,7 +231,7 @@ class UNetEngine:
     def __init__(self, unet):
         from .nn import LN_UNBIASED
         if unet.spatial not in (1, 2):
-            raise NotImplementedError('spatial=3 U-Nets have no gfx950 kernels (no reference experiment uses them)')
+            raise NotImplementedError('this engine serves spatial = 1, 2 (spatial = 3: engine3d.UNet3dEngine)')
         self.unet = unet
         self.unbiased = LN_UNBIASED
         self.depth = len(unet.hidden_blocks)
@@ -785,6 +785,10 @@ def attach_context(src: Source, c: Optional[Tensor], spatial: int):
 def unet_apply(unet, x: Tensor, y: Tensor) -> Tensor:
     """``UNet.forward(x, y)`` (nn.py:184-206): x (N, C, *spatial), y (N|1, mod_features)."""
     ops._dev(x, y)
+    if unet.spatial == 3:
+        from .engine3d import run_unet3d
+        out = run_unet3d(unet, x.reshape((-1,) + tuple(x.shape[-4:])), y.reshape(-1, y.shape[-1]))
+        return out.reshape(tuple(x.shape[:-4]) + tuple(out.shape[1:]))
     xv, src = source_from_tensor(x, unet.spatial)
     out = run_unet(unet, src, y.reshape(-1, y.shape[-1]), x)
     return out if unet.spatial == 2 else out[:, :, 0]

@@ -132,7 +132,8 @@ class UNet(nn.Module):
 
     Arguments are the reference's: ``in_channels, out_channels, mod_features, hidden_channels,
     hidden_blocks, kernel_size, stride, activation, spatial`` and ``**kwargs`` forwarded to the
-    convolutions (``padding_mode='circular'`` for Kolmogorov).  ``spatial`` 1 and 2 run on MI355X.
+    convolutions (``padding_mode='circular'`` for Kolmogorov).  ``spatial`` 1 and 2 run on the tuned kernels, ``spatial=3``
+    on the general 3-D kernel (``engine3d``).
 
     Parameter layout (matches the reference's state_dict): ``heads.0`` / ``tails.{D-1}`` are plain
     convolutions, deeper heads are ``Sequential(conv)``, deeper tails ``Sequential(LayerNorm,
@@ -197,8 +198,11 @@ class UNet(nn.Module):
 
     # -- engine plumbing ---------------------------------------------------------------------
     def engine(self):
-        from .engine import UNetEngine
         if self._engine is None:
+            if self.spatial == 3:
+                from .engine3d import UNet3dEngine as UNetEngine
+            else:
+                from .engine import UNetEngine
             object.__setattr__(self, '_engine', UNetEngine(self))
         return self._engine
 

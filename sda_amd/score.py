@@ -82,17 +82,30 @@ class ScoreUNet(nn.Module):
         c = self._context(c)
         ops._dev(x, t, c)
         spatial = self.network.spatial
+        if spatial == 3:
+            return self._forward3d(x, t, c)
         xv, src = source_from_tensor(x, spatial)
         attach_context(src, c, spatial)
         emb = self.embedding(t.reshape(-1))
         out = run_unet(self.network, src, emb, x)
         return out.reshape(x.shape)
 
+    def _forward3d(self, x: Tensor, t: Tensor, c: Optional[Tensor]) -> Tensor:
+        """``spatial=3`` (score.py:81-93 as written: context channels concatenated, batch axes flattened): the general 3-D
+        engine takes one planar tensor, so the concat is materialised here."""
+        from .engine3d import run_unet3d
+        feats = x
+        if c is not None:
+            batch = torch.broadcast_shapes(x.shape[:-4], c.shape[:-4])
+            feats = torch.cat((x.expand(batch + x.shape[-4:]), c.expand(batch + c.shape[-4:])), dim=-4)
+        out = run_unet3d(self.network, feats.reshape((-1,) + tuple(feats.shape[-4:])), self.embedding(t.reshape(-1)))
+        return out.reshape(x.shape)
+
     def grad_bytes_per_sample(self, x_shape) -> Optional[int]:
         """HBM the input-VJP keeps alive per row of a batch ``x_shape`` = (B, C, *spatial); None when ``x_shape`` has no
         single leading batch axis (see GaussianScore._groups)."""
         spatial = self.network.spatial
-        if len(x_shape) != spatial + 2:
+        if len(x_shape) != spatial + 2 or spatial == 3:
             return None
         sp = tuple(x_shape)[-spatial:]
         h, w = (1, sp[0]) if spatial == 1 else sp
