@@ -798,6 +798,9 @@ def block_forward_standalone(block, x: Tensor, y: Tensor) -> Tensor:
     """``ModResidualBlock.forward`` outside a U-Net (nn.py:27-28): same three kernels as inside the engine."""
     ops._dev(x, y)
     spatial = x.dim() - 2
+    if spatial == 3:
+        from .engine3d import block_forward_standalone3d
+        return block_forward_standalone3d(block, x, y)
     if spatial not in (1, 2):
         raise NotImplementedError
     xs = x.contiguous()

@@ -289,3 +289,18 @@ def run_unet3d(unet, x: Tensor, emb: Tensor) -> Tensor:
         raise SdaHipError(f'time embedding batch {T} does not broadcast against {x.shape[0]} images')
     mod_all = engine.modulation(emb)
     return _UNet3dFunction.apply(x, engine, mod_all, T != 1)
+
+
+def block_forward_standalone3d(block, x: Tensor, y: Tensor) -> Tensor:
+    """``ModResidualBlock.forward`` on a 5-D tensor outside a U-Net (nn.py:27-28): the block's three launches."""
+    from .nn import LN_UNBIASED
+    xs = x.contiguous()
+    n, c = xs.shape[:2]
+    eng = UNet3dEngine.__new__(UNet3dEngine)
+    eng.unbiased, eng.mod_total = LN_UNBIASED, c
+    blk = _Block3d(block, c, 0)
+    lin = blk.project
+    mod = ops.linear_small(y.reshape(-1, y.shape[-1]).contiguous(), lin.weight.detach().contiguous(), lin.bias.detach().contiguous())
+    if mod.shape[0] not in (1, n):
+        raise SdaHipError('modulation batch does not broadcast')
+    return eng._block_fwd(blk, xs, mod, mod.shape[0] != 1, None)

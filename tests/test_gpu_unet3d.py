@@ -147,3 +147,17 @@ def test_unet3d_mid_size_against_oracle_and_guided_sampling(dev):
     torch.manual_seed(0)
     s = sde.sample((2,), steps=3, corrections=1, tau=0.5)
     assert s.shape == (2, 3, 8, 12, 8) and torch.isfinite(s).all()
+
+
+def test_mod_residual_block_3d_standalone(dev):
+    """``ModResidualBlock`` called on its own (nn.py:18-28) with a per-sample modulation input."""
+    net, g = _net('b', dev)
+    blk = net.network.descent[1][0]
+    torch.manual_seed(3)
+    x = torch.randn(3, 20, 3, 3, 2, device=dev)
+    y = torch.randn(3, 8, device=dev)
+    got = blk(x, y)
+    sd = {k: v.double().cpu() for k, v in blk.state_dict().items()}
+    cfg = O.UNetConfig(20, 20, 8, (20,), (1,), (1, 3, 3), 1, 'ELU', 3, 'zeros')
+    want = O._mod_block(sd, '', cfg, x.double().cpu(), y.double().cpu())
+    assert_close(got, want, 1e-5)
