@@ -147,6 +147,11 @@ def test_unet3d_mid_size_against_oracle_and_guided_sampling(dev):
     torch.manual_seed(0)
     s = sde.sample((2,), steps=3, corrections=1, tau=0.5)
     assert s.shape == (2, 3, 8, 12, 8) and torch.isfinite(s).all()
+    # the same loop with each step replayed from a hipGraph (PCSampler.capture)
+    sde.use_graph = True
+    torch.manual_seed(0)
+    sg = sde.sample((2,), steps=3, corrections=1, tau=0.5)
+    assert_close(sg, s, 1e-5, what='graph-replayed steps')
 
 
 def test_mod_residual_block_3d_standalone(dev):
