@@ -18,6 +18,9 @@
 #include "sda_common.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C3_U
+#define C3_U 2
+#endif
 
 struct AxisMap { int in, out, k, pad, stride, up, dil, vext; };
 
@@ -59,16 +62,36 @@ __global__ __launch_bounds__(256) void conv3d_kernel(Conv3dArgs g) {
             for (int kw = 0; kw < g.aw.k; ++kw, ++tap) {
                 const int sw = c3_src(g.aw, ow, kw, g.circular);
                 const bool ok = live && sd >= 0 && sh >= 0 && sw >= 0;
+                // a tap no position of the wavefront sees (zero-inserted source: 7 of 8 taps of a stride-2 layer's VJP;
+                // padding at a volume face) multiplies zeros only: skip its whole channel loop
+                if (!__builtin_amdgcn_ballot_w64(ok)) continue;
                 const float* xs = xi + ((int64_t)sd * g.ah.in + sh) * g.aw.in + sw;
                 const float* wt = g.w + ((int64_t)tap * g.ciq * g.mblocks + mb0) * 64 + lane;
-                for (int q = 0; q < g.ciq; ++q) {
-                    const int ci = q * 4 + kg;
-                    float b = 0.f;
-                    if (ok && ci < g.cin) { b = xs[(int64_t)ci * plane]; if (g.act_in) b = sda_act(g.act_in, b); }
-                    const float* wq = wt + (int64_t)q * g.mblocks * 64;
+                // C3_U input-channel quads per iteration, all their loads issued before the MFMAs (the loop is latency-bound: one
+                // wavefront per SIMD or two, every operand a fresh global / L2 round trip)
+                for (int q = 0; q < g.ciq; q += C3_U) {
+                    float b[C3_U], a[C3_U][4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        if (m < nmb) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[m * 64], b, acc[m], 0, 0, 0);
+                    for (int u = 0; u < C3_U; ++u) {
+                        const bool have = q + u < g.ciq;
+                        const int ci = (q + u) * 4 + kg;
+                        b[u] = (ok && have && ci < g.cin) ? xs[(int64_t)ci * plane] : 0.f;
+                        const float* wq = wt + (int64_t)(have ? q + u : q) * g.mblocks * 64;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) a[u][m] = m < nmb ? wq[m * 64] : 0.f;
+                    }
+                    if (g.act_in) {
+#pragma unroll
+                        for (int u = 0; u < C3_U; ++u) b[u] = sda_act(g.act_in, b[u]);       // (act(0) = 0 for every activation)
+                    }
+#pragma unroll
+                    for (int u = 0; u < C3_U; ++u) {
+                        if (q + u < g.ciq) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                if (m < nmb) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], b[u], acc[m], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
