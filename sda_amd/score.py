@@ -334,7 +334,18 @@ class VPSDE(nn.Module):
         return sampler.result()
 
     def loss(self, x: Tensor, c: Tensor = None, w: Tensor = None) -> Tensor:
-        raise NotImplementedError('training (the denoising loss, score.py:265-276) is outside the sampling hot path')
+        r"""The denoising loss (score.py:265-276), as a VALUE: what the reference's validation pass computes under ``no_grad``
+        (sda/utils.py ``loop``).  The networks here form input gradients only, so a call that would need parameter gradients
+        (grad mode on, trainable parameters) raises instead of returning a loss whose ``backward()`` trains nothing."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.eps.parameters()):
+            raise NotImplementedError('training is outside the sampling hot path: parameter gradients are never formed. '
+                                      'Evaluate the loss under torch.no_grad() (validation), or freeze the parameters')
+        t = torch.rand(x.shape[0], dtype=x.dtype, device=x.device)
+        x, eps = self.forward(x, t, train=True)
+        err = (self.eps(x, t, c) - eps).square()
+        if w is None:
+            return err.mean()
+        return (err * w).mean() / w.mean()
 
 
 class PCSampler:

@@ -785,3 +785,36 @@ def test_whole_mlp_kernel_equals_layer_path_and_oracle(dev, rows, widths, act, m
     # no-grad call (no saves) gives the same output
     with torch.no_grad():
         assert torch.equal(net(x.to(dev)), out_f_)
+
+
+def test_denoising_loss_value_matches_reference_formula(dev):
+    """``VPSDE.loss`` (sda/score.py:265-276) as a value -- what the reference's validation pass computes under no_grad: the
+    training-style call of the score network (per-sample t) on a trajectory window, as experiments/kolmogorov/train.py does with
+    ``VPSDE(score.kernel, shape=...)``.  Checked against the oracle net in float64 on the same t / eps draws."""
+    from sda_amd.score import VPSDE
+    g, grp = load_golden('mcscore2d_tiny')
+    mc = build_mcscore2d_tiny()
+    mc.load_state_dict(grp['sd'])
+    kernel = mc.kernel.to(dev)
+    sde = VPSDE(kernel, shape=(6, 8, 8)).to(dev)
+    torch.manual_seed(7)
+    x = torch.randn(5, 6, 8, 8, device=dev)
+    w = torch.rand(5, 1, 8, 8, device=dev) + 0.5
+    with pytest.raises(NotImplementedError, match='parameter gradients'):
+        sde.loss(x)                                                       # grad mode + trainable parameters: refuse, do not mis-train
+    sd = {k[len('kernel.'):]: v.double() for k, v in grp['sd'].items()}
+    cfg = O.UNetConfig(7, 6, 8, (4, 8), (1, 1), 3, 2, 'SiLU', 2, 'circular')
+    sched = O.Schedule()
+    for weight in (None, w):
+        torch.manual_seed(11)
+        with torch.no_grad():
+            got = sde.loss(x, w=weight)
+        torch.manual_seed(11)                                             # the same draws, in the order loss() makes them
+        t = torch.rand(5, dtype=x.dtype, device=dev)
+        eps = torch.randn_like(x)
+        t64, e64, x64 = t.double().cpu(), eps.double().cpu(), x.double().cpu()
+        tb = t64.reshape(-1, 1, 1, 1)
+        xt = sched.mu(tb) * x64 + sched.sigma(tb) * e64
+        err = (O.score_unet(sd, '', cfg, xt, t64, sd['forcing']) - e64).square()
+        want = err.mean() if weight is None else (err * weight.double().cpu()).mean() / weight.double().cpu().mean()
+        assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()), (got.item(), want.item())

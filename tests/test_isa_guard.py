@@ -127,3 +127,24 @@ def test_product_library_has_no_ablation_switches(built):
     read it.  The tooling build (-DSDA_ABLATE) does."""
     blob = open(os.path.join(built, 'libsda_hip.so'), 'rb').read()
     assert b'SDA_CONV_DEBUG' not in blob
+
+
+def test_fallback_kernels_keep_scratch_out_of_their_multiply_loops(built):
+    """The first-generation Winograd kernel (the fallback for widths / tiles conv_wino4 does not take) carries ~19 spilled
+    registers (tile geometry kept across the stage loop).  That is tolerable only while every scratch access sits OUTSIDE the
+    multiply loop -- once per tile, not once per stage; the general 3-D kernel has none at all."""
+    dis = G.disassemble(os.path.join(built, 'conv_wino.o'))
+    seen = 0
+    for name, ins in dis.items():
+        if 'conv_wino_kernel' not in name:
+            continue
+        seen += 1
+        mf = [i for i, t in enumerate(ins) if 'v_mfma' in t]
+        sc = [i for i, t in enumerate(ins) if 'scratch_' in t]
+        assert mf and len(sc) <= 32, (name, len(sc))
+        assert all(i < mf[0] or i > mf[-1] for i in sc), (name, [i for i in sc if mf[0] <= i <= mf[-1]])
+    assert seen == 2
+    meta = G.kernel_metadata(os.path.join(built, 'conv3d.o'))
+    k3 = [v for k, v in meta.items() if 'conv3d_kernel' in k]
+    assert len(k3) == 1 and k3[0]['vgpr_spill_count'] == 0 and k3[0]['private_segment_fixed_size'] == 0, k3
+    assert not any('scratch_' in t for k, ins in G.disassemble(os.path.join(built, 'conv3d.o')).items() for t in ins)
