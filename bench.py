@@ -477,6 +477,8 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
+    # (the host driver of this pool only supports dmabuf IPC: without this RCCL's hipIpcGetMemHandle fails; normally exported already)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     plan = launch_plan(args.gpus, os.environ, sys.argv[1:])
     if plan is not None:
         # `python bench.py --gpus N` (the driver's verbatim call, no torchrun): this process becomes the launcher of N ranks
