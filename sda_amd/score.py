@@ -224,7 +224,7 @@ class MCScoreNet(nn.Module):
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
         kernel = self.kernel
         fused = isinstance(kernel, ScoreUNet) and type(kernel).forward is ScoreUNet.forward \
-            and x.dim() == kernel.network.spatial + 3
+            and x.dim() == kernel.network.spatial + 3 and kernel.network.spatial != 3    # (3-D kernels: the generic path)
         if fused:
             ops._dev(x, t)
             ctx_c = kernel._context(c)

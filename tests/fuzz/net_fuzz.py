@@ -41,8 +41,13 @@ def _min_preact(run):
     return min(seen) if seen else 1.0
 
 
+SPATIAL3 = False            # --spatial3: every case is a 3-D U-Net (the general kernel of csrc/conv3d.hip)
+
+
 def one_case(rng, dev, idx):
     spatial = rng.choice([1, 2, 2])
+    if SPATIAL3:
+        spatial = 3
     depth = rng.choice([1, 2, 2, 3])
     widths = {1: [4, 8, 24, 64, 96], 2: [4, 8, 16, 96], 3: [4, 8]}[depth]
     c0 = rng.choice(widths)
@@ -59,6 +64,9 @@ def one_case(rng, dev, idx):
     size = [mult * rng.choice([1, 2, 3, 4, 8]) for _ in range(spatial)]
     if spatial == 2 and c0 >= 64:
         size = [min(s, 16) for s in size]
+    if spatial == 3:
+        size = [min(s, 8 if c0 < 64 else 4) for s in size]
+        size = [max(s, mult) for s in size]
     emb = rng.choice([8, 16])
     cfg = dict(spatial=spatial, hidden=hidden, blocks=blocks, act=act, pad=pad, mc=mc, order=order, channels=channels,
                context=context, size=size)
@@ -123,7 +131,10 @@ def main():
     ap.add_argument('--cases', type=int, default=60)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--only', type=int, default=-1, help='report only this case index (the sequence is still drawn)')
+    ap.add_argument('--spatial3', action='store_true', help='3-D U-Nets only (small volumes)')
     args = ap.parse_args()
+    global SPATIAL3
+    SPATIAL3 = args.spatial3
     rng = random.Random(args.seed)
     dev = torch.device('cuda:0')
     bad = skipped = 0

@@ -166,3 +166,26 @@ def test_mod_residual_block_3d_standalone(dev):
     cfg = O.UNetConfig(20, 20, 8, (20,), (1,), (1, 3, 3), 1, 'ELU', 3, 'zeros')
     want = O._mod_block(sd, '', cfg, x.double().cpu(), y.double().cpu())
     assert_close(got, want, 1e-5)
+
+
+def test_mcscorenet_over_a_3d_kernel(dev):
+    """``MCScoreNet(..., spatial=3)`` (score.py:113-164 builds a ScoreUNet kernel for any ``spatial``): windows over a trajectory of
+    volumes, one time per window, forward and input VJP against the oracle's composition."""
+    from sda_amd.score import MCScoreNet
+    torch.manual_seed(21)
+    net = MCScoreNet(2, order=1, embedding=8, hidden_channels=(6, 12), hidden_blocks=(1, 1), kernel_size=3,
+                     activation=torch.nn.SiLU, spatial=3, padding_mode='circular').to(dev)
+    cfg = O.UNetConfig(6, 6, 8, (6, 12), (1, 1), 3, 2, 'SiLU', 3, 'circular')
+    sd = {k: v.double().cpu() for k, v in net.state_dict().items()}
+    x = torch.randn(2, 5, 2, 4, 4, 6, device=dev)
+    t = torch.rand(2, 3, device=dev)
+    kern = lambda a, b, _c=None: O.score_unet(sd, 'kernel.', cfg, a, b, None)
+    xr = x.double().cpu().requires_grad_(True)
+    ref = O.mc_score_net(kern, 1, xr, t.double().cpu())
+    cot = torch.randn_like(x)
+    gref, = torch.autograd.grad((ref * cot.double().cpu()).sum(), xr)
+    xg = x.clone().requires_grad_(True)
+    out = net(xg, t)
+    assert_close(out, ref.detach(), 1e-5, what='forward')
+    gx, = torch.autograd.grad((out * cot).sum(), xg)
+    assert_close(gx, gref, 1e-5, what='input VJP')
