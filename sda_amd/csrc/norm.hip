@@ -433,6 +433,16 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
         hh[j] = ln_ld4<SPLIT == 8>(x + off);
         if (!on) { g[j] = make_float4(0.f, 0.f, 0.f, 0.f); hh[j] = make_float4(m4.x, m4.y, m4.z, m4.w); }
     }
+    // the residual stream's loads go out with the other two streams' (a third more bytes in flight per wavefront), not behind
+    // the cross-lane reduction: 96 channels at 256^2 5.57 -> 5.86 TB/s, 384 channels at 64^2 4.05 -> 5.12 (tools/ln_bench.py, 120 windows)
+    float4 rr_[CPL];
+    if (res) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int k = sub + SPLIT * j;
+            rr_[j] = ln_ld4<SPLIT == 8>(res + base + (int64_t)(k < c ? k : 0) * hw);
+        }
+    }
     if (mp) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
             float4 v = make_float4(r4.x * (g[j].x - a.x - hh[j].x * b.x), r4.y * (g[j].y - a.y - hh[j].y * b.y),
                                    r4.z * (g[j].z - a.z - hh[j].z * b.z), r4.w * (g[j].w - a.w - hh[j].w * b.w));
             if (res) {
-                const float4 rr = ln_ld4<SPLIT == 8>(res + off);
+                const float4 rr = rr_[j];
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             ln_st4<SPLIT == 8>(gx + off, v);
