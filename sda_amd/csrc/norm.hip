@@ -564,9 +564,15 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
             hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (c <= 192 && quad_mode == 2) {            // (A/B: 128-byte runs, 24 channels per lane)
+            dim3 gr((unsigned)((nquad + 31) / 32));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else if (c <= 192) {
             dim3 gr((unsigned)((nquad + 15) / 16));
             hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (quad_mode == 2) {                        // (A/B: 32-byte runs, 12 channels per lane, three wavefronts per SIMD)
+            dim3 gr((unsigned)((nquad + 7) / 8));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<32, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else {
             dim3 gr((unsigned)((nquad + 15) / 16));
             hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
