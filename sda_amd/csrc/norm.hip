@@ -227,6 +227,9 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
         hipStream_t st = (hipStream_t)stream;
         dim3 bl(LN_THREADS);
         if (c <= 96) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        // 192 channels as 8 lanes x 24 channels (128-byte runs, non-temporal): 0.298 -> 0.233 ms at 120 windows, 5.1 -> 6.5 TB/s
+        // (SDA_LN_STATS_QUAD=3: the 16 x 12 layout, for A/B); 384 channels as 8 x 48 (297 registers) lose: 4.65 vs 5.1 TB/s
+        else if (c <= 192 && quad_mode != 3) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 24>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         else if (c <= 192) hipLaunchKernelGGL((ln_stats_quad_kernel<16, 12>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         else hipLaunchKernelGGL((ln_stats_quad_kernel<16, 24>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         return sda_launch_status();
@@ -564,15 +567,15 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
             hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        } else if (c <= 192 && quad_mode == 2) {            // (A/B: 128-byte runs, 24 channels per lane)
+        } else if (c <= 192 && quad_mode != 3) {
+            // 8 lanes x 24 channels: 128-byte runs like the 96-channel level (one wavefront per SIMD -- 376 registers -- but with the
+            // residual loads ahead of the reduction it beats 16 x 12's 64-byte runs: 1.21 -> 1.07 ms at 120 windows, 5.0 -> 5.65 TB/s;
+            // before that change it lost, 4.48 vs 4.87.  SDA_LN_BWD_QUAD=3 keeps 16 x 12 for A/B.  384 channels as 32 x 12: 3.8 vs 5.0 TB/s)
             dim3 gr((unsigned)((nquad + 31) / 32));
             hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else if (c <= 192) {
             dim3 gr((unsigned)((nquad + 15) / 16));
             hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
-        } else if (quad_mode == 2) {                        // (A/B: 32-byte runs, 12 channels per lane, three wavefronts per SIMD)
-            dim3 gr((unsigned)((nquad + 7) / 8));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<32, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else {
             dim3 gr((unsigned)((nquad + 15) / 16));
             hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
