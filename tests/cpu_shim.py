@@ -182,3 +182,50 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, 'POOLED', False)        # (and the pooled-output form of the tails' VJP: plain launch + pooling reader)
     monkeypatch.setattr(ops, 'BLOCK1D', False)       # the fused 1-D block is a device kernel: the host replay takes the per-layer path
     monkeypatch.setattr(E.UNetEngine, "chunk_size", lambda self, n, hs, ws, save, device, fraction=None: n)
+    _install_3d(monkeypatch)
+
+
+def _install_3d(monkeypatch):
+    """The 3-D engine (sda_amd/engine3d.py) on CPU: its two launch types replaced by torch's conv3d, so that the sequencing of
+    heads / blocks / tails and of the hand-written VJP is checked without a GPU (the kernel itself: tests/test_gpu_unet3d.py)."""
+    import torch.nn.functional as F
+    from sda_amd import engine3d as E3
+
+    def _conv(self, x, up):
+        w, pads = self.conv.weight.detach(), list(self.pad)
+        for ax, u in enumerate(up):
+            x = x.repeat_interleave(u, dim=2 + ax)
+        if self.circular:
+            flat = []
+            for p in reversed(pads):
+                flat += [p, p]
+            return F.conv3d(F.pad(x, flat, mode='circular'), w, None, stride=self.stride)
+        return F.conv3d(x, w, None, stride=self.stride, padding=pads)
+
+    def forward(self, x, *, up=(1, 1, 1), act_in=0, res=None):
+        if act_in:
+            x = _ACT[act_in](x)
+        out = _conv(self, x, up)
+        if self.conv.bias is not None:
+            out = out + self.conv.bias.detach().reshape(1, -1, 1, 1, 1)
+        return (out if res is None else out + res).contiguous()
+
+    def vjp(self, g, in_size, *, act=0, z=None, res=None):
+        with torch.enable_grad():
+            xin = torch.zeros((g.shape[0], self.cin) + tuple(in_size), requires_grad=True)
+            y = _conv(self, xin, (1, 1, 1))
+        out, = torch.autograd.grad(y, xin, g)
+        if z is not None:
+            with torch.enable_grad():
+                zz = z.detach().clone().requires_grad_(True)
+                dz, = torch.autograd.grad(_ACT[act](zz).sum(), zz)
+            out = out * dz
+        return (out if res is None else out + res).contiguous()
+
+    def pool_sum(g, f):
+        n, c, d, h, w = g.shape
+        return g.reshape(n, c, d // f[0], f[0], h // f[1], f[1], w // f[2], f[2]).sum((3, 5, 7)).contiguous()
+
+    monkeypatch.setattr(E3._Conv3d, 'forward', forward)
+    monkeypatch.setattr(E3._Conv3d, 'vjp', vjp)
+    monkeypatch.setattr(E3, '_pool_sum', pool_sum)

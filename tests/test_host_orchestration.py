@@ -254,3 +254,23 @@ def test_gaussian_score_reads_live_std_gamma():
     gv = GaussianScore(g['y_obs'], A=_A, std=torch.full(g['y_obs'].shape[-3:], 0.2), sde=inner, gamma=5e-2)
     assert gv._scalars is None
     assert_close(gv(x, t), fresh(0.2, 5e-2, _A), 1e-5)
+
+
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_unet3d_orchestration_golden(case):
+    """``UNet(spatial=3)``: engine3d's sequencing (heads, modulated blocks, LayerNorm -> up-sample -> conv tails, skips) and its
+    hand-written input VJP against the fixture the reference's own Conv3d U-Net produced (launches = torch conv3d stand-ins)."""
+    from sda_amd.score import ScoreUNet
+    g, grp = load_golden('unet3d_tiny')
+    if case == 'a':
+        net = ScoreUNet(2, context=1, embedding=8, hidden_channels=(4, 8), hidden_blocks=(1, 1), kernel_size=3,
+                        activation=nn.SiLU, spatial=3, padding_mode='circular')
+    else:
+        net = ScoreUNet(3, embedding=8, hidden_channels=(5, 20), hidden_blocks=(1, 2), kernel_size=(1, 3, 3), stride=(1, 2, 2),
+                        activation=nn.ELU, spatial=3)
+    net.load_state_dict(grp['sd_' + case])
+    x = g['x_' + case].clone().requires_grad_(True)
+    out = net(x, g['t_' + case], g.get('c_' + case))
+    assert_close(out, g['out_' + case], TOL)
+    gx, = torch.autograd.grad((out * g['cot_' + case]).sum(), x)
+    assert_close(gx, g['gx_' + case], TOL)
