@@ -22,6 +22,8 @@ from ._lib import SdaHipError
 class _Conv3d:
     """Packed forward / input-VJP weights of one ``nn.Conv3d`` (re-packed when the parameter changes)."""
 
+    MAX_IMAGES = 65535
+
     def __init__(self, conv):
         if tuple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
             raise NotImplementedError('dilated / grouped convolutions have no gfx950 kernel')
@@ -70,15 +72,21 @@ class _Conv3d:
         for t in (x, out, z, res):
             if t is not None and not t.is_contiguous():
                 raise SdaHipError('conv3d operands are planar and contiguous')
+        if x.shape[1] != cin or out.shape[1] != cout or out.shape[0] != x.shape[0]:
+            raise SdaHipError(f'conv3d: operand shapes {tuple(x.shape)} -> {tuple(out.shape)} do not match the {cin} -> {cout} operator')
         d = _lib.Conv3dDesc()
-        d.x, d.w, d.bias, d.z, d.res, d.out = x.data_ptr(), w.data_ptr(), ops._ptr(bias), ops._ptr(z), ops._ptr(res), out.data_ptr()
-        d.n, d.cin, d.cout = x.shape[0], cin, cout
+        d.w, d.bias, d.cin, d.cout = w.data_ptr(), ops._ptr(bias), cin, cout
         for a in range(3):
             d.in_size[a], d.out_size[a] = x.shape[2 + a], out.shape[2 + a]
             d.k[a], d.pad[a], d.stride[a], d.up[a], d.dil[a] = self.k[a], pad[a], stride[a], up[a], dil[a]
         d.circular, d.act, d.act_in = int(self.circular), act, act_in
-        assert x.shape[1] == cin and out.shape[1] == cout and out.shape[0] == x.shape[0]
-        _lib.check(_lib.load().sda_conv3d(d, ops._stream()), 'sda_conv3d')
+        lib, n = _lib.load(), x.shape[0]
+        for lo in range(0, n, self.MAX_IMAGES):              # (the image index is the grid's z dimension: 65 535 per launch)
+            hi = min(n, lo + self.MAX_IMAGES)
+            d.n = hi - lo
+            d.x, d.out = x[lo:hi].data_ptr(), out[lo:hi].data_ptr()
+            d.z, d.res = (None if z is None else z[lo:hi].data_ptr()), (None if res is None else res[lo:hi].data_ptr())
+            _lib.check(lib.sda_conv3d(d, ops._stream()), 'sda_conv3d')
         return out
 
     def forward(self, x: Tensor, *, up=(1, 1, 1), act_in=0, res=None) -> Tensor:

@@ -189,3 +189,21 @@ def test_mcscorenet_over_a_3d_kernel(dev):
     assert_close(out, ref.detach(), 1e-5, what='forward')
     gx, = torch.autograd.grad((out * cot).sum(), xg)
     assert_close(gx, gref, 1e-5, what='input VJP')
+
+
+def test_conv3d_batch_beyond_one_launch(dev, monkeypatch):
+    """More images than one launch's grid takes (65 535 in the product; 3 here): the launcher walks the batch in slices."""
+    from sda_amd.engine3d import _Conv3d
+    torch.manual_seed(2)
+    conv = torch.nn.Conv3d(3, 5, 3, padding=1).to(dev)
+    x = torch.randn(8, 3, 4, 4, 4, device=dev)
+    res = torch.randn(8, 5, 4, 4, 4, device=dev)
+    op = _Conv3d(conv)
+    whole = op.forward(x, res=res)
+    monkeypatch.setattr(_Conv3d, 'MAX_IMAGES', 3)
+    assert torch.equal(op.forward(x, res=res), whole)
+    g = torch.randn_like(whole)
+    z = torch.randn_like(x)
+    sliced = op.vjp(g, (4, 4, 4), act=1, z=z)
+    monkeypatch.setattr(_Conv3d, 'MAX_IMAGES', 65535)
+    assert torch.equal(op.vjp(g, (4, 4, 4), act=1, z=z), sliced)
