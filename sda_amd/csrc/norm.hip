@@ -118,16 +118,23 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_reg_kernel(const float* _
 // hw % 4 == 0, c <= SPLIT * CPL: a lane owns FOUR consecutive pixels (16-byte loads) and every SPLIT-th channel, the SPLIT lanes
 // of a quad sit 64 / SPLIT apart (see ln_bwd_quad_kernel); the channel vectors stay in registers between the mean and the
 // centred pass.
-template <int SPLIT, int CPL>
+// NW > 1: NW wavefronts of a workgroup share a quad group, each with its own slice of SPLIT * CPL channels (c <= NW * SPLIT * CPL), and
+// combine their partial sums through LDS -- the 384-channel level keeps the 128-byte runs and the register footprint of the 96-channel
+// layout (8 lanes x 12 channels, four wavefronts) instead of 24 channels per lane on 64-byte runs.
+template <int SPLIT, int CPL, int NW = 1>
 __global__ __launch_bounds__(LN_THREADS) void ln_stats_quad_kernel(const float* __restrict__ x, int64_t nquad, int c, int hw,
                                                                    const float* __restrict__ mod, int64_t mod_sn, float eps,
                                                                    int unbiased, float* __restrict__ mean,
                                                                    float* __restrict__ rstd) {
     constexpr int QW = 64 / SPLIT;
+    constexpr int WPB = LN_THREADS / 64;
+    static_assert(WPB % NW == 0, "cooperating wavefronts must tile the workgroup");
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    const int wib = threadIdx.x >> 6, cw = wib % NW;
+    const int64_t wave = NW > 1 ? (int64_t)blockIdx.x * (WPB / NW) + wib / NW : ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
     const int64_t quad = wave * QW + (lane & (QW - 1));
-    const int sub = lane / QW;
+    const int sub = cw * (SPLIT * CPL) + lane / QW;          // first channel of this lane
+    __shared__ float4 part[2][NW > 1 ? WPB : 1][QW];
     const bool live = quad < nquad;
     const int64_t pix = (live ? quad : 0) * 4;
     const int64_t n = pix / hw;
@@ -156,6 +163,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_quad_kernel(const float* 
     for (int o = QW; o < 64; o <<= 1) {
         s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
     }
+    if constexpr (NW > 1) {
+        if (lane < QW) part[0][wib][lane] = s;
+        __syncthreads();
+        s = part[0][wib - cw][lane & (QW - 1)];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) { const float4 t = part[0][wib - cw + i][lane & (QW - 1)]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    }
     const float ic = 1.f / (float)c;
     const float4 m = make_float4(s.x * ic, s.y * ic, s.z * ic, s.w * ic);
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -169,6 +183,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_stats_quad_kernel(const float* 
 #pragma unroll
     for (int o = QW; o < 64; o <<= 1) {
         q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64); q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
+    }
+    if constexpr (NW > 1) {
+        if (lane < QW) part[1][wib][lane] = q;
+        __syncthreads();
+        q = part[1][wib - cw][lane & (QW - 1)];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) { const float4 t = part[1][wib - cw + i][lane & (QW - 1)]; q.x += t.x; q.y += t.y; q.z += t.z; q.w += t.w; }
     }
     if (live && sub == 0) {
         const float iv = 1.f / (float)(unbiased ? c - 1 : c);
@@ -229,6 +250,10 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
         if (c <= 96) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         // 192 channels as 8 lanes x 24 channels (128-byte runs, non-temporal): 0.298 -> 0.233 ms at 120 windows, 5.1 -> 6.5 TB/s
         // (SDA_LN_STATS_QUAD=3: the 16 x 12 layout, for A/B); 384 channels as 8 x 48 (297 registers) lose: 4.65 vs 5.1 TB/s
+        else if (c <= 192 && quad_mode == 4) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12, 2>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        // 384 channels: four cooperating wavefronts on the 96-channel layout, partial sums through LDS: 0.148 -> 0.132 ms, 5.1 -> 5.7 TB/s
+        // (for 192 channels two cooperating wavefronts measure 6.3 TB/s against 8 x 24's 6.5; ln_bwd gains nothing from either: 5.2 / 5.75)
+        else if (c > 192 && quad_mode != 3) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12, 4>), dim3((unsigned)((nquad + 7) / 8)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         else if (c <= 192 && quad_mode != 3) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 24>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         else if (c <= 192) hipLaunchKernelGGL((ln_stats_quad_kernel<16, 12>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         else hipLaunchKernelGGL((ln_stats_quad_kernel<16, 24>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
@@ -399,17 +424,21 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_split_kernel(const float* _
 // SPLIT-th channel; a wavefront covers 64 / SPLIT pixel quads, so each channel plane is touched in contiguous runs of
 // (64 / SPLIT) * 16 bytes -- a whole 128-byte line for SPLIT = 8 (the dword version above moves 64-byte runs with four times
 // the instructions).  The SPLIT lanes of a quad sit 64 / SPLIT apart and combine their partial sums with cross-lane adds.
-template <int SPLIT, int CPL, int POOL = 1>          // POOL == 2: gh at twice the resolution, summed over 2 x 2 cells (w = row length)
+template <int SPLIT, int CPL, int POOL = 1, int NW = 1>   // POOL == 2: gh at twice the resolution, summed over 2 x 2 cells (w = row length); NW: see ln_stats_quad_kernel
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __restrict__ gh, const float* __restrict__ x,
                                                                  int64_t nquad, int c, int hw, int w, const float* __restrict__ mod,
                                                                  int64_t mod_sn, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, int unbiased,
                                                                  const float* __restrict__ res, float* __restrict__ gx) {
     constexpr int QW = 64 / SPLIT;                          // quads per wavefront
+    constexpr int WPB = LN_THREADS / 64;
+    static_assert(WPB % NW == 0, "cooperating wavefronts must tile the workgroup");
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
+    const int wib = threadIdx.x >> 6, cw = wib % NW;
+    const int64_t wave = NW > 1 ? (int64_t)blockIdx.x * (WPB / NW) + wib / NW : ((int64_t)blockIdx.x * LN_THREADS + threadIdx.x) >> 6;
     const int64_t quad = wave * QW + (lane & (QW - 1));
-    const int sub = lane / QW;
+    const int sub = cw * (SPLIT * CPL) + lane / QW;          // first channel of this lane
+    __shared__ float4 part[2][NW > 1 ? WPB : 1][QW];
     const bool live = quad < nquad;
     const int64_t pix = (live ? quad : 0) * 4;
     const int64_t n = pix / hw;
@@ -466,6 +495,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
     for (int o = QW; o < 64; o <<= 1) {
         s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
         s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+    }
+    if constexpr (NW > 1) {
+        if (lane < QW) { part[0][wib][lane] = s1; part[1][wib][lane] = s2; }
+        __syncthreads();
+        s1 = part[0][wib - cw][lane & (QW - 1)]; s2 = part[1][wib - cw][lane & (QW - 1)];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) {
+            const float4 t1 = part[0][wib - cw + i][lane & (QW - 1)], t2 = part[1][wib - cw + i][lane & (QW - 1)];
+            s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+            s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+        }
     }
     if (!live) return;
     const float ia = 1.f / (float)c, ib = 1.f / (float)(unbiased ? c - 1 : c);
@@ -567,6 +607,12 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
             hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (c <= 192 && quad_mode == 4) {            // (A/B: two cooperating wavefronts, 8 lanes x 12 channels each)
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+        } else if (c > 192 && quad_mode == 4) {             // (A/B: four cooperating wavefronts)
+            dim3 gr((unsigned)((nquad + 7) / 8));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 4>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
         } else if (c <= 192 && quad_mode != 3) {
             // 8 lanes x 24 channels: 128-byte runs like the 96-channel level (one wavefront per SIMD -- 376 registers -- but with the
             // residual loads ahead of the reduction it beats 16 x 12's 64-byte runs: 1.21 -> 1.07 ms at 120 windows, 5.0 -> 5.65 TB/s;
