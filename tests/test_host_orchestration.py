@@ -274,3 +274,33 @@ def test_unet3d_orchestration_golden(case):
     assert_close(out, g['out_' + case], TOL)
     gx, = torch.autograd.grad((out * g['cot_' + case]).sum(), x)
     assert_close(gx, g['gx_' + case], TOL)
+
+
+def test_denoising_loss_is_a_value_only():
+    """``VPSDE.loss`` (sda/score.py:265-276): the reference's validation quantity under no_grad; a call that would need parameter
+    gradients is refused (the networks form input gradients only)."""
+    from sda_amd.score import VPSDE
+    g, grp = load_golden('unet1d_two_level')
+    net = build_unet1d_two_level()
+    net.load_state_dict(grp['sd'])
+    sde = VPSDE(net, shape=(3, 20))
+    x = g['x']
+    with pytest.raises(NotImplementedError, match='parameter gradients'):
+        sde.loss(x)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        got = sde.loss(x)
+    torch.manual_seed(3)
+    t = torch.rand(x.shape[0])
+    eps = torch.randn_like(x)
+    from oracle import sda_oracle as O
+    sched = O.Schedule()
+    tb = t.double().reshape(-1, 1, 1)
+    xt = sched.mu(tb) * x.double() + sched.sigma(tb) * eps.double()
+    cfg = O.UNetConfig(3, 3, 8, (8, 16), (1, 2), 3, 2, 'SiLU', 1, 'zeros')
+    sd = {k: v.double() for k, v in grp['sd'].items()}
+    want = (O.score_unet(sd, '', cfg, xt, t.double()) - eps.double()).square().mean()
+    assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert torch.isfinite(sde.loss(x))                   # frozen parameters: allowed with grad mode on
