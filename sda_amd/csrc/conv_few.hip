@@ -34,7 +34,16 @@ __global__ __launch_bounds__(512, 4) void conv_few_kernel(const sda_conv_desc d,
     __shared__ __attribute__((aligned(16))) float smem[2 * CF_BUF];
     const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int t = blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), and a halo row (34 floats starting one float before a
+    // 128-byte line) touches three lines: with tile = blockIdx, horizontally adjacent tiles always ran on DIFFERENT XCDs and each
+    // L2 fetched all three lines -- 9.5 GB per launch against 3.35 GB algorithmic (profiles/r04_kolmogorov256_few_traffic.json).
+    // Each XCD now walks a contiguous range of tiles: neighbours in x and y meet in the same L2.
+    int t;
+    {
+        const int total = (int)gridDim.x, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int tq = total >> 3, tr = total & 7;
+        t = xcd * tq + (xcd < tr ? xcd : tr) + slot;
+    }
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
     const int n = t / tiles_y;
