@@ -103,7 +103,7 @@ class _ConvCache:
         # (data_ptr, _version) catches optimiser steps, .to(), load_state_dict and in-place ops on the parameter; writes
         # through `.data` (EMA swaps: p.data.copy_(ema)) bump neither -- those callers use UNet.invalidate_engine()
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, str(w.device), None if self.conv.bias is None else self.conv.bias._version)
+        key = (w.data_ptr(), ops.tensor_version(w), str(w.device), None if self.conv.bias is None else ops.tensor_version(self.conv.bias))
         if key != self._key:
             self._key, self._fwd, self._bwd, self._parity = key, None, {}, None
 
@@ -283,7 +283,7 @@ class UNetEngine:
 
     def projection(self):
         """All blocks' ``project`` Linears concatenated row-wise: one small kernel gives every modulation vector."""
-        key = tuple((b.project.weight.data_ptr(), b.project.weight._version, b.project.bias._version) for b in self._blocks())
+        key = tuple((b.project.weight.data_ptr(), ops.tensor_version(b.project.weight), ops.tensor_version(b.project.bias)) for b in self._blocks())
         if key != self._proj_key:
             blocks = sorted(self._blocks(), key=lambda b: b.mod_off)
             w = torch.cat([b.project.weight.detach() for b in blocks], dim=0).contiguous()

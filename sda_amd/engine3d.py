@@ -44,7 +44,7 @@ class _Conv3d:
 
     def pack(self, transpose: bool) -> Tensor:
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = (w.data_ptr(), ops.tensor_version(w), str(w.device))
         if key != self._key:
             self._key, self._packs = key, {}
         if transpose not in self._packs:
@@ -98,6 +98,10 @@ class _Conv3d:
     def vjp(self, g: Tensor, in_size, *, act=0, z=None, res=None) -> Tensor:
         """Gradient w.r.t. the convolution's (possibly up-sampled) input of extent ``in_size``: the transposed convolution --
         flipped taps, zero insertion for a strided layer --, optionally x act'(z), optionally + res."""
+        if self.circular and any(n != go * s for n, go, s in zip(in_size, g.shape[2:], self.stride)):
+            # (the kernel wraps the zero-inserted gradient with period out x stride; only then is that the forward's period)
+            raise SdaHipError(f'circular strided Conv3d VJP: input extent {tuple(in_size)} is not output {tuple(g.shape[2:])} x stride '
+                              f'{tuple(self.stride)}')
         out = torch.empty((g.shape[0], self.cin) + tuple(in_size), device=g.device, dtype=torch.float32)
         pad = tuple(k - 1 - p for k, p in zip(self.k, self.pad))
         return self._launch(g, self.pack(True), out, self.cout, self.cin, pad=pad, dil=self.stride, act=act, z=z, res=res)
@@ -167,7 +171,7 @@ class UNet3dEngine:
         blocks = self._blocks()
         if not blocks:
             return None
-        key = tuple((b.project.weight.data_ptr(), b.project.weight._version, b.project.bias._version) for b in blocks)
+        key = tuple((b.project.weight.data_ptr(), ops.tensor_version(b.project.weight), ops.tensor_version(b.project.bias)) for b in blocks)
         if key != self._proj_key:
             w = torch.cat([b.project.weight.detach() for b in blocks], dim=0).contiguous()
             bias = torch.cat([b.project.bias.detach() for b in blocks], dim=0).contiguous()

@@ -13,16 +13,18 @@ from ..utils import ACTIVATIONS, load_config
 
 class LocalScoreUNet(ScoreUNet):
     r"""Score U-Net with a forcing channel sin(4 * 2 pi (i + 1/2) / size) as its single context channel
-    (kolmogorov/utils.py:29-46).  The channel is never concatenated: the head convolution's loader reads it as a
-    broadcast context plane."""
+    (kolmogorov/utils.py:29-46), defined as the reference defines it: ``forward`` hands ``self.forcing`` on as the context.
+    The channel is never concatenated (the head convolution's loader reads it as a broadcast context plane), and inside an
+    ``MCScoreNet`` the override is recognised as context-only (``score._context_only_override``), so this class -- and the
+    reference's own, when its driver file runs unchanged on this package -- takes the fused window path."""
 
     def __init__(self, channels: int, size: int = 64, **kwargs):
         super().__init__(channels, 1, **kwargs)
         domain = 2 * torch.pi / size * (torch.arange(size) + 1 / 2)
         self.register_buffer('forcing', torch.sin(4 * domain).expand(1, size, size).clone())
 
-    def _context(self, c):
-        return self.forcing
+    def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        return super().forward(x, t, self.forcing)
 
 
 def make_score(

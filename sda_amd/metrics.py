@@ -5,7 +5,8 @@ r"""Evaluation metrics of the sampling experiments: the reference's ``sda.utils.
   solved on the host, as in the reference (``ot.emd2`` is POT's CPU network simplex; POT is a third-party dependency the
   reference does not vendor).  With empty weight vectors POT uses uniform weights, and for equally many samples on both
   sides -- how experiments/lorenz/eval.py:61-63,89 call it (1024 vs 1024) -- an optimal plan is a permutation, so the LP
-  is a linear assignment problem (``sda_assignment_cost``, exact, O(n^3)).  Unequal sample counts are not supported.
+  is a linear assignment problem (``sda_assignment_cost``, exact, O(n^3)).  Unequal sample counts go through an integral
+  min-cost flow on the host (``sda_transport_cost``), exact as well.
 * ``mmd`` -- squared distances from the same kernel (differences are squared directly instead of expanding
   |x|^2 + |y|^2 - 2 x.y, which removes the reference's fp32 cancellation noise on the small bandwidths), then one fused
   pass per Gram block accumulates the seven Gaussian kernels in float64.

@@ -78,6 +78,7 @@ class _FusedPlan:
         self.ok = (1 <= len(self.gemms) <= _lib.MLP_MAXG and len(acts) <= 1 and len(epss) <= 1 and
                    all(i <= _MLP_W and o <= _MLP_W and lin.bias is not None for _, i, o, lin in self.gemms) and
                    all(i == o for k, i, o, _ in self.gemms if k) and
+                   all(i >= 2 for k, i, _o, _ in self.gemms if k == 1 and LN_UNBIASED) and   # (unbiased LayerNorm of one feature: C ABI says UNSUPPORTED)
                    all(self.gemms[j][1] == self.gemms[j - 1][2] for j in range(1, len(self.gemms))))
         self.act = acts.pop() if acts else 0
         self.eps = epss.pop() if epss else 1e-5
@@ -86,7 +87,7 @@ class _FusedPlan:
         self._key = None
 
     def _pack(self):
-        key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.bias._version, str(lin.weight.device)) for *_, lin in self.gemms)
+        key = tuple((lin.weight.data_ptr(), ops.tensor_version(lin.weight), ops.tensor_version(lin.bias), str(lin.weight.device)) for *_, lin in self.gemms)
         if key == self._key:
             return
         fw, bw, bs, w_off, b_off, wn, bn = [], [], [], [], [], 0, 0

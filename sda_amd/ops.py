@@ -18,6 +18,12 @@ WINOGRAD = os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3
 WINOGRAD4 = os.environ.get('SDA_CONV_WINO4', '1') != '0'    # ... its one-wave-per-SIMD kernel where images are multiples of 16
 
 
+def tensor_version(t) -> int:
+    """``t._version`` for cache keys; inference-mode tensors have no version counter (reading it raises) and cannot be written
+    in place either, so a constant stands in for them."""
+    return 0 if t is None or t.is_inference() else t._version
+
+
 def _dev(*tensors):
     for t in tensors:
         if t is None:
@@ -561,6 +567,10 @@ def pc_correct(x: Tensor, eps: Tensor, z: Tensor, b: int, partial: Tensor, tau: 
     per = x.numel() // b
     _lib.check(_lib.load().sda_pc_correct(x.data_ptr(), eps.data_ptr(), z.data_ptr(), b, per, partial.data_ptr(),
                                           nchunk, tau, sigma, _ptr(coef_dev), _stream()), 'sda_pc_correct')
+
+
+#: rows sda_pc_correct_keyed takes (its batch axis is grid.y; csrc/step1d.hip returns SDA_E_BADARG above)
+PC_KEYED_MAX_ROWS = 65535
 
 
 def pc_correct_keyed(x: Tensor, eps: Tensor, b: int, partial: Tensor, nchunk: int, tau: float, coef_dev: Tensor, seed: int, row0: int,

@@ -101,6 +101,9 @@ def all_gather_samples(local: Tensor, batch: int) -> Tensor:
     return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
 
 
+_UNSET = object()
+
+
 def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64, corrections: int = 0, tau: float = 1.0,
                    seed: int = 0, gather: bool = True, rank: Optional[int] = None,
                    world_size: Optional[int] = None) -> Tensor:
@@ -124,18 +127,23 @@ def sample_sharded(sde, batch: int, c: Optional[Tensor] = None, steps: int = 64,
                          'to all-reduce with; run it under a process group')
     if coupled and batch < world_size:
         raise ValueError(f'a batch-coupled score needs every rank in every all-reduce: batch {batch} < world size {world_size}')
-    sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, world_size)
-    if corrections > 0:
-        sde.noise_source = KeyedNoise((lo, hi), event, seed + 1, corrections, sde.device.device)
-    use_graph = sde.use_graph
-    for m in coupled:
-        m.shard = (lo, hi, batch, dist.group.WORLD if world_size > 1 else None)
-    if coupled and world_size > 1:
-        sde.use_graph = False            # (a collective per evaluation: the step is launched eagerly, not replayed)
+    # everything this function touches on the caller's objects is snapshotted first and restored whatever happens
+    keep = (sde.__dict__.get('initial_noise', _UNSET), sde.__dict__.get('noise_source', _UNSET), sde.__dict__.get('use_graph', _UNSET))
     try:
+        sde.initial_noise = sharded_initial_noise(batch, event, seed, rank, world_size)
+        if corrections > 0:
+            sde.noise_source = KeyedNoise((lo, hi), event, seed + 1, corrections, sde.device.device)
+        for m in coupled:
+            m.shard = (lo, hi, batch, dist.group.WORLD if world_size > 1 else None)
+        if coupled and world_size > 1:
+            sde.use_graph = False            # (a collective per evaluation: the step is launched eagerly, not replayed)
         local = sde.sample((hi - lo,), c=c, steps=steps, corrections=corrections, tau=tau)
     finally:
-        sde.initial_noise, sde.noise_source, sde.use_graph = None, None, use_graph
+        for name, value in zip(('initial_noise', 'noise_source', 'use_graph'), keep):
+            if value is _UNSET:
+                sde.__dict__.pop(name, None)     # (was the class default: leave no instance attribute behind)
+            else:
+                setattr(sde, name, value)
         for m in coupled:
             m.shard = None
     return all_gather_samples(local, batch) if gather else local

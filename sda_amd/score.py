@@ -9,6 +9,7 @@ differentiating a user-supplied observation operator ``A``.  No CPU path exists:
 """
 
 import math
+import threading
 from typing import Callable, Optional, Union
 
 import torch
@@ -66,6 +67,44 @@ class ScoreNet(nn.Module):
         return self.network(feats)
 
 
+class _ForwardProbe(threading.local):
+    """Armed while ``MCScoreNet`` asks a ``ScoreUNet`` subclass what its ``forward`` override hands on to ``ScoreUNet.forward``
+    (see ``_context_only_override``): ``calls`` collects the argument tuples, ``out`` is the placeholder returned instead of
+    running the network."""
+    calls = None
+    out = None
+
+
+_probe = _ForwardProbe()
+
+
+def _context_only_override(kernel: 'ScoreUNet', shape, t: Tensor, c: Optional[Tensor]):
+    """Does ``kernel.forward(x, t, c)`` amount to ``ScoreUNet.forward(kernel, x, t, c')`` for some context ``c'``?
+
+    That is the shape of the reference's own ``LocalScoreUNet`` (experiments/kolmogorov/utils.py:45-46: ``return
+    super().forward(x, t, self.forcing)``), whose nets ``make_score`` builds when the reference's driver files run unchanged on
+    this package.  The override is executed once on a storage-less placeholder of the unfolded shape with ``ScoreUNet.forward``
+    recording its arguments instead of launching; if it was entered exactly once, with the placeholder and ``t`` untouched, and
+    its result came back unchanged, the override only chose the context and ``(True, c')`` is returned -- the fused window
+    path may then stand in for ``fold(kernel(unfold(x)))``.  Anything else (arithmetic on x, several calls, post-processing,
+    an exception on the placeholder) answers ``(False, None)`` and the caller runs the override for real."""
+    if type(kernel).forward is ScoreUNet.forward:
+        return True, kernel._context(c)
+    ph = torch.empty(shape, device='meta')
+    out = torch.empty(shape, device='meta')
+    _probe.calls, _probe.out = [], out
+    try:
+        res = type(kernel).forward(kernel, ph, t, c)
+        calls = _probe.calls
+    except Exception:  # noqa: BLE001 -- an override that cannot digest the placeholder simply takes the generic path
+        return False, None
+    finally:
+        _probe.calls, _probe.out = None, None
+    if len(calls) == 1 and res is out and calls[0][0] is kernel and calls[0][1] is ph and calls[0][2] is t:
+        return True, kernel._context(calls[0][3])
+    return False, None
+
+
 class ScoreUNet(nn.Module):
     r"""U-Net score network (score.py:66-93): context channels concatenated, batch dims flattened, t embedded."""
 
@@ -79,6 +118,9 @@ class ScoreUNet(nn.Module):
         return c
 
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
+        if _probe.calls is not None:                     # (an MCScoreNet is asking what a subclass passes on; nothing runs)
+            _probe.calls.append((self, x, t, c))
+            return _probe.out
         c = self._context(c)
         ops._dev(x, t, c)
         spatial = self.network.spatial
@@ -223,11 +265,17 @@ class MCScoreNet(nn.Module):
 
     def forward(self, x: Tensor, t: Tensor, c: Tensor = None) -> Tensor:
         kernel = self.kernel
-        fused = isinstance(kernel, ScoreUNet) and type(kernel).forward is ScoreUNet.forward \
-            and x.dim() == kernel.network.spatial + 3 and kernel.network.spatial != 3    # (3-D kernels: the generic path)
+        fused = isinstance(kernel, ScoreUNet) and x.dim() == kernel.network.spatial + 3 \
+            and kernel.network.spatial != 3 \
+            and not (kernel._forward_hooks or kernel._forward_pre_hooks)         # (3-D kernels, hooked kernels: the generic path)
+        ctx_c = None
+        if fused:
+            # a subclass whose forward only supplies the context (the reference's LocalScoreUNet) is as good as the stock one
+            wl = 2 * self.order + 1
+            fused, ctx_c = _context_only_override(
+                kernel, (x.shape[0], max(x.shape[1] - 2 * self.order, 0), wl * x.shape[2]) + tuple(x.shape[3:]), t, c)
         if fused:
             ops._dev(x, t)
-            ctx_c = kernel._context(c)
             ops._dev(ctx_c)
             emb = kernel.embedding(t.reshape(-1))
             xin = x if x.is_contiguous() else x.contiguous()
@@ -423,7 +471,8 @@ class PCSampler:
         for j in range(self.corrections):
             F.forward(x, 1)
             F.backward(2, 1)                                  # eps(x, t - dt) and its per-tile sums of squares
-            if type(ns) is KeyedNoise and tuple(ns.event) == tuple(x.shape[1:]) and ns.hi - ns.lo == self.nb:
+            if type(ns) is KeyedNoise and tuple(ns.event) == tuple(x.shape[1:]) and ns.hi - ns.lo == self.nb \
+                    and self.nb <= ops.PC_KEYED_MAX_ROWS:         # (the batch is grid.y there; larger: draw + general correction)
                 ops.pc_correct_keyed(x, F.out, self.nb, F.partial, F.ptiles, self.tau, F.coef[6:7], ns.seed, ns.lo, F.step_i,
                                      ns.corrections, j)
             else:
@@ -600,6 +649,10 @@ class DPSGaussianScore(nn.Module):
         return out
 
 
+def _reprime_scalars(module, incompatible_keys) -> None:
+    module._prime_scalars()
+
+
 class GaussianScore(nn.Module):
     r"""Likelihood guidance for Gaussian inverse problems, p(y|x) = N(y | A(x), std^2 + gamma (sigma/mu)^2)
     (score.py:347-396).  Returns :math:`-\sigma(t) s(x(t), t | y)`.
@@ -619,7 +672,7 @@ class GaussianScore(nn.Module):
         self.detach = detach
         self._scalar_cache = None
         self._prime_scalars()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._prime_scalars())
+        self.register_load_state_dict_post_hook(_reprime_scalars)        # (a module-level function: the module stays picklable)
 
     def _prime_scalars(self):
         """Read std / gamma back NOW (construction, .to(), load_state_dict) so that the first guided evaluation -- possibly inside a
@@ -644,7 +697,7 @@ class GaussianScore(nn.Module):
         std, gamma = self.std, self.gamma
         if std.numel() != 1 or gamma.numel() != 1:
             return None
-        ver = lambda b: 0 if b.is_inference() else b._version        # (inference-mode tensors have no version counter)
+        ver = ops.tensor_version
         key = (std.data_ptr(), ver(std), std.device, gamma.data_ptr(), ver(gamma), gamma.device)
         hit = self._scalar_cache
         if hit is None or hit[0] != key:

@@ -55,7 +55,8 @@ def test_golden_mcscore2d_fused_and_generic(dev):
         out = net(x, t)
     assert_close(out.cpu(), g['out'], TOL, what='fused unfold/fold path')
 
-    # a user-style subclass overriding forward (as experiments/kolmogorov/utils.py does) takes the generic path
+    # a user-style subclass overriding forward the way experiments/kolmogorov/utils.py does (context only) is recognised and
+    # fused (tests/test_gpu_dropin.py looks at the routes); one that post-processes takes the generic path
     from sda_amd.score import MCScoreNet, ScoreUNet
 
     class UserLocal(ScoreUNet):
@@ -73,7 +74,20 @@ def test_golden_mcscore2d_fused_and_generic(dev):
     net2.to(dev)
     with torch.no_grad():
         out2 = net2(x, t)
-    assert_close(out2.cpu(), g['out'], TOL, what='generic path')
+    assert_close(out2.cpu(), g['out'], TOL, what='context-only override')
+
+    class UserPost(UserLocal):
+        def forward(self, x, t, c=None):
+            return super().forward(x, t, c) * 1.0
+
+    net3 = MCScoreNet(2, order=1)
+    net3.kernel = UserPost(6, 8, embedding=8, hidden_channels=(4, 8), hidden_blocks=(1, 1), kernel_size=3,
+                           activation=nn.SiLU, spatial=2, padding_mode='circular')
+    net3.load_state_dict(grp['sd'])
+    net3.to(dev)
+    with torch.no_grad():
+        out3 = net3(x, t)
+    assert_close(out3.cpu(), g['out'], TOL, what='generic path')
 
 
 def test_golden_guided_score_grad_and_dps(dev):
