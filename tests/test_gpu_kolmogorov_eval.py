@@ -1,0 +1,184 @@
+"""GPU: 2-D END-TO-END parity at the reference network size (VERDICT r4 missing #3).
+
+(i)  FREE-RUNNING, multi-step: the reference's Kolmogorov net (experiments/kolmogorov/train.py:15-22 -- window 5, (96, 192, 384),
+     (3, 3, 3), 22.9 M parameters) at 64 x 64 on trajectories of L = 6 (two windows each), Gaussian guidance through
+     ``x[..., ::4, ::4]`` with std 0.1, one Langevin correction per step -- 32 diffusion steps = 64 guided evaluations deep, every
+     step replayed from the captured hipGraph, nothing teacher-forced -- against the oracle's sampling loop (sda/score.py:225-263,
+     :375-396) run in fp32 and in fp64 from the same initial draw and the same corrector noise.  Bound (SURVEY 8c tier 3): the
+     reference arithmetic's own fp32-vs-fp64 deviation on this chain, floor 1e-4 -- and that deviation must itself stay small,
+     otherwise the chain is too ill-conditioned to test anything and the test FAILS rather than passing vacuously.
+(ii) STATISTICAL, the reference's own acceptance check for this experiment -- ``(A(x) - y_star).std()  # should be ~ 0.1``
+     (experiments/kolmogorov/figures.ipynb#cell11) -- in the form tests/test_gpu_lorenz_eval.py has for Lorenz: with
+     ``bench.SyntheticScore(net, scale=0)`` (the network still runs, forward and VJP, in every evaluation) the prior is N(0, I) and
+     eps is exact, so the posterior given ``y = A x + N(0, std^2)`` is Gaussian in closed form: N(y / (1 + std^2),
+     std^2 / (1 + std^2)) on the observed pixels, N(0, 1) elsewhere.  Full K64 net at 64 x 64, 16 trajectories x 16 frames,
+     128 steps x C = 1, free-running on the device RNG; checked against the closed form where the reference ALGORITHM attains it and
+     against two independent runs of the oracle's loop for what the algorithm itself biases.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import sda_oracle as O
+from tests.util import oracle_eps_from_module, rel_err
+
+pytestmark = pytest.mark.gpu
+K64 = dict(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from sda_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def k64(dev):
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(70)
+    net = make_score(size=64, **K64)
+    assert sum(p.numel() for p in net.parameters()) == 22_874_922          # the reference K64 net
+    return net, oracle_eps_from_module(net, 'mc2d')
+
+
+def _sub4(x):
+    return x[..., ::4, ::4]
+
+
+@pytest.mark.parametrize('batch', [1, 2])
+def test_k64_free_running_guided_hipgraph_vs_oracle(dev, k64, batch):
+    import bench
+    from sda_amd import observe as Ob
+    from sda_amd.parallel import KeyedNoise
+    from sda_amd.score import GaussianScore, VPSDE
+    net, eps_net = k64
+    net.to(dev)
+    steps, corr, tau, std, gamma = 32, 1, 0.5, 0.1, 1e-2
+    event = (6, 2, 64, 64)
+    torch.manual_seed(71 + batch)
+    x1 = torch.randn((batch,) + event)
+    y = torch.randn(_sub4(x1[0]).shape)                         # one observation shared by the batch (figures.ipynb#cell10)
+    ns = KeyedNoise((0, batch), event, 77, corr, dev)           # graph-safe corrector noise; the same draws go to the oracle
+    zs = torch.stack([ns(i, j) for i in range(steps) for j in range(corr)]).cpu()
+
+    score = bench.SyntheticScore(net)                           # a raw random-init net overflows under guidance
+    inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)
+    gs = GaussianScore(y, A=Ob.Subsample.space(4), std=std, sde=inner, gamma=gamma)
+    sde = VPSDE(gs, shape=event).to(dev)
+    sde.initial_noise, sde.noise_source = x1, ns
+    sampler = sde.sampler((batch,), steps=steps, corrections=corr, tau=tau).capture()
+    assert sampler._graph is not None
+    for _ in range(steps):
+        sampler.step()
+    got = sampler.result().cpu()
+    assert torch.isfinite(got).all()
+
+    sched = O.Schedule()
+
+    def oracle(dtype):
+        def eps(xx, tt):
+            mu, sg = sched.mu(tt), sched.sigma(tt)
+            return xx * (sg / (mu * mu + sg * sg)) + 0.1 * eps_net(xx, tt, None if dtype == torch.float32 else dtype)
+        sc = lambda xx, tt: O.gaussian_score(eps, sched, y.to(dtype), _sub4, std, gamma, xx, tt)
+        zz = zs.to(dtype)
+        return O.sample(sc, sched, x1.to(dtype), 4, steps, corr, tau, noise=lambda i, j: zz[i * corr + j])
+
+    ref32, ref64 = oracle(torch.float32), oracle(torch.float64)
+    assert torch.isfinite(ref64).all()
+    own = rel_err(ref32.double(), ref64)
+    err = rel_err(got.double(), ref64)
+    err32 = rel_err(got.double(), ref32.double())
+    print(f'K64 @ 64^2, B = {batch}, L = 6, {steps} guided PC steps (C = 1) through the hipGraph: HIP vs fp64 oracle {err:.2e}, '
+          f'HIP vs fp32 oracle {err32:.2e}, fp32 oracle vs fp64 oracle {own:.2e}')
+    assert own < 2e-3, (f'the oracle disagrees with itself across precisions by {own:.2e} on this chain: too ill-conditioned for a '
+                        f'free-running parity test to mean anything -- shorten it instead of widening the bound')
+    assert err <= max(1e-4, 3 * own), (f'{steps}-step free-running guided sample: HIP path vs fp64 oracle {err:.2e}; the fp32 oracle itself '
+                                       f'is {own:.2e} from the fp64 oracle (bound: max(1e-4, 3x that))')
+
+
+_ORACLE_RUNS = {}
+
+
+def _oracle_samples(y, std, gamma, seed, shape, steps, corr, tau):
+    key = (seed, tuple(shape), steps, corr, tau, std, gamma, float(y.double().sum()))
+    if key not in _ORACLE_RUNS:                                           # (shared by the eager and the graph variant)
+        _ORACLE_RUNS[key] = _oracle_samples_run(y, std, gamma, seed, shape, steps, corr, tau)
+    return _ORACLE_RUNS[key]
+
+
+def _oracle_samples_run(y, std, gamma, seed, shape, steps, corr, tau):
+    sched = O.Schedule()
+    eta = 1e-3
+    eps = lambda x, t: x * (sched.sigma(t) / (1 + eta * eta))            # exact for N(0, I) data (bench.SyntheticScore, scale = 0)
+    score = lambda x, t: O.gaussian_score(eps, sched, y, _sub4, std, gamma, x, t)
+    torch.manual_seed(seed)
+    return O.sample(score, sched, torch.randn(shape), 4, steps, corr, tau)
+
+
+def _per_sample_log_spread(obs, y):
+    return (obs - y).flatten(1).std(dim=1).log()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
+    import bench
+    from sda_amd import observe as Ob
+    from sda_amd.score import GaussianScore, VPSDE
+    net, _ = k64
+    net.to(dev)
+    B, L, steps, corr, tau, std, gamma = 256, 6, 128, 1, 0.5, 0.1, 1e-2
+    event = (L, 2, 64, 64)
+    torch.manual_seed(80)
+    y = torch.randn(_sub4(torch.empty(event)).shape) * math.sqrt(1 + std ** 2)        # y = A x + noise, x ~ N(0, I)
+    ref_a = _oracle_samples(y, std, gamma, 81, (B,) + event, steps, corr, tau)
+    ref_b = _oracle_samples(y, std, gamma, 82, (B,) + event, steps, corr, tau)
+
+    score = bench.SyntheticScore(net, scale=0.0)                          # the net still runs (forward + VJP) at every evaluation
+    inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)
+    gs = GaussianScore(y, A=Ob.Subsample.space(4), std=std, sde=inner, gamma=gamma)
+    sde = VPSDE(gs, shape=event).to(dev)
+    sde.use_graph = graph
+    torch.manual_seed(83)
+    x = sde.sample((B,), steps=steps, corrections=corr, tau=tau).cpu()
+    assert torch.isfinite(x).all()
+
+    zcrit = 4.5
+    obs, oa, ob = _sub4(x), _sub4(ref_a), _sub4(ref_b)                    # (B, L, 2, 16, 16)
+    n = obs.numel()
+    pm = y / (1 + std ** 2)
+    # (a) analytic posterior mean on the observed pixels (the corrector inflates their variance, not their mean): pooled z-score
+    #     with the sample's own spread, and the regression slope of the samples on y (closed form 1 / (1 + std^2))
+    res = obs - pm
+    z = (res.mean() / (res.std() / math.sqrt(n))).abs().item()
+    assert z < zcrit, f'observed pixels: pooled mean {z:.1f} standard errors from the analytic posterior mean'
+    yy = y.expand_as(obs)
+    slope = ((obs * yy).sum() / (yy * yy).sum()).item()
+    se = (res.std() / (yy * yy).sum().sqrt()).item()
+    assert abs(slope - 1 / (1 + std ** 2)) < zcrit * se + 1e-4, f'slope of A(x) on y {slope:.5f} vs {1 / (1 + std ** 2):.5f} (se {se:.1e})'
+    # (b) the reference's own acceptance check, figures.ipynb#cell11: (A(x) - y).std().  Measured with the oracle's loop: on this
+    #     N(0, I) prior the reference ALGORITHM leaves ~ 3 std with one tau = 0.5 correction per step (a predictor-only run collapses
+    #     to 0.1 std), and the per-trajectory spread is log-normal-ish with sd(log) ~ 0.44, because each trajectory adapts its own
+    #     Langevin step (score.py:259).  So: same order as std, and the per-trajectory log-spreads of the GPU run against those of
+    #     an oracle run by a two-sample z-test -- with the second oracle run as a check that the test is calibrated
+    spread, spread_a = (obs - y).std().item(), (oa - y).std().item()
+    assert 0.5 * std < spread < 6 * std, f'(A(x) - y).std() = {spread:.4f} is not of the order of std = {std}'
+    lg, la, lb = (_per_sample_log_spread(v, y) for v in (obs, oa, ob))
+    two = lambda p, q: ((p.mean() - q.mean()) / (p.var() / B + q.var() / B).sqrt()).abs().item()
+    z_s, z_cal = two(lg, la), two(lb, la)
+    assert z_cal < zcrit, f'oracle run vs oracle run: {z_cal:.1f} sigma -- the yardstick itself is off'
+    assert z_s < zcrit, (f'per-trajectory log (A(x) - y).std(): GPU {lg.mean():.3f} vs oracle {la.mean():.3f} ({z_s:.1f} sigma; oracle pair '
+                         f'{z_cal:.1f} sigma)')
+    assert abs(lg.std().item() / la.std().item() - 1) < 0.25                                  # and the same dispersion
+    # (c) unobserved pixels keep the prior N(0, 1): mean, and variance as the oracle's loop leaves it
+    mask = torch.ones(64, 64, dtype=torch.bool)
+    mask[::4, ::4] = False
+    un, un_a = x[..., mask], ref_a[..., mask]
+    assert abs(un.mean().item()) < zcrit / math.sqrt(un.numel())
+    assert abs(un.var().item() / un_a.var().item() - 1) < 0.01
+    print(f'kolmogorov assimilation (graph={graph}): (A(x)-y).std() {spread:.4f} (oracle {spread_a:.4f}; std {std}), mean z {z:.2f}, '
+          f'slope {slope:.5f} (closed form {1 / (1 + std ** 2):.5f}), log-spread {lg.mean():.3f} +- {lg.std():.3f} (oracle '
+          f'{la.mean():.3f} +- {la.std():.3f}; z {z_s:.2f}, oracle pair {z_cal:.2f})')
