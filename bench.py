@@ -437,6 +437,35 @@ def lorenz_eval_cpu(args, step, std, B, L, S, steps):
                        f'(oracle/sda_oracle.py), {cores} threads; scaled by {rows}/{B} rows and 2 / (37/6) evaluations per step')
 
 
+def partition(per_gpu, scaling, rank, world):
+    """(rows of this rank, global batch, first global row).  weak: every rank owns one configuration shard (`per_gpu` rows; N = 8 is
+    the BASELINE configuration itself).  strong: the configuration's global batch (per_gpu x 8) is fixed and split over the ranks."""
+    from sda_amd import parallel
+    if scaling == 'strong':
+        global_batch = per_gpu * 8
+        lo, hi = parallel.shard_range(global_batch, rank, world)
+        return hi - lo, global_batch, lo
+    return per_gpu, per_gpu * world, rank * per_gpu
+
+
+def rank_inputs(wl, event, scaling, rank, world):
+    """This rank's rows of the job's observation y and initial draw x(1), both keyed by GLOBAL row: any world size sees the same
+    y and samples the same trajectories, ranks draw distinct noise, and no rank materialises rows it does not own."""
+    from sda_amd import parallel
+    b, global_batch, lo = partition(wl['per_gpu'], scaling, rank, world)
+    oshape = (event[0], event[1], event[2] // 4, event[3] // 4) if wl['kind'] == 'kolmogorov' else ((event[0] + 7) // 8, 1)
+    if scaling == 'strong':
+        return (parallel.sharded_initial_noise(global_batch, oshape, 2, rank, world),
+                parallel.sharded_initial_noise(global_batch, event, 1, rank, world))
+    y = torch.stack([torch.randn(oshape, generator=torch.Generator().manual_seed(2000003 + lo + i)) for i in range(b)])
+    gen = torch.Generator()
+    rows = []
+    for i in range(lo, lo + b):
+        gen.manual_seed((1 * 1000003 + i) & 0x7fffffffffffffff)
+        rows.append(torch.randn(tuple(event), generator=gen))
+    return y, torch.stack(rows)
+
+
 def launch_plan(gpus, env, argv):
     """argv of the torch.distributed.run launcher this process re-executes itself under, or None when it already IS a rank
     (WORLD_SIZE set: launched by torchrun / the driver's `python -m torch.distributed.run ...` form) or a 1-GPU job.
@@ -513,36 +542,15 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.per_gpu:
         wl['per_gpu'] = args.per_gpu
-    if args.scaling == 'strong':
-        # the global batch of the configuration (per_gpu x 8) is fixed and split over the ranks
-        global_batch = wl['per_gpu'] * 8
-        lo, hi = parallel.shard_range(global_batch, rank, world)
-        b = hi - lo
-    else:
-        b = wl['per_gpu']
-        global_batch = b * world
-        lo = rank * b
+    b, global_batch, lo = partition(wl['per_gpu'], args.scaling, rank, world)
     net, event, A = build_model(wl, device)
     score = SyntheticScore(net)
     inner = VPSDE(score, shape=())
     object.__setattr__(score, '_sched', inner)       # plain attribute: not a submodule (inner.eps is score)
-    # observation of this rank's rows: row i of the global y is keyed by i, like the noise (any world size sees the same y)
-    oshape = (event[0], event[1], event[2] // 4, event[3] // 4) if wl['kind'] == 'kolmogorov' else ((event[0] + 7) // 8, 1)
-    y = parallel.sharded_initial_noise(global_batch, oshape, 2, rank, world) if args.scaling == 'strong' else \
-        torch.stack([torch.randn(oshape, generator=torch.Generator().manual_seed(2000003 + lo + i)) for i in range(b)])
+    y, x_init = rank_inputs(wl, event, args.scaling, rank, world)
     eps_mod = GaussianScore(y, A=A, std=0.1, sde=inner) if args.guided else score
     sde = VPSDE(eps_mod, shape=event).to(device)
-    # every rank draws its rows of the row-keyed noise streams: 1-GPU and N-GPU jobs sample the same trajectories, ranks draw
-    # distinct noise, nothing scales with the world size, and the corrector draw is graph-capturable (sda_randn_rows)
-    if args.scaling == 'strong':
-        sde.initial_noise = parallel.sharded_initial_noise(global_batch, event, 1, rank, world)
-    else:
-        gen = torch.Generator()
-        rows = []
-        for i in range(lo, lo + b):
-            gen.manual_seed((1 * 1000003 + i) & 0x7fffffffffffffff)
-            rows.append(torch.randn(tuple(event), generator=gen))
-        sde.initial_noise = torch.stack(rows)
+    sde.initial_noise = x_init
     if args.corrections > 0:
         sde.noise_source = parallel.KeyedNoise((lo, lo + b), event, 2, args.corrections, device)
     sampler = sde.sampler((b,), steps=1000, corrections=args.corrections, tau=args.tau)

@@ -137,3 +137,64 @@ def test_gloo_world2_sample_sharded_equals_single_process():
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
+
+
+def _worker8(rank, ws, port, ret):
+    """One of 8 ranks of the real partition shape scaled down (configs[3]: 128 trajectories -> 16 per rank; here 16 -> 2 per rank):
+    equal shares, i.e. the single `all_gather_into_tensor` path."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    mpatch = pytest.MonkeyPatch()
+    try:
+        from tests import cpu_shim
+        cpu_shim.install(mpatch)
+        calls = []
+        real = dist.all_gather_into_tensor
+        mpatch.setattr(dist, 'all_gather_into_tensor', lambda out, inp, **kw: (calls.append(tuple(out.shape)), real(out, inp, **kw))[1])
+        batch = 2 * ws
+        assert P.shard_range(batch, rank, ws) == (2 * rank, 2 * rank + 2)
+        sde = _tiny_guided_sde()
+        got = P.sample_sharded(sde, batch, steps=2, corrections=1, tau=0.5, seed=7)
+        assert got.shape == (batch, 5, 2, 8, 8) and calls == [(batch, 5, 2, 8, 8)]
+        assert sde.initial_noise is None and sde.noise_source is None
+        if rank == 0:                                   # the single-process run of the same job, once
+            alone = P.sample_sharded(sde, batch, steps=2, corrections=1, tau=0.5, seed=7, rank=0, world_size=1)
+            ret['equal'] = bool(torch.equal(got, alone))
+            ret['maxdiff'] = float((got - alone).abs().max())
+        ret[rank] = True
+    finally:
+        mpatch.undo()
+        dist.destroy_process_group()
+
+
+def test_gloo_world8_equal_shares_equals_single_process():
+    """world_size 8 -- the node the BASELINE configurations are quoted on: 8 ranks x 2 trajectories gathered by ONE
+    all_gather_into_tensor equal the 16-trajectory single-process run bit for bit (row-keyed noise, no in-loop collective)."""
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(8))
+    assert ret['equal'], ret['maxdiff']
+
+
+def test_sample_sharded_restores_what_the_caller_had_set(monkeypatch):
+    from tests import cpu_shim
+    cpu_shim.install(monkeypatch)
+    sde = _tiny_guided_sde()
+    mine = lambda i, j: torch.zeros(1, 5, 2, 8, 8)
+    sde.noise_source = mine
+    sde.use_graph = False
+    P.sample_sharded(sde, 2, steps=1, corrections=1, tau=0.5, seed=1, rank=0, world_size=1)
+    assert sde.noise_source is mine and sde.initial_noise is None and sde.__dict__['use_graph'] is False
+    fresh = _tiny_guided_sde()
+    with pytest.raises(ZeroDivisionError):
+        monkeypatch.setattr(P, 'KeyedNoise', lambda *a, **k: 1 / 0)
+        P.sample_sharded(fresh, 2, steps=1, corrections=1, tau=0.5, seed=1, rank=0, world_size=1)
+    assert fresh.initial_noise is None and 'initial_noise' not in fresh.__dict__ and 'use_graph' not in fresh.__dict__
