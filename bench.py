@@ -248,7 +248,7 @@ PEAK_MFMA_F32 = 157.3      # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0          # GB/s
 
 
-def roofline_report(prof, prof_steps, step_s, args, root):
+def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
     """Per kernel family, from HIP-event timings of `prof_steps` steps.  The dominant family's ISSUED MFMA rate over the fp32
     matrix peak is `frac` (Winograd F(2x2,3x3) issues 1/2.25 of the algorithmic flops); the direct-equivalent rate is an extra."""
     s = prof.summary()
@@ -273,11 +273,12 @@ def roofline_report(prof, prof_steps, step_s, args, root):
                      'algorithmic_GBps': gbs, 'frac_of_8TBps': gbs / PEAK_HBM}
     conv = {k: v for k, v in fam.items() if 'issued_mfma_tflops' in v}
     dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
-    traffic, tfile = None, None
-    for rnd in ('r04', 'r03', 'r02'):             # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    traffic, tfile, tracked = None, None, {}
+    for rnd in ('r05', 'r04', 'r03', 'r02'):      # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            tracked = json.load(open(tfile))
+            traffic = tracked.get('hbm_bytes_per_launch')
             break
     kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
               'wino4zp': 'conv_wino4_kernel, zero-position form (up-sampling tails and their VJP: 9 of 16 Winograd positions)',
@@ -291,6 +292,19 @@ def roofline_report(prof, prof_steps, step_s, args, root):
               'block1d_fwd': 'block1d_fwd_kernel (fused 1-D residual block, v_mfma_f32_16x16x4_f32)',
               'block1d_bwd': 'block1d_bwd_kernel (fused 1-D residual block VJP, v_mfma_f32_16x16x4_f32)'}.get(dom, dom)
     d = conv.get(dom, {})
+    # the clock `frac` was measured at.  The peak is quoted at 2.4 GHz; the boxes of the pool sustain 2.17-2.29 GHz under this kernel
+    # (power-limited, data dependent), so the same build reads 0.70-0.73 depending on the box.  Two readings: the matrix-core
+    # stream's own clock on THIS box (sda_clock_probe, run after the warm-up steps), and the dominant kernel's clock = its cycles per
+    # launch (GRBM_GUI_ACTIVE / 8 XCDs from the tracked PMC pass of this build -- a property of the code) / its live launch time.
+    clock = None
+    if clock_probe is not None and d.get('mfma_util') is not None:
+        clock = {'peak_quoted_at_GHz': 2.4, 'probe': clock_probe, 'frac_at_probe_clock': d['mfma_util'] * 2.4 / clock_probe['ghz']}
+        cyc = (tracked.get('dominant_kernel_counters_per_launch') or {}).get('GRBM_GUI_ACTIVE')
+        if cyc and dom == 'wino4' and d.get('avg_launch_ms'):
+            ghz = cyc / 8 / (d['avg_launch_ms'] * 1e-3) / 1e9
+            clock.update(dominant_kernel_GHz=ghz, dominant_kernel_cycles_per_launch=cyc / 8,
+                         frac_of_kernel_cycles=d['mfma_util'] * 2.4 / ghz,
+                         cycles_source=os.path.basename(tfile) + ' (GRBM_GUI_ACTIVE / 8, tracked PMC pass)')
     latency = None
     if dom in ('small1d', 'block1d_fwd', 'block1d_bwd', 'net1d_fwd', 'net1d_bwd'):
         # the 1-D nets are LATENCY-bound (a launch is a few hundred kFLOP per image): the model that prices them is launches per
@@ -306,7 +320,7 @@ def roofline_report(prof, prof_steps, step_s, args, root):
                    'floor_us_per_step_bracketed_kernels': 1.7 * n_launch}
     return {'bound': 'latency' if latency else 'mfma', 'latency': latency,
             'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-            'frac': d.get('mfma_util'), 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
+            'frac': d.get('mfma_util'), 'clock': clock, 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
             'traffic_is': 'HBM/fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE '
                           '(calibrated on known byte counts in the kernel\'s own access shapes, tools/fetch_calib.hip); compare with '
@@ -573,6 +587,11 @@ def main():
     for _ in range(args.warmup):
         sampler.step()
     sync()
+    probe = None
+    if rank == 0 and not args.no_profile:
+        probe = ops.clock_probe(device)              # (before the timed region; synchronises)
+    if world > 1:
+        sync()
     prof = None
     if rank == 0 and not args.no_profile and not args.graph:
         prof = ops.ConvProfile()                     # eager timed region: the events bracket the timed launches themselves
@@ -635,7 +654,7 @@ def main():
         if os.environ.get('SDA_HIP_LIB'):            # a tooling build of the kernels was swapped in: say so in the line
             out['kernel_library_override'] = os.environ['SDA_HIP_LIB']
         if prof is not None and prof_steps > 0:
-            out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT)
+            out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT, probe)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, args, bool(args.guided), args.corrections)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 9
+#define SDA_ABI_VERSION 10
 
 enum {
     SDA_OK = 0,
@@ -519,6 +519,15 @@ int sda_conv3d(const sda_conv3d_desc* d, void* stream);
 int64_t sda_conv3d_packed_floats(int cout, int cin, int kd, int kh, int kw, int transpose);
 int sda_pack_conv3d_weight(const float* w, int cout, int cin, int kd, int kh, int kw, int transpose, float* dst, void* stream);
 int sda_pool3d_sum(const float* g, int64_t nc, int d, int h, int w, int fd, int fh, int fw, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement support (ABI v10; no counterpart in the reference, which has no measurement code -- SURVEY.md section 6):
+ * the shader clock the fp32 matrix-core stream sustains on this device.  `blocks` workgroups of 256 threads each issue
+ * iters x 8 v_mfma_f32_16x16x4_f32 per wave from registers; out[2 b] = shader cycles (s_memtime), out[2 b + 1] = 100 MHz ticks
+ * (s_memrealtime) workgroup b's first wave saw across its stream: clock = cycles / ticks x 100 MHz.  `sink`: one float of scratch.
+ * bench.py runs it after the warm-up steps and reports roofline.frac next to the clock it was measured at.
+ * ------------------------------------------------------------------------------------------ */
+int sda_clock_probe(unsigned long long* out, int blocks, float* sink, int iters, void* stream);
 
 #ifdef __cplusplus
 }

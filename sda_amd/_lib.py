@@ -224,6 +224,7 @@ SIGNATURES = {
     'sda_sumsq_partial': (c_int, [c_fp, c_int, c_int64, c_fp, c_int, c_void_p]),
     'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),
     'sda_randn_rows': (c_int, [c_fp, c_int, c_int64, c_uint64, c_int64, c_int64, c_fp, c_int64, c_int64, c_void_p]),
+    'sda_clock_probe': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'sda_philox_words': (c_int, [c_fp, c_int64, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
     'sda_denoise': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_guided_combine': (c_int, [c_fp, c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),

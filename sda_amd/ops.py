@@ -706,3 +706,24 @@ def assignment_cost(cost: Tensor):
     _lib.check(_lib.load().sda_assignment_cost(cost.data_ptr(), n, ctypes.addressof(total), cols.data_ptr()),
                'sda_assignment_cost')
     return total.value, cols
+
+
+def clock_probe(device, ms: float = 2.0, blocks: int = 1024) -> dict:
+    """The shader clock (GHz) the fp32 matrix-core stream sustains on ``device`` right now (``sda_clock_probe``): ``blocks``
+    workgroups of four waves issue register-resident v_mfma_f32_16x16x4_f32 for about ``ms`` milliseconds and time themselves with
+    the shader-clock and the 100 MHz counters.  Measurement support for bench.py; synchronises the device."""
+    lib = _lib.load()
+    out = torch.zeros(2 * blocks, device=device, dtype=torch.int64)
+    sink = torch.zeros(1, device=device, dtype=torch.float32)
+    # 8 MFMAs x 32 cycles per round and wave, one wave per SIMD per resident workgroup; `blocks` over 256 CUs run in waves of 256 x
+    # (workgroups per CU): size the rounds so that the whole launch lasts ~ms at 2.4 GHz
+    per_cu = max(1, -(-blocks // 256))
+    iters = max(64, int(ms * 1e-3 * 2.4e9 / (8 * 32) / per_cu))
+    with torch.cuda.device(device):
+        for _ in range(2):                                  # (the first launch also pays the code upload)
+            _lib.check(lib.sda_clock_probe(out.data_ptr(), blocks, sink.data_ptr(), iters, _stream()), 'sda_clock_probe')
+        torch.cuda.synchronize(device)
+    v = out.reshape(blocks, 2).double()
+    ghz = (v[:, 0] / v[:, 1].clamp_min(1)) * 0.1
+    return {'ghz': float(ghz.median()), 'ghz_min': float(ghz.min()), 'ghz_max': float(ghz.max()), 'blocks': blocks,
+            'mfma_per_wave': iters * 8, 'instruction': 'v_mfma_f32_16x16x4_f32, register operands'}

@@ -736,3 +736,12 @@ def test_wino4_silu_derivative_strongly_negative_preactivation(dev, cin, hw):
     assert ops.conv_path(desc) == 2                      # conv_wino4
     assert torch.isfinite(out).all(), 'SiLU\'(z) overflowed for a strongly negative pre-activation'
     assert_close(out.cpu(), ref_conv(x, wgt, None, 1, True) * dz, TOL)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(dev):
+    """sda_clock_probe (measurement support for bench.py): the fp32 matrix-core stream's own clock, from the device's shader-clock
+    and 100 MHz counters.  MI355X: 2.4 GHz peak, 2.1-2.4 sustained under this stream."""
+    from sda_amd import ops
+    r = ops.clock_probe(dev, ms=2.0)
+    assert 1.2 < r['ghz_min'] <= r['ghz'] <= r['ghz_max'] < 2.6, r
+    assert r['ghz_max'] - r['ghz_min'] < 0.5, r
