@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 10
+#define SDA_ABI_VERSION 11
 
 enum {
     SDA_OK = 0,
@@ -127,6 +127,21 @@ typedef struct sda_conv_desc {
      * them.  With it the 2 x 2 up-sampled / pooled launches above run their zero-position form; without it the up-sampled launch
      * runs the full kernel (same result bit for bit) and the pooled launch is SDA_E_UNSUPPORTED. */
     const float* w_wino4_zp;
+    /* OPT-IN (ABI v11; all zero = off): the fp32 multiply emulated on the f16 matrix cores, fp32 accumulation (csrc/conv_h2.hip).
+     *   w_h2: sda_pack_conv_weight_h2's packing of the layer (every weight as two halves hi + lo of s_w w), w_h2_scale = s_w
+     *         (sda_conv_h2_scale(max |w|)).
+     *   x_amax: device scalar, max |value the loader feeds the multiply| (after modulation + LayerNorm / activation) or any upper
+     *         bound of it -- sda_absmax of the tensor, or the out_amax of the launch that produced it; NULL: x_amax_static (a bound
+     *         known on the host: sqrt(channels) behind a LayerNorm).  The kernel derives the power-of-two input scale from it.
+     *   out_amax: optional device scalar, atomically maxed (as uint bits; the caller zeroes it) with max |out| of this launch.
+     * Served by sda_conv_h2 for 3 x 3 / stride 1 / cin % 32 == 0 / cout % 96 == 0 / 16 x 16-tileable planar launches with the loader
+     * fusions none / activation / (modulation +) LayerNorm and the epilogues bias, x act'(z), + res; sda_conv_igemm ignores the
+     * fields.  Error against float64 equals the fp32 Winograd kernel's (3e-7, tools/f16_split_numerics.py). */
+    const void* w_h2;
+    float w_h2_scale;
+    float x_amax_static;
+    const float* x_amax;
+    float* out_amax;
 } sda_conv_desc;
 
 int sda_conv_igemm(const sda_conv_desc* d, void* stream);
@@ -528,6 +543,22 @@ int sda_pool3d_sum(const float* g, int64_t nc, int d, int h, int w, int fd, int 
  * bench.py runs it after the warm-up steps and reports roofline.frac next to the clock it was measured at.
  * ------------------------------------------------------------------------------------------ */
 int sda_clock_probe(unsigned long long* out, int blocks, float* sink, int iters, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * OPT-IN f16 x 2 emulation of the fp32 multiply (ABI v11; csrc/conv_h2.hip; see sda_conv_desc.w_h2).  Same layers as the
+ * w_wino4 kernel -- the block convolutions nn.Conv2d(3 x 3) of sda/nn.py:131-142 and their backward-data -- as a DIRECT
+ * convolution on v_mfma_f32_16x16x32_f16: x w ~ hi_x hi_w + hi_x lo_w + lo_x hi_w, fp32 accumulation.
+ *   sda_conv_h2: the launch (SDA_E_UNSUPPORTED outside the range above: run sda_conv_igemm); sda_conv_h2_supported: 1 / 0, no launch.
+ *   sda_pack_conv_weight_h2: torch-layout [cout][cin][3][3] -> fragments in MFMA lane order (transpose = 1: the input-VJP operator,
+ *     taps flipped, cin <-> cout), w_amax = max |w| (host); sda_conv_h2_packed_bytes: size of dst (0: shape not served).
+ *   sda_conv_h2_scale: the power of two s with s amax in [2^10, 2^11].   sda_absmax: amax[0] = max |x| (device scalar).
+ * ------------------------------------------------------------------------------------------ */
+int sda_conv_h2(const sda_conv_desc* d, void* stream);
+int sda_conv_h2_supported(const sda_conv_desc* d);
+int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int transpose, float w_amax, void* dst, void* stream);
+int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose);
+float sda_conv_h2_scale(float amax);
+int sda_absmax(const float* x, int64_t numel, float* amax, void* stream);
 
 #ifdef __cplusplus
 }

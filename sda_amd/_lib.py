@@ -54,6 +54,8 @@ class ConvDesc(Structure):
         ('w_wino4', c_fp),
         ('pool_h', ctypes.c_int32), ('pool_w', ctypes.c_int32),
         ('w_wino4_zp', c_fp),
+        ('w_h2', ctypes.c_void_p), ('w_h2_scale', ctypes.c_float), ('x_amax_static', ctypes.c_float),
+        ('x_amax', c_fp), ('out_amax', c_fp),
     ]
 
 
@@ -225,6 +227,12 @@ SIGNATURES = {
     'sda_pc_correct': (c_int, [c_fp, c_fp, c_fp, c_int, c_int64, c_fp, c_int, c_float, c_float, c_fp, c_void_p]),
     'sda_randn_rows': (c_int, [c_fp, c_int, c_int64, c_uint64, c_int64, c_int64, c_fp, c_int64, c_int64, c_void_p]),
     'sda_clock_probe': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'sda_conv_h2': (c_int, [POINTER(ConvDesc), c_void_p]),
+    'sda_conv_h2_supported': (c_int, [POINTER(ConvDesc)]),
+    'sda_pack_conv_weight_h2': (c_int, [c_fp, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'sda_conv_h2_packed_bytes': (c_int64, [c_int, c_int, c_int]),
+    'sda_conv_h2_scale': (c_float, [c_float]),
+    'sda_absmax': (c_int, [c_fp, c_int64, c_fp, c_void_p]),
     'sda_philox_words': (c_int, [c_fp, c_int64, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
     'sda_denoise': (c_int, [c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),
     'sda_guided_combine': (c_int, [c_fp, c_fp, c_fp, c_int64, c_float, c_float, c_fp, c_fp, c_void_p]),

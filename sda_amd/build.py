@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.environ.get('SDA_LIBDIR') or os.path.join(HERE, 'lib')      # (SDA_LIBDIR: tooling builds beside the product one)
 ARCH = 'gfx950'
-SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_small1d.hip', 'conv_few.hip', 'conv_par4.hip', 'conv3d.hip', 'block1d.hip', 'net1d.hip', 'step1d.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'mlp1d.hip', 'observe.hip', 'metrics.hip', 'noise.hip', 'probe.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_small1d.hip', 'conv_few.hip', 'conv_par4.hip', 'conv_h2.hip', 'conv3d.hip', 'block1d.hip', 'net1d.hip', 'step1d.hip', 'norm.hip', 'elementwise.hip', 'linear.hip', 'mlp1d.hip', 'observe.hip', 'metrics.hip', 'noise.hip', 'probe.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # extra compile flags (e.g. SDA_EXTRA_HIPCC_FLAGS=-DSDA_W4_VARIANTS builds the tuning variants tools/wino4_check.py compares)
 EXTRA_FLAGS = os.environ.get('SDA_EXTRA_HIPCC_FLAGS', '').split()

@@ -21,6 +21,7 @@ The image axis is processed in chunks sized from free HBM (288 GB on MI355X); wh
 images than can keep their activations resident, the forward is recomputed chunk by chunk inside the backward
 ("activation memory under guidance").
 """
+import math
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -173,7 +174,7 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                 zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
                 ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
                 ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None, parity4_w: Optional[Tensor] = None,
-                pool=(1, 1)):
+                pool=(1, 1), x_amax=None, out_amax: Optional[Tensor] = None):
     """pool != (1, 1): `out` is the pooled tensor [n][cout][ho / pool_h][wo / pool_w] (cell sums; sda_conv_desc.pool_h / pool_w);
     returns None when no kernel serves the pooled form (the caller runs the plain launch and pools in its reader)."""
     out_strides = (0, 0, 0, 0)
@@ -199,6 +200,12 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        pad=pad, out_strides=out_strides, pool=pool, w_wino4_zp_ptr=None if zp is None else zp.data_ptr())
     if pool != (1, 1):
         return d if ops.conv_pooled(d) else None
+    if getattr(pk, 'h2', None) is not None and parity4_w is None:
+        # OPT-IN f16 x 2 multiply (ops.MULTIPLY): behind a LayerNorm the loader's output is bounded by sqrt(channels); otherwise the
+        # caller says how large the input is (the producing launch's out_amax, or an ops.absmax pass)
+        bound = math.sqrt(src['cx']) if ln is not None else x_amax
+        if ops.conv_h2(d, pk, bound, out_amax):
+            return d
     if parity4_w is not None:
         # all four parity classes of a stride-2 VJP in one launch: the class-(0,0) descriptor with the concatenated packing
         d.w = parity4_w.data_ptr()
@@ -498,12 +505,13 @@ class UNetEngine:
         ops.ln_stats(a, mod, mod_sn, blk.ln.eps, self.unbiased, mean, rstd)
         z = torch.empty_like(a)
         pk = c1.fwd()
+        z_amax = getattr(pk, 'out_amax', None)           # (f16 x 2 launches report max |z|: |act(z)| <= max(|z|, 0.28) scales conv2's input)
         launch_conv(pk, planar_source(a), z, h, w, circular=c1.circular, bias=pk.bias, mod=mod, mod_sn=mod_sn,
-                    ln=(mean, rstd))
+                    ln=(mean, rstd), out_amax=z_amax)
         y = torch.empty_like(a)
         c2 = blk.conv2
         pk = c2.fwd()
-        launch_conv(pk, planar_source(z), y, h, w, circular=c2.circular, bias=pk.bias, act_in=blk.act, res=a)
+        launch_conv(pk, planar_source(z), y, h, w, circular=c2.circular, bias=pk.bias, act_in=blk.act, res=a, x_amax=z_amax)
         if saved is not None:
             saved.append((a, mean, rstd, z))
         return y
@@ -590,10 +598,14 @@ class UNetEngine:
             ops.block1d_bwd(g, a, z, mean, rstd, mod, mod_sn, c1.bwd(), c2.bwd(), c1.circular, blk.act, self.unbiased, gx)
             return gx
         gz = torch.empty_like(a)
-        launch_conv(c2.bwd(), planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act)
+        pk2 = c2.bwd()
+        g_amax = gz_amax = None
+        if getattr(pk2, 'h2', None) is not None and g.is_contiguous():
+            g_amax, gz_amax = ops.absmax(g, pk2.in_amax), pk2.out_amax      # (one streaming read of g: its producer is not an h2 launch)
+        launch_conv(pk2, planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act, x_amax=g_amax, out_amax=gz_amax)
         gh = torch.empty_like(a)
         c1 = blk.conv1
-        launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular)
+        launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular, x_amax=gz_amax)
         gx = torch.empty_like(a)
         ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, (1, 1), g, gx)
         return gx

@@ -4,6 +4,7 @@ Every function launches a hand-written gfx950 kernel on the CURRENT torch stream
 tensors must live on a HIP device (`_dev()` raises otherwise).
 """
 import ctypes
+import math
 import os
 from typing import Optional
 
@@ -16,6 +17,11 @@ from ._lib import ACT_IDS, ConvDesc
 CONV_CK = 8          # K-stage depth of conv_igemm (SDA_CONV_CK)
 WINOGRAD = os.environ.get('SDA_CONV_WINO', '1') != '0'      # Winograd F(2x2,3x3) for eligible 3x3 layers
 WINOGRAD4 = os.environ.get('SDA_CONV_WINO4', '1') != '0'    # ... its one-wave-per-SIMD kernel where images are multiples of 16
+#: OPT-IN: 'f16x2' = the block convolutions multiply on the f16 matrix cores with every fp32 operand split into two halves, fp32
+#: accumulation (csrc/conv_h2.hip; same 3e-7 error against float64 as the fp32 Winograd kernel).  Default 'f32': fp32 MFMAs only.
+MULTIPLY = os.environ.get('SDA_MULTIPLY', 'f32')
+if MULTIPLY not in ('f32', 'f16x2'):
+    raise ValueError(f"SDA_MULTIPLY={MULTIPLY!r} (expected 'f32' or 'f16x2')")
 
 
 def tensor_version(t) -> int:
@@ -173,6 +179,48 @@ def conv_igemm(desc: ConvDesc):
     _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
 
 
+def absmax(x: Tensor, out: Tensor) -> Tensor:
+    """out[0] = max |x| (device scalar; one streaming read of x): the input scale of an f16x2 launch whose producer did not report it."""
+    _dev(x, out)
+    if not x.is_contiguous():
+        raise _lib.SdaHipError('absmax reads a contiguous tensor')
+    _lib.check(_lib.load().sda_absmax(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), 'sda_absmax')
+    return out
+
+
+def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]) -> bool:
+    """Run the launch on the f16 x 2 kernel (csrc/conv_h2.hip) when `pk` carries that packing and the kernel serves the shape.
+    x_amax: device scalar (Tensor) or a host bound (float) on the magnitude of what the loader feeds the multiply.  False: not
+    served -- the caller runs the fp32 kernels."""
+    if getattr(pk, 'h2', None) is None or x_amax is None:
+        return False
+    lib = _lib.load()
+    desc.w_h2, desc.w_h2_scale = pk.h2.data_ptr(), pk.h2_scale
+    if torch.is_tensor(x_amax):
+        desc.x_amax, desc.x_amax_static = x_amax.data_ptr(), 0.0
+    else:
+        desc.x_amax, desc.x_amax_static = None, float(x_amax)
+    desc.out_amax = None if out_amax is None else out_amax.data_ptr()
+    if not lib.sda_conv_h2_supported(ctypes.byref(desc)):
+        desc.w_h2 = None
+        return False
+    prof = conv_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if out_amax is not None:
+        out_amax.zero_()
+    _lib.check(lib.sda_conv_h2(ctypes.byref(desc), _stream()), 'sda_conv_h2')
+    if prof is not None:
+        e1.record()
+        prof.records.append((e0, e1, prof.flops(desc), 'h2'))
+        rd, wr = prof.alg_bytes(desc)
+        b = prof.family_bytes.setdefault('h2', [0.0, 0.0])
+        b[0] += rd
+        b[1] += wr
+    return True
+
+
 PARITY4 = os.environ.get('SDA_CONV_PAR4', '1') != '0'
 
 
@@ -269,6 +317,22 @@ class PackedConv:
             self._wino4_zp = torch.empty(int(lib.sda_wino4_zp_floats(self.k_pad, self.m_pad)), device=w.device, dtype=torch.float32)
             _lib.check(lib.sda_pack_conv_weight_wino4_zp(self.wino4.data_ptr(), self.k_pad, self.m_pad, self._wino4_zp.data_ptr(), _stream()),
                        'sda_pack_conv_weight_wino4_zp')
+
+        # ... and, OPT-IN (ops.MULTIPLY == 'f16x2'), the two-halves packing of csrc/conv_h2.hip with its scale (max |w| is read back
+        # once, here -- packing happens in warm-up, never under graph capture) and the device scalars its launches report through
+        self.h2 = None
+        if MULTIPLY == 'f16x2' and (self.kh, self.kw) == (3, 3) and (not transpose or keep == cin) and w.numel() > 0:
+            lib = _lib.load()
+            nbytes = int(lib.sda_conv_h2_packed_bytes(cout, cin, int(transpose)))
+            if nbytes > 0:
+                w_amax = float(w.abs().max())
+                if w_amax > 0.0 and math.isfinite(w_amax):
+                    self.h2 = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+                    _lib.check(lib.sda_pack_conv_weight_h2(w.data_ptr(), cout, cin, int(transpose), w_amax, self.h2.data_ptr(), _stream()),
+                               'sda_pack_conv_weight_h2')
+                    self.h2_scale = float(lib.sda_conv_h2_scale(w_amax))
+                    self.out_amax = torch.zeros(1, device=w.device, dtype=torch.float32)     # max |out| of this layer's last launch
+                    self.in_amax = torch.zeros(1, device=w.device, dtype=torch.float32)      # scratch for an absmax pass over its input
 
     def wino4_zp(self) -> Optional[Tensor]:
         """The zero-position packing of `wino4` (None without it): what the up-sampling tails (sda/nn.py:161-169 of the reference) and

@@ -95,6 +95,9 @@ def test_k64_free_running_guided_hipgraph_vs_oracle(dev, k64, batch):
           f'HIP vs fp32 oracle {err32:.2e}, fp32 oracle vs fp64 oracle {own:.2e}')
     assert own < 2e-3, (f'the oracle disagrees with itself across precisions by {own:.2e} on this chain: too ill-conditioned for a '
                         f'free-running parity test to mean anything -- shorten it instead of widening the bound')
+    # north_star's own bar, not elastic: the HIP path against the fp32 reference arithmetic from the same draws, rtol 1e-4 (measured
+    # 2e-5 after 64 guided evaluations: the two fp32 chains stay together although each is 2e-4 from the fp64 one)
+    assert err32 <= 1e-4, f'{steps}-step free-running guided sample: HIP path vs the fp32 oracle {err32:.2e} > 1e-4'
     assert err <= max(1e-4, 3 * own), (f'{steps}-step free-running guided sample: HIP path vs fp64 oracle {err:.2e}; the fp32 oracle itself '
                                        f'is {own:.2e} from the fp64 oracle (bound: max(1e-4, 3x that))')
 
