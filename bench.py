@@ -245,6 +245,7 @@ def _cpu_model():
 
 
 PEAK_MFMA_F32 = 157.3      # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_MFMA_F16 = 2500.0     # TFLOP/s, dense f16 / bf16 MFMA (same guide; the 5 PFLOP/s headline figure includes 2:1 sparsity)
 PEAK_HBM = 8000.0          # GB/s
 
 
@@ -256,10 +257,11 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
     for name, r in s['families'].items():
         alg = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
         # (zero-position form of conv_wino4: 54 of the 96 multiplies of a Winograd stage are issued)
-        issued = alg / 4.0 if name == 'wino4zp' else alg / 2.25 if name.startswith('wino') else alg
+        # (f16 x 2 direct convolution: three f16 MFMA products per multiply, priced against the f16 matrix peak)
+        issued = alg / 4.0 if name == 'wino4zp' else alg / 2.25 if name.startswith('wino') else 3.0 * alg if name == 'h2' else alg
         fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
                      'share_of_step': r['ms'] * 1e-3 / prof_steps / step_s,
-                     'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / PEAK_MFMA_F32,
+                     'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / (PEAK_MFMA_F16 if name == 'h2' else PEAK_MFMA_F32),
                      'avg_launch_ms': r['ms'] / max(1, r['launches']),
                      'avg_launch_gflop_algorithmic': r['flops'] / max(1, r['launches']) / 1e9}
         if name in prof.family_bytes:
@@ -274,13 +276,15 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
     conv = {k: v for k, v in fam.items() if 'issued_mfma_tflops' in v}
     dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
     traffic, tfile, tracked = None, None, {}
+    suffix = '' if args.multiply == 'f32' else '_' + args.multiply
     for rnd in ('r05', 'r04', 'r03', 'r02'):      # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-        tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}_traffic.json')
+        tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}{suffix}_traffic.json')
         if os.path.exists(tfile):
             tracked = json.load(open(tfile))
             traffic = tracked.get('hbm_bytes_per_launch')
             break
-    kernel = {'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
+    kernel = {'h2': 'conv_h2_kernel (direct 3x3, fp32 multiply emulated as three f16 products, v_mfma_f32_32x32x16_f16)',
+              'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
               'wino4zp': 'conv_wino4_kernel, zero-position form (up-sampling tails and their VJP: 9 of 16 Winograd positions)',
               'wino': 'conv_wino_kernel (Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)',
               'direct': 'conv_igemm_ws_kernel (direct implicit GEMM, v_mfma_f32_32x32x2_f32)',
@@ -319,7 +323,7 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
                    'step_us': step_s * 1e6, 'launch_floor_us': 1.7,
                    'floor_us_per_step_bracketed_kernels': 1.7 * n_launch}
     return {'bound': 'latency' if latency else 'mfma', 'latency': latency,
-            'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+            'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F16 if dom == 'h2' else PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': d.get('mfma_util'), 'clock': clock, 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
             'traffic_is': 'HBM/fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE '
@@ -517,6 +521,9 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help="weak: every rank owns a configuration shard (N = 8 is the configuration itself); strong: the 8-shard global batch is split over the ranks")
     ap.add_argument('--lorenz-net', default='global', choices=['global', 'local'], help='lorenz_eval: the score network (lorenz/utils.py:26-59)')
     ap.add_argument('--lorenz-freq', default='lo', choices=['lo', 'hi'], help='lorenz_eval: observation setting (eval.py:50-53)')
+    ap.add_argument('--multiply', default='f32', choices=['f32', 'f16x2'],
+                    help="f32 (default, the headline): fp32 MFMAs.  f16x2 (OPT-IN second line): the block convolutions multiply on the f16 matrix "
+                         "cores, every fp32 operand as two halves, three products, fp32 accumulation (csrc/conv_h2.hip)")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -548,6 +555,7 @@ def main():
 
     from sda_amd import ops, parallel
     from sda_amd.score import GaussianScore, VPSDE
+    ops.set_multiply(args.multiply)
 
     if args.workload == 'lorenz_eval':
         if world != 1:
@@ -638,7 +646,9 @@ def main():
                       '16-trajectory per-GPU shard)' if args.workload == 'kolmogorov256' else f'diffusion-steps/s ({args.workload})',
             'value': value, 'unit': 'diffusion-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (random-init net + exact Gaussian term, synthetic observations)',
+            'dtype': 'f32' if args.multiply == 'f32' else 'f32 emulated as 2 x f16 (three f16 products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulate; OPT-IN, not the headline)',
+            'multiply': args.multiply,
+            'data': 'synthetic (random-init net + exact Gaussian term, synthetic observations)',
             'config': {'workload': args.workload, 'description': wl['desc'], 'event': list(event),
                        'per_gpu_batch': b, 'global_batch': global_batch, 'guided': bool(args.guided),
                        'corrections': args.corrections, 'tau': args.tau, 'schedule_steps': 1000,

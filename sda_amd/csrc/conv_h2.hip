@@ -8,38 +8,46 @@
 // that puts max |x| at 2^11, so that hi never overflows and the low piece's fp16 subnormal spacing, 2^-24, is 2^-35 of the tensor's
 // scale): 22 significand bits in 4 bytes -- the operand bytes of fp32.  A product of two halves is exact in fp32, and
 //     x w  ~  hi_x hi_w + hi_x lo_w + lo_x hi_w          (dropped: lo_x lo_w, relative 2^-22)
-// is three v_mfma_f32_16x16x32_f16 per 16 couts x 16 pixels x 32 channels where the fp32 pipe needs eight v_mfma_f32_16x16x4_f32: at the
-// measured issue rates (17 against 32 cycles per instruction and SIMD, MI355X_MICROARCH.md) 51 cycles against 256.  That is 5x per
-// multiply -- more than Winograd F(2x2,3x3) saves (2.25x), so this kernel is a DIRECT convolution: no transforms, no transform-domain
-// round-off, no helper-wave arithmetic.  Measured against float64 (tools/f16_split_numerics.py): the same 3e-7 relative error as the
+// is three v_mfma_f32_32x32x16_f16 (32 cycles each from one wave) per 32 couts x 32 pixels x 16 channels where the fp32 pipe needs sixteen
+// v_mfma_f32_16x16x4_f32 (32 cycles each): 96 cycles against 512, 5.3x per multiply -- more than Winograd F(2x2,3x3) saves (2.25x), so this
+// kernel is a DIRECT convolution: no transforms, no transform-domain round-off, no helper-wave arithmetic.  (The 16x16x32 shape issues
+// only every 25 cycles from a single wave -- profiles/r04_bf16x6_prototype.txt, and this kernel's first version: 28 per MFMA.)  Measured against float64 (tools/f16_split_numerics.py): the same 3e-7 relative error as the
 // fp32 Winograd kernel.
 //
 // Structure (one workgroup = 4 waves, one per SIMD, up to 512 registers each; tile = 96 couts x 16 x 16 pixels of one image):
 //   * K loop over chunks of 32 input channels.  The chunk's 18 x 18 halo tile lives in LDS as [pixel][hi: 32 halves | lo: 32 halves]
-//     (+ 32 B pad: 160 B per pixel makes the ds_read_b128 of 16 consecutive pixels conflict-free), double buffered, ONE barrier per
+//     (+ 32 B pad per pixel and 16 B per halo row: the ds_read_b128 of a 2 x 16-pixel fragment is conflict-free), double buffered, ONE barrier per
 //     chunk.  Every wave fills its quarter of the next chunk's tile while it multiplies the current one: wave w owns channels 8 w .. 8 w + 7
 //     -- global loads (padding / wrap resolved once per tile), the loader fusions of the reference's blocks (time modulation +
 //     LayerNorm, or the activation; sda/nn.py:28,137-139), the split, two 16-byte LDS stores per pixel.  The f16 MFMA leaves three
 //     issue slots per instruction free, and the loader needs ~330 of a chunk's ~1 900.
-//   * per tap and chunk a wave multiplies 6 cout fragments x 4 pixel rows x 3 products = 72 MFMAs.  B: eight ds_read_b128 (the tap is
-//     a pixel offset into the halo tile).  A: twelve global_load_dwordx4 straight from the packed weights (sda_pack_conv_weight_h2:
-//     fragments in lane order, 12 KiB per tap and chunk, the same addresses in all four waves -- L1 hits for three of them), one tap
-//     ahead.
+//   * per tap and chunk a wave multiplies 2 K steps x 3 cout fragments x 2 pixel fragments (two tile rows each) x 3 products = 36
+//     MFMAs.  B: eight ds_read_b128 (the tap is a pixel offset into the halo tile).  A: the tap's 12 KiB of packed weights
+//     (sda_pack_conv_weight_h2: fragments in lane order) go through a two-slot LDS ring -- every wave fetches a quarter (three
+//     global_load_dwordx4, three taps ahead) and stores it two taps ahead, one barrier per tap, twelve ds_read_b128 per wave one tap
+//     ahead.  (First version: every wave fetched all twelve fragments itself -- 4 x the L1 traffic, and the kernel ran as slowly with
+//     its MFMAs removed: profiles/r05_h2_ablation.txt.)
 //   * epilogue: x 1 / (s_x s_w), + bias, x act'(z) or + residual, 64-byte row segments; optionally max |out| (one atomic per wave)
 //     so that the NEXT h2 launch knows its input scale without a pass over the tensor.
 // Roofline: f16 matrix pipe (2.5 PFLOP/s dense / 3 products); algorithmic bytes: x once per 96-cout tile x 1.27 (halo), out once.
 #include "sda_common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef _Float16 h2_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
 typedef float h2_f4 __attribute__((ext_vector_type(4)));
+typedef float h2_f16v __attribute__((ext_vector_type(16)));
 
 #define H2_TS 16                       // tile side (pixels)
 #define H2_HS (H2_TS + 2)              // halo side
 #define H2_NPX (H2_HS * H2_HS)         // 324 halo pixels
 #define H2_PXB 160                     // bytes per halo pixel in LDS: 64 hi + 64 lo + 32 pad
-#define H2_TILE (H2_NPX * H2_PXB)      // 51 840 B
+#define H2_ROWB (H2_HS * H2_PXB + 16)   // 2 896 B per halo row (row pad: the two rows of a 32-pixel fragment land on different bank quads)
+#define H2_DUMMY (H2_HS * H2_ROWB)      // 52 128: where loader lanes without a pixel (slots 324 .. 383) store -- never read
+#define H2_TILE (H2_DUMMY + 64 * H2_PXB) // 62 368 B
+#define H2_ASLOT (12 * 64 * 16)         // 12 288 B: one tap's weight fragments
+#define H2_LDS (2 * H2_TILE + 2 * H2_ASLOT)
 #define H2_CK 32                       // channels per chunk
 #define H2_BM 96                       // couts per workgroup
 #define H2_RND ((H2_NPX + 63) / 64)    // 6 loader rounds per wave and chunk
@@ -66,7 +74,9 @@ struct h2_args {
     int tiles_x, tiles_y, n_ct, nchunk;
 };
 
-template <int LOADER>           // 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
+// ABL (tooling builds, -DSDA_H2_ABLATE + $SDA_H2_ABL; results WRONG): 1 no weight loads in the loop, 2 no loader in the loop, 4 no MFMAs,
+// 8 no epilogue stores -- what each costs, measured by leaving it out (tools/h2_check.py --ablate)
+template <int LOADER, int ABL = 0>           // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
 __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
 
     // ---- loader plan of this lane (the same for every chunk): halo pixel p = lane + 64 r, channels 8 wave .. + 7 of the chunk
     const float* ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)(8 * wave) * d.x_sc;
-    int goff[H2_RND];
+    int goff[H2_RND], lds_wr[H2_RND];
     unsigned valid = 0;
     float mean[H2_RND], rstd[H2_RND];
 #pragma unroll
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
         y = ok ? y : 0;
         x = ok ? x : 0;
         goff[r] = y * (int)d.x_sy + x * (int)d.x_sx;
+        lds_wr[r] = (p < H2_NPX ? hy * H2_ROWB + hx * H2_PXB : H2_DUMMY + lane * H2_PXB) + wave * 16;     // (+ 64: the low piece)
         valid |= ok ? (1u << r) : 0u;
         if (LOADER == 2) {
             const int64_t sp = (int64_t)n * d.hs * d.ws + (int64_t)y * d.ws + x;
@@ -113,9 +124,8 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
         }
     }
     const float* modp = (LOADER == 2 && d.mod) ? d.mod + (int64_t)n * d.mod_sn + 8 * wave : nullptr;
-    const int lds_wr = lane * H2_PXB + wave * 16;                   // + 64 r * H2_PXB; + 64 for the low piece
 
-    float raw[2][8];                                                // two rounds in flight
+    float raw[2][H2_RND][8];                                        // the loader's values of two chunks: requested a whole chunk ahead
     auto load_round = [&](int chunk, int r, float (&v)[8]) {
         const float* src = ximg + (int64_t)chunk * H2_CK * d.x_sc + goff[r];
 #pragma unroll
@@ -131,125 +141,241 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
                 if (modp) u += modp[chunk * H2_CK + i];
                 u = (u - mean[r]) * rstd[r];
             }
-            if (LOADER == 1) u = sda_act(d.act_in, u);
+            if (LOADER == 1) u = u * sda_sigmoid(u);                 // (SiLU: the launcher admits no other activation here)
             u = ok ? u * sx : 0.f;
             const _Float16 h = (_Float16)u;
             hi[i] = h;
             lo[i] = (_Float16)(u - (float)h);
         }
-        if (lane + 64 * r < H2_NPX) {
-            *reinterpret_cast<h2_h8*>(buf + lds_wr + 64 * r * H2_PXB) = hi;
-            *reinterpret_cast<h2_h8*>(buf + lds_wr + 64 * r * H2_PXB + 64) = lo;
-        }
+        *reinterpret_cast<h2_h8*>(buf + lds_wr[r]) = hi;            // (no branch: a conditional store would split the tap's
+        *reinterpret_cast<h2_h8*>(buf + lds_wr[r] + 64) = lo;       //  scheduling region)
     };
 
-    // ---- consumer addressing.  B fragment j of tap (dy, dx): pixels (4 wave + j + dy) * 18 + dx + (lane & 15), channels 8 (lane >> 4) ..
-    const int b_rd = ((4 * wave) * H2_HS + (lane & 15)) * H2_PXB + (lane >> 4) * 16;
-    // A: [cout tile][chunk][tap][m][piece][lane] x 16 B
-    const h2_h8* wq = reinterpret_cast<const h2_h8*>(a.w) + (int64_t)ct * a.nchunk * (9 * 6 * 2 * 64) + lane;
+    // ---- consumer addressing.  B fragment f of tap (dy, dx), K step ks: pixel rows 4 wave + 2 f + ((lane & 31) >> 4) + dy, columns
+    // dx + (lane & 15), channels 16 ks + 8 (lane >> 5) ..
+    const int b_rd = (4 * wave + ((lane & 31) >> 4)) * H2_ROWB + (lane & 15) * H2_PXB + (lane >> 5) * 16;
+    // A: [cout tile][chunk][tap][ks][m][piece][lane] x 16 B
+    const h2_h8* wq = reinterpret_cast<const h2_h8*>(a.w) + (int64_t)ct * a.nchunk * (9 * 2 * 3 * 2 * 64) + lane;
 
-    h2_f4 acc[6][4];
+    h2_f16v acc[3][2];
 #pragma unroll
-    for (int m = 0; m < 6; ++m)
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[m][j] = h2_f4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
 
-    // ---- prologue: chunk 0 into buffer 0
+    // ---- prologue: chunk 0 into buffer 0 (all its requests in flight together), chunk 1 requested
 #pragma unroll
-    for (int r = 0; r < H2_RND; ++r) {
-        load_round(0, r, raw[0]);
-        store_round(0, r, raw[0], smem);
-    }
-    h2_h8 A[2][6][2], B[2][4][2];
-    auto load_A = [&](int chunk, int tap, h2_h8 (&dst)[6][2]) {
-        const h2_h8* p = wq + (int64_t)(chunk * 9 + tap) * (6 * 2 * 64);
+    for (int r = 0; r < H2_RND; ++r) load_round(0, r, raw[0][r]);
+    const int c1 = a.nchunk > 1 ? 1 : 0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            dst[m][0] = p[(m * 2 + 0) * 64];
-            dst[m][1] = p[(m * 2 + 1) * 64];
-        }
+    for (int r = 0; r < H2_RND; ++r) load_round(c1, r, raw[1][r]);
+    h2_h8 A[2][2][3][2], B[2][2][2][2];                             // [set][K step][fragment][piece]
+    // weights: global tap g = 9 chunk + tap; its 12 fragments are contiguous in the packing.  This wave's quarter: fragments 3 wave + j.
+    unsigned char* aring = smem + 2 * H2_TILE;
+    const int gtaps = 9 * a.nchunk;
+    h2_h8 aq[3];
+    auto fetch_A = [&](int g) {                                     // global -> registers (quarter)
+        const h2_h8* p = wq + (int64_t)(g < gtaps ? g : gtaps - 1) * (12 * 64) + 3 * wave * 64;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) aq[j] = p[j * 64];
     };
-    auto load_B = [&](const unsigned char* buf, int tap, h2_h8 (&dst)[4][2]) {
+    auto stash_A = [&](int slot) {                                  // registers -> ring slot (quarter)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<h2_h8*>(aring + slot * H2_ASLOT + (3 * wave + j) * 1024 + lane * 16) = aq[j];
+    };
+    auto load_A = [&](int slot, h2_h8 (&dst)[2][3][2]) {           // ring slot -> operand registers (all twelve)
+        const unsigned char* p = aring + slot * H2_ASLOT + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                dst[ks][m][0] = *reinterpret_cast<const h2_h8*>(p + ((ks * 3 + m) * 2 + 0) * 1024);
+                dst[ks][m][1] = *reinterpret_cast<const h2_h8*>(p + ((ks * 3 + m) * 2 + 1) * 1024);
+            }
+    };
+    auto load_B = [&](const unsigned char* buf, int tap, h2_h8 (&dst)[2][2][2]) {
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const unsigned char* p = buf + b_rd + (dy * H2_HS + dx) * H2_PXB;
+        const unsigned char* p = buf + b_rd + dy * H2_ROWB + dx * H2_PXB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dst[j][0] = *reinterpret_cast<const h2_h8*>(p + j * H2_HS * H2_PXB);
-            dst[j][1] = *reinterpret_cast<const h2_h8*>(p + j * H2_HS * H2_PXB + 64);
-        }
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                dst[ks][f][0] = *reinterpret_cast<const h2_h8*>(p + 2 * f * H2_ROWB + ks * 32);
+                dst[ks][f][1] = *reinterpret_cast<const h2_h8*>(p + 2 * f * H2_ROWB + ks * 32 + 64);
+            }
     };
-    load_A(0, 0, A[0]);
+    {
+        // (every request of the prologue is in flight before the first use: one round trip, not one per operand)
+        h2_h8 aq1[3];
+        fetch_A(0);
+        const h2_h8* p1 = wq + (int64_t)(gtaps > 1 ? 1 : 0) * (12 * 64) + 3 * wave * 64;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) aq1[j] = p1[j * 64];
+        stash_A(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<h2_h8*>(aring + H2_ASLOT + (3 * wave + j) * 1024 + lane * 16) = aq1[j];
+    }
+#pragma unroll
+    for (int r = 0; r < H2_RND; ++r) store_round(0, r, raw[0][r], smem);
+    fetch_A(2);
     __syncthreads();
+    load_A(0, A[0]);
+    __syncthreads();                                               // (slot 0 is read: tap 0 may overwrite it with tap 2's weights)
 
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    // One chunk = nine taps; P = the operand set tap 0 multiplies with (the sets alternate per tap, so a chunk that starts on set 0
+    // hands over on set 1: the chunk loop below runs in pairs and every index stays a compile-time constant -- no register moves).
+    // The instruction order of a tap is pinned (sched_group_barrier): left alone, the scheduler sinks the next tap's loads to their
+    // first use and every tap starts with an exposed L2 round trip (measured: 3 000 cycles per tap instead of 1 250).
+    auto chunk_body = [&](auto parity, int chunk) {
+        constexpr int P = decltype(parity)::value;
         const unsigned char* cur = smem + (chunk & 1) * H2_TILE;
         unsigned char* nxt = smem + ((chunk + 1) & 1) * H2_TILE;
-        const int cn = chunk + 1 < a.nchunk ? chunk + 1 : chunk;       // (last chunk: reloads itself into the idle buffer; branch-free)
-        load_B(cur, 0, B[0]);
+        // (past the last chunk the loader re-requests / re-stores that chunk into the idle buffer: branch-free)
+        const int cn = chunk + 1 < a.nchunk ? chunk + 1 : chunk, cnn = chunk + 2 < a.nchunk ? chunk + 2 : a.nchunk - 1;
+        load_B(cur, 0, B[P]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int s = tap & 1;
-            // operands of the next tap (the first tap of the next chunk: A only -- its B tile is complete after the barrier)
-            if (tap < 8) {
-                load_A(chunk, tap + 1, A[s ^ 1]);
-                load_B(cur, tap + 1, B[s ^ 1]);
-            } else {
-                load_A(cn, 0, A[s ^ 1]);
+            const int s = (P + tap) & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            // weights: tap g + 2's quarter (fetched during the previous tap) into the slot tap g's weights were read from, tap g + 3's
+            // requested, tap g + 1's twelve fragments read; B of the next tap (the first tap of the next chunk: after the barrier)
+            if (!(ABL & 1)) {
+                stash_A(s);
+                fetch_A(9 * chunk + tap + 3);
+                load_A(s ^ 1, A[s ^ 1]);
             }
-            // this wave's share of the next chunk's tile: round r is requested in tap r and stored two taps later
-            if (tap >= 2 && tap < H2_RND + 2) store_round(cn, tap - 2, raw[tap & 1], nxt);      // (consumes raw[tap & 1] first)
-            if (tap < H2_RND) load_round(cn, tap, raw[tap & 1]);
+            if (tap < 8) load_B(cur, tap + 1, B[s ^ 1]);
+            // this wave's share of the tiles ahead: tap r stores round r of the NEXT chunk (requested a whole chunk ago -- an HBM round trip
+            // under load is 2-3 us, three taps) and requests round r of the chunk after that into the set this chunk's values came from
+            if (tap < H2_RND && !(ABL & 2)) {
+                store_round(cn, tap, raw[P ^ 1][tap], nxt);
+                load_round(cnn, tap, raw[P][tap]);
+            }
             // small products first (fp32 accumulation)
 #pragma unroll
-            for (int m = 0; m < 6; ++m)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ABL & 4) {                                     // (keep the operands alive without multiplying)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][m][0], B[s][j][1], acc[m][j], 0, 0, 0);
+                    for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][ks][m][0][0] + (float)A[s][ks][m][1][0];
 #pragma unroll
-            for (int m = 0; m < 6; ++m)
+                    for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][ks][f][0][0] + (float)B[s][ks][f][1][0];
+                    continue;
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][m][1], B[s][j][0], acc[m][j], 0, 0, 0);
+                for (int m = 0; m < 3; ++m)
 #pragma unroll
-            for (int m = 0; m < 6; ++m)
+                    for (int f = 0; f < 2; ++f)
+                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][0], B[s][ks][f][1], acc[m][f], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][m][0], B[s][j][0], acc[m][j], 0, 0, 0);
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][1], B[s][ks][f][0], acc[m][f], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][0], B[s][ks][f][0], acc[m][f], 0, 0, 0);
+            }
+            // ---- the tap's issue order: 36 MFMAs (32 cycles each) with everything else threaded between them: the ring stores first (the
+            // barrier at the tap's end publishes them), the next tap's A and B reads, the requests, the loader's arithmetic riding along
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            if (tap < H2_RND) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                       // the ring slot (and, after tap 8, the next chunk's tile) is published
         }
-        __syncthreads();
-        // 9 taps: the operand set of the next chunk's tap 0 is A[1]; keep the parity bookkeeping static
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            A[0][m][0] = A[1][m][0];
-            A[0][m][1] = A[1][m][1];
+    };
+    {
+        int chunk = 0;
+        for (; chunk + 1 < a.nchunk; chunk += 2) {
+            chunk_body(std::integral_constant<int, 0>{}, chunk);
+            chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
         }
+        if (chunk < a.nchunk) chunk_body(std::integral_constant<int, 0>{}, chunk);
     }
 
-    // ---- epilogue.  acc[m][j][r]: cout co0 + 16 m + 4 (lane >> 4) + r, pixel (oy0 + 4 wave + j, ox0 + (lane & 15))
+    // ---- epilogue.  acc[m][f][r]: cout co0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel row oy0 + 4 wave + 2 f + ((lane & 31) >> 4),
+    // column ox0 + (lane & 15)
     const float inv = 1.0f / (sx * a.w_scale);
     const int64_t osn = (int64_t)d.cout * d.ho * d.wo, osc = (int64_t)d.ho * d.wo;
-    const int64_t obase = (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 4)) * osc + (int64_t)(oy0 + 4 * wave) * d.wo + ox0 + (lane & 15);
+    const int64_t obase = (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + ((lane & 31) >> 4)) * d.wo + ox0 + (lane & 15);
     float amax = 0.f;
+    // (the epilogue's mode is decided ONCE, by uniform branches around three straight-line copies: tested per element the
+    //  compiler emits a branch per store.)  Every operand of the tile is requested before the first store: one round trip.
+    auto epilogue = [&](auto mode, auto with_bias) {
+        constexpr int EPI = decltype(mode)::value;                 // 0 none, 1 x act'(z), 2 + res
+        constexpr bool BIAS = decltype(with_bias)::value;
+        float bias[3][16], opnd[3][2][16];
+        const float* op = EPI == 1 ? d.dact_z : d.res;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        float bias[4];
+        for (int m = 0; m < 3; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = d.bias ? d.bias[co0 + 16 * m + 4 * (lane >> 4) + r] : 0.f;
-        float opnd[4][4];
-        const float* op = d.dact_z ? d.dact_z : d.res;
-        if (op) {
+            for (int r = 0; r < 16; ++r) bias[m][r] = BIAS ? d.bias[co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
+            if (EPI != 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) opnd[j][r] = op[obase + (int64_t)(16 * m + r) * osc + (int64_t)j * d.wo];
+                    for (int r = 0; r < 16; ++r)
+                        opnd[m][f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo];
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < 3; ++m) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[m][j][r] * inv + bias[r];
-                if (d.dact_z) v *= sda_dact(d.act_d, opnd[j][r]);
-                else if (d.res) v += opnd[j][r];
-                amax = fmaxf(amax, fabsf(v));
-                d.out[obase + (int64_t)(16 * m + r) * osc + (int64_t)j * d.wo] = v;
-            }
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][f][r] * inv + bias[m][r];
+                    if (EPI == 1) v *= sda_dact(SDA_ACT_SILU, opnd[m][f][r]);
+                    if (EPI == 2) v += opnd[m][f][r];
+                    amax = fmaxf(amax, fabsf(v));
+                    if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo] = v;
+                }
+        }
+    };
+    using h2_c0 = std::integral_constant<int, 0>;
+    using h2_c1 = std::integral_constant<int, 1>;
+    using h2_c2 = std::integral_constant<int, 2>;
+    if (d.dact_z) {
+        if (d.bias) epilogue(h2_c1{}, std::true_type{}); else epilogue(h2_c1{}, std::false_type{});
+    } else if (d.res) {
+        if (d.bias) epilogue(h2_c2{}, std::true_type{}); else epilogue(h2_c2{}, std::false_type{});
+    } else {
+        if (d.bias) epilogue(h2_c0{}, std::true_type{}); else epilogue(h2_c0{}, std::false_type{});
     }
     if (a.out_amax) {
 #pragma unroll
@@ -259,10 +385,10 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight packing
-// dst (16-byte units): ((((ct * nchunk + chunk) * 9 + tap) * 6 + m) * 2 + piece) * 64 + lane  ->  8 halves:
-//   forward  (transpose = 0): W[co = 96 ct + 16 m + (lane & 15)][ci = 32 chunk + 8 (lane >> 4) + i][tap]
+// dst (16-byte units): (((((ct * nchunk + chunk) * 9 + tap) * 2 + ks) * 3 + m) * 2 + piece) * 64 + lane  ->  8 halves:
+//   forward  (transpose = 0): W[co = 96 ct + 32 m + (lane & 31)][ci = 32 chunk + 16 ks + 8 (lane >> 5) + i][tap]
 //   backward (transpose = 1): the operator of the input VJP -- its "cout" is the forward cin and vice versa, taps flipped:
-//                             W[co = 32 chunk + 8 (lane >> 4) + i][ci = 96 ct + 16 m + (lane & 15)][8 - tap]
+//                             W[co = 32 chunk + 16 ks + 8 (lane >> 5) + i][ci = 96 ct + 32 m + (lane & 31)][8 - tap]
 __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, int transpose, float scale, h2_h8* __restrict__ dst,
                                int64_t units) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,17 +396,18 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
     const int lane = (int)(u & 63);
     int64_t t = u >> 6;
     const int piece = (int)(t & 1); t >>= 1;
-    const int m = (int)(t % 6); t /= 6;
+    const int m = (int)(t % 3); t /= 3;
+    const int ks = (int)(t & 1); t >>= 1;
     const int tap = (int)(t % 9); t /= 9;
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;     // operator rows / contraction
     const int nchunk = K / H2_CK;
     const int chunk = (int)(t % nchunk);
     const int ct = (int)(t / nchunk);
-    const int row = H2_BM * ct + 16 * m + (lane & 15);
+    const int row = H2_BM * ct + 32 * m + (lane & 31);
     h2_h8 out;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int k = H2_CK * chunk + 8 * (lane >> 4) + i;
+        const int k = H2_CK * chunk + 16 * ks + 8 * (lane >> 5) + i;
         float v = 0.f;
         if (row < M) {
             const int co = transpose ? k : row, ci = transpose ? row : k, tp = transpose ? 8 - tap : tap;
@@ -295,7 +422,7 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
 extern "C" int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose) {
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;
     if (M <= 0 || K <= 0 || M % H2_BM || K % H2_CK) return 0;
-    return (int64_t)(M / H2_BM) * (K / H2_CK) * 9 * 6 * 2 * 64 * 16;
+    return (int64_t)(M / H2_BM) * (K / H2_CK) * 9 * 2 * 3 * 2 * 64 * 16;
 }
 
 extern "C" float sda_conv_h2_scale(float amax) { return h2_scale_of(amax); }
@@ -313,7 +440,16 @@ extern "C" int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int tr
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ amax) {
     float m = 0.f;
     const h2_f4* x4 = reinterpret_cast<const h2_f4*>(x);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {                 // four 16-byte requests in flight per lane
+        h2_f4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(x4 + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(fmaxf(m, fabsf(v[k][0])), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3])));
+    }
+    for (; i < n4; i += stride) {
         const h2_f4 v = __builtin_nontemporal_load(x4 + i);
         m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
@@ -329,7 +465,7 @@ extern "C" int sda_absmax(const float* x, int64_t numel, float* amax, void* stre
     if (e != hipSuccess) return (int)e;
     const int64_t n4 = numel / 4;
     const int64_t want = (n4 + 255) / 256;
-    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, numel, amax);
     return sda_launch_status();
 }
@@ -346,6 +482,8 @@ static bool h2_ok(const sda_conv_desc* d) {
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return false;
     if (d->mod && !d->ln_mean) return false;
     if (d->ln_mean && d->act_in != SDA_ACT_NONE) return false;
+    if (d->act_in != SDA_ACT_NONE && d->act_in != SDA_ACT_SILU) return false;
+    if (d->dact_z && d->act_d != SDA_ACT_SILU) return false;
     if (d->dact_z && d->res) return false;
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 ||
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
@@ -369,9 +507,23 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.n_ct = d->cout / H2_BM;
     a.nchunk = d->cx / H2_CK;
     if (!(a.w_scale > 0.f) || (!a.x_amax && !(a.x_amax_static > 0.f))) return SDA_E_BADARG;
-    const int lds = 2 * H2_TILE;
+    const int lds = H2_LDS;
     const unsigned grid = (unsigned)((int64_t)d->n * a.tiles_x * a.tiles_y * a.n_ct);
-    int rc;
+    int rc = SDA_OK;
+#ifdef SDA_H2_ABLATE
+    {
+        static const int abl = getenv("SDA_H2_ABL") ? atoi(getenv("SDA_H2_ABL")) : 0;
+        static bool seta[16][SDA_MAX_DEVICES];
+        const void* fn = nullptr;
+#define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, v>); \
+            if (!d->ln_mean && d->act_in == SDA_ACT_NONE) { if ((rc = sda_raise_dyn_lds(fn, lds, seta[v])) != SDA_OK) return rc; \
+                hipLaunchKernelGGL((conv_h2_kernel<0, v>), dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
+        switch (abl) {
+            H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(15)
+            default: break;
+        }
+    }
+#endif
     if (d->ln_mean) {
         static bool set2[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2>), lds, set2)) != SDA_OK) return rc;

@@ -104,7 +104,8 @@ class _ConvCache:
         # (data_ptr, _version) catches optimiser steps, .to(), load_state_dict and in-place ops on the parameter; writes
         # through `.data` (EMA swaps: p.data.copy_(ema)) bump neither -- those callers use UNet.invalidate_engine()
         w = self.conv.weight
-        key = (w.data_ptr(), ops.tensor_version(w), str(w.device), None if self.conv.bias is None else ops.tensor_version(self.conv.bias))
+        key = (w.data_ptr(), ops.tensor_version(w), str(w.device), None if self.conv.bias is None else ops.tensor_version(self.conv.bias),
+               ops.MULTIPLY)                            # (switching the multiply re-packs: the f16 x 2 packing is made with the others)
         if key != self._key:
             self._key, self._fwd, self._bwd, self._parity = key, None, {}, None
 
@@ -506,8 +507,10 @@ class UNetEngine:
         z = torch.empty_like(a)
         pk = c1.fwd()
         z_amax = getattr(pk, 'out_amax', None)           # (f16 x 2 launches report max |z|: |act(z)| <= max(|z|, 0.28) scales conv2's input)
-        launch_conv(pk, planar_source(a), z, h, w, circular=c1.circular, bias=pk.bias, mod=mod, mod_sn=mod_sn,
-                    ln=(mean, rstd), out_amax=z_amax)
+        d1 = launch_conv(pk, planar_source(a), z, h, w, circular=c1.circular, bias=pk.bias, mod=mod, mod_sn=mod_sn,
+                         ln=(mean, rstd), out_amax=z_amax)
+        if not (d1 is not None and d1.w_h2):
+            z_amax = None                                # (the fp32 kernels served conv1: nothing was reported, the slot is stale)
         y = torch.empty_like(a)
         c2 = blk.conv2
         pk = c2.fwd()
@@ -602,7 +605,9 @@ class UNetEngine:
         g_amax = gz_amax = None
         if getattr(pk2, 'h2', None) is not None and g.is_contiguous():
             g_amax, gz_amax = ops.absmax(g, pk2.in_amax), pk2.out_amax      # (one streaming read of g: its producer is not an h2 launch)
-        launch_conv(pk2, planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act, x_amax=g_amax, out_amax=gz_amax)
+        d2 = launch_conv(pk2, planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act, x_amax=g_amax, out_amax=gz_amax)
+        if not (d2 is not None and d2.w_h2):
+            gz_amax = None
         gh = torch.empty_like(a)
         c1 = blk.conv1
         launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular, x_amax=gz_amax)

@@ -24,6 +24,16 @@ if MULTIPLY not in ('f32', 'f16x2'):
     raise ValueError(f"SDA_MULTIPLY={MULTIPLY!r} (expected 'f32' or 'f16x2')")
 
 
+def set_multiply(mode: str) -> str:
+    """Select how the block convolutions multiply: 'f32' (default: fp32 MFMAs) or 'f16x2' (opt-in, csrc/conv_h2.hip).  Returns the
+    previous mode.  Takes effect at the next evaluation (packed weights are keyed on it); not inside a captured graph."""
+    global MULTIPLY
+    if mode not in ('f32', 'f16x2'):
+        raise ValueError(f"multiply mode {mode!r} (expected 'f32' or 'f16x2')")
+    prev, MULTIPLY = MULTIPLY, mode
+    return prev
+
+
 def tensor_version(t) -> int:
     """``t._version`` for cache keys; inference-mode tensors have no version counter (reading it raises) and cannot be written
     in place either, so a constant stands in for them."""

@@ -1,0 +1,216 @@
+"""GPU: the OPT-IN f16 x 2 multiply (csrc/conv_h2.hip; ops.set_multiply('f16x2') / SDA_MULTIPLY / bench.py --multiply f16x2).
+
+Every fp32 operand of the block convolutions (sda/nn.py:131-142 and their backward-data) is split into two halves, hi + lo, and the
+multiply runs as three f16 MFMA products with fp32 accumulation.  Checked here:
+  (i)   single launches -- every loader / epilogue the reference's blocks use, forward and backward-data packings, both padding modes,
+        input magnitudes from 1e-3 to 1e3 -- against a float64 convolution: <= 3e-6 of the output's scale (the fp32 kernels: <= 2e-6);
+  (ii)  the reference's Kolmogorov net at 64 x 64: score, guided score and input VJP against the oracle at the suite's rtol 1e-4,
+        and against the SAME evaluation on the fp32 kernels;
+  (iii) 16 free-running guided predictor-corrector steps through the hipGraph against the fp32 oracle at rtol 1e-4;
+  (iv)  the launch reports max |out| exactly, and shapes the kernel does not serve fall back to the fp32 kernels."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sda_oracle as O
+from tests.util import assert_close, oracle_eps_from_module, rel_err
+
+pytestmark = pytest.mark.gpu
+K64 = dict(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from sda_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture
+def f16x2():
+    from sda_amd import ops
+    prev = ops.set_multiply('f16x2')
+    yield
+    ops.set_multiply(prev)
+
+
+def _ref64(x, w, bias, circular, transpose, ln, mod, silu_in, dact_z, res):
+    x, w = x.double().cpu(), w.double().cpu()
+    if ln:
+        u = x + (0 if mod is None else mod.double().cpu().reshape(1, -1, 1, 1))
+        var, mean = torch.var_mean(u, dim=1, unbiased=True, keepdim=True)
+        x = (u - mean) / torch.sqrt(var + 1e-5)
+    if silu_in:
+        x = F.silu(x)
+    xp = F.pad(x, (1, 1, 1, 1), mode='circular') if circular else F.pad(x, (1, 1, 1, 1))
+    if transpose:
+        w = w.flip(2, 3).transpose(0, 1)
+    y = F.conv2d(xp, w, None if bias is None else bias.double().cpu())
+    if dact_z is not None:
+        z = dact_z.double().cpu()
+        s = torch.sigmoid(z)
+        y = y * (s * (1 + z * (1 - s)))
+    if res is not None:
+        y = y + res.double().cpu()
+    return y
+
+
+CASES = [('plain', {}), ('mod+LN', dict(ln=True, mod=True)), ('LN', dict(ln=True)), ('SiLU+res', dict(silu=True, res=True)), ('dact', dict(dact=True))]
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(96, 96, 32, 2), (192, 96, 16, 3), (96, 192, 48, 1), (384, 384, 16, 2)])
+@pytest.mark.parametrize('transpose', [False, True])
+def test_h2_launches_vs_float64(dev, f16x2, cin, cout, hw, n, transpose):
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(cin + cout + hw + int(transpose))
+    for circular in (True, False):
+        for name, fz in CASES:
+            scale = 10.0 ** torch.randint(-3, 4, (1,)).item()
+            x = torch.randn(n, cout if transpose else cin, hw, hw, device=dev) * scale
+            w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
+            b = None if transpose else torch.randn(cout, device=dev)
+            pk = ops.PackedConv(w, b, transpose=transpose)
+            assert pk.h2 is not None
+            out = torch.empty(n, cin if transpose else cout, hw, hw, device=dev)
+            mod = torch.randn(x.shape[1], device=dev) * scale if fz.get('mod') else None
+            ln = None
+            if fz.get('ln'):
+                u = x + (0 if mod is None else mod.reshape(1, -1, 1, 1))
+                var, mean = torch.var_mean(u, dim=1, unbiased=True)
+                ln = (mean.reshape(-1).contiguous(), (1 / torch.sqrt(var + 1e-5)).reshape(-1).contiguous())
+            dz = torch.randn_like(out) if fz.get('dact') else None
+            rs = torch.randn_like(out) * scale if fz.get('res') else None
+            kw = dict(circular=circular, bias=pk.bias, act_in=1 if fz.get('silu') else 0, res=rs)
+            if ln is not None:
+                kw['ln'] = ln
+                if mod is not None:
+                    kw.update(mod=mod, mod_sn=0)
+            if dz is not None:
+                kw.update(dact_z=dz, act_d=1)
+            xa = None if ln is not None else ops.absmax(x, pk.in_amax)
+            d = launch_conv(pk, planar_source(x), out, hw, hw, x_amax=xa, out_amax=pk.out_amax, **kw)
+            assert d.w_h2, f'{name}: the f16 x 2 kernel did not serve the launch'
+            ref = _ref64(x, w, b, circular, transpose, ln is not None, mod, fz.get('silu'), dz, rs)
+            err = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+            assert err <= 3e-6, f'{cin}->{cout} @{hw} {"bwd" if transpose else "fwd"} {"circ" if circular else "zero"} {name} x~{scale:g}: {err:.2e}'
+            assert abs(pk.out_amax.item() - out.abs().max().item()) <= 1e-6 * out.abs().max().item()
+
+
+def test_h2_scale_and_fallbacks(dev, f16x2):
+    from sda_amd import _lib, ops
+    from sda_amd.engine import launch_conv, planar_source
+    lib = _lib.load()
+    for amax, want in ((1.0, 1024.0), (1.5, 1024.0), (2.0, 512.0), (1000.0, 2.0), (3e-3, 2.0 ** 19), (0.0, 1.0), (float('inf'), 1.0)):
+        assert lib.sda_conv_h2_scale(amax) == want, (amax, lib.sda_conv_h2_scale(amax))
+    assert lib.sda_conv_h2_packed_bytes(96, 96, 0) == 3 * 9 * 12 * 1024 and lib.sda_conv_h2_packed_bytes(96, 11, 0) == 0
+    # a 3 x 3 layer whose channels do not tile (11 -> 96, the head) and an image that does not tile by 16: the fp32 kernels serve them
+    for cin, cout, hw in ((11, 96, 32), (96, 96, 24)):
+        x = torch.randn(1, cin, hw, hw, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        pk = ops.PackedConv(w, None)
+        out = torch.empty(1, cout, hw, hw, device=dev)
+        d = launch_conv(pk, planar_source(x), out, hw, hw, circular=True, x_amax=None if pk.h2 is None else ops.absmax(x, pk.in_amax))
+        assert not d.w_h2
+        ref = F.conv2d(F.pad(x.double().cpu(), (1, 1, 1, 1), mode='circular'), w.double().cpu())
+        assert rel_err(out, ref) < 2e-6
+    # without a magnitude for the input the launch stays on the fp32 kernels, too
+    x = torch.randn(1, 96, 32, 32, device=dev)
+    pk = ops.PackedConv(torch.randn(96, 96, 3, 3, device=dev) * 0.05, None)
+    d = launch_conv(pk, planar_source(x), torch.empty_like(x), 32, 32, circular=True)
+    assert pk.h2 is not None and not d.w_h2
+
+
+@pytest.fixture(scope='module')
+def k64(dev):
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(90)
+    net = make_score(size=64, **K64)
+    return net, oracle_eps_from_module(net, 'mc2d')
+
+
+def test_h2_k64_score_guided_and_vjp_vs_oracle(dev, k64):
+    from sda_amd import observe as Ob
+    from sda_amd import ops
+    from sda_amd.score import GaussianScore, VPSDE
+    net, eps_o = k64
+    net.to(dev)
+    torch.manual_seed(91)
+    x = torch.randn(2, 6, 2, 64, 64)
+    t = torch.tensor(0.37)
+    sub4 = lambda v: v[..., ::4, ::4]
+    y = torch.randn(sub4(x).shape)
+    g = torch.randn_like(x)
+    res = {}
+    for mode in ('f32', 'f16x2'):
+        prev = ops.set_multiply(mode)
+        try:
+            launched = []
+            real = ops.conv_h2
+            ops.conv_h2 = lambda *a, **k: (lambda r: (launched.append(r), r)[1])(real(*a, **k))
+            xd = x.to(dev).requires_grad_(True)
+            out = net(xd, t.to(dev))
+            vjp, = torch.autograd.grad(out, xd, g.to(dev))
+            gs = GaussianScore(y, A=Ob.Subsample.space(4), std=0.1, sde=VPSDE(net, shape=())).to(dev)
+            guided = gs(x.to(dev), t.to(dev))
+            res[mode] = (out.detach().cpu(), vjp.cpu(), guided.cpu(), sum(launched))
+        finally:
+            ops.conv_h2 = real
+            ops.set_multiply(prev)
+    assert res['f32'][3] == 0
+    assert res['f16x2'][3] >= 2 * 2 * 36, f"only {res['f16x2'][3]} launches took the f16 x 2 kernel"     # 36 block convolutions, fwd + VJP, two evaluations
+    ref = eps_o(x, t)
+    xo = x.double().requires_grad_(True)
+    ref_v, = torch.autograd.grad(eps_o(xo, t.double(), torch.float64), xo, g.double())
+    ref_g = O.gaussian_score(eps_o, O.Schedule(), y, sub4, 0.1, 1e-2, x, t)
+    for mode in ('f32', 'f16x2'):
+        out, vjp, guided, _ = res[mode]
+        assert_close(out, ref, 1e-4, what=f'eps ({mode})')
+        assert_close(vjp, ref_v, 1e-4, what=f'vjp ({mode})')
+        assert_close(guided, ref_g, 1e-4, what=f'guided ({mode})')
+    # the two multiplies agree with each other far inside the tolerance
+    e = [rel_err(res['f16x2'][i], res['f32'][i].double()) for i in range(3)]
+    r32 = [rel_err(res['f32'][0], ref.double()), rel_err(res['f32'][1], ref_v), rel_err(res['f32'][2], ref_g.double())]
+    r16 = [rel_err(res['f16x2'][0], ref.double()), rel_err(res['f16x2'][1], ref_v), rel_err(res['f16x2'][2], ref_g.double())]
+    print(f'K64 @ 64^2 (eps, vjp, guided): f16x2 vs f32 kernels {e[0]:.1e} {e[1]:.1e} {e[2]:.1e}; vs oracle f32 {r32[0]:.1e} {r32[1]:.1e} {r32[2]:.1e}, '
+          f'f16x2 {r16[0]:.1e} {r16[1]:.1e} {r16[2]:.1e}')
+    assert max(e) < 2e-5
+
+
+def test_h2_free_running_guided_hipgraph_vs_fp32_oracle(dev, k64, f16x2):
+    import bench
+    from sda_amd import observe as Ob
+    from sda_amd.parallel import KeyedNoise
+    from sda_amd.score import GaussianScore, VPSDE
+    net, eps_net = k64
+    net.to(dev)
+    steps, corr, tau, std, gamma = 16, 1, 0.5, 0.1, 1e-2
+    event = (6, 2, 64, 64)
+    sub4 = lambda v: v[..., ::4, ::4]
+    torch.manual_seed(92)
+    x1 = torch.randn((1,) + event)
+    y = torch.randn(sub4(x1[0]).shape)
+    ns = KeyedNoise((0, 1), event, 78, corr, dev)
+    zs = torch.stack([ns(i, j) for i in range(steps) for j in range(corr)]).cpu()
+    score = bench.SyntheticScore(net)
+    inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)
+    gs = GaussianScore(y, A=Ob.Subsample.space(4), std=std, sde=inner, gamma=gamma)
+    sde = VPSDE(gs, shape=event).to(dev)
+    sde.initial_noise, sde.noise_source = x1, ns
+    sampler = sde.sampler((1,), steps=steps, corrections=corr, tau=tau).capture()
+    for _ in range(steps):
+        sampler.step()
+    got = sampler.result().cpu()
+    sched = O.Schedule()
+
+    def eps(xx, tt):
+        mu, sg = sched.mu(tt), sched.sigma(tt)
+        return xx * (sg / (mu * mu + sg * sg)) + 0.1 * eps_net(xx, tt)
+    sc = lambda xx, tt: O.gaussian_score(eps, sched, y, sub4, std, gamma, xx, tt)
+    ref32 = O.sample(sc, sched, x1, 4, steps, corr, tau, noise=lambda i, j: zs[i * corr + j])
+    err = rel_err(got.double(), ref32.double())
+    print(f'f16x2, K64 @ 64^2, {steps} guided PC steps through the hipGraph vs the fp32 oracle: {err:.2e}')
+    assert torch.isfinite(got).all() and err <= 1e-4

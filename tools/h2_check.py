@@ -21,6 +21,8 @@ from sda_amd.engine import launch_conv, planar_source
 assert ops.MULTIPLY == 'f16x2'
 dev = torch.device('cuda:0')
 quick = '--quick' in sys.argv
+timing_only = '--timing-only' in sys.argv
+plain_only = '--plain' in sys.argv
 
 
 def ref64(x, w, bias, circular, transpose, ln, mod, act_in, dact_z, res):
@@ -75,7 +77,7 @@ torch.manual_seed(0)
 print('--- correctness: max |err| / max |ref| against float64')
 worst = 0.0
 cases = [('plain', {}), ('mod+LN', dict(ln=True, mod=True)), ('LN', dict(ln=True)), ('SiLU+res', dict(act_in=1, res=True)), ('x act\'(z)', dict(dact=True))]
-for cin, cout, hw, n in ((96, 96, 32, 2), (192, 96, 16, 3), (96, 192, 48, 1), (384, 384, 16, 2)):
+for cin, cout, hw, n in (() if timing_only else ((96, 96, 32, 2), (192, 96, 16, 3), (96, 192, 48, 1), (384, 384, 16, 2))):
     for transpose in (False, True):
         for circular in (True, False):
             for name, fz in cases:
@@ -114,7 +116,7 @@ shapes = [('96->96 @256^2 x30', 96, 96, 256, 30), ('192->192 @128^2 x60', 192, 1
 if quick:
     shapes = shapes[:1] + shapes[2:3]
 for label, cin, cout, hw, n in shapes:
-    for name, fz in cases:
+    for name, fz in (cases[:1] if plain_only else cases):
         x = torch.randn(n, cin, hw, hw, device=dev)
         w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
         pk = ops.PackedConv(w, torch.randn(cout, device=dev))
