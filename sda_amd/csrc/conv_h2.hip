@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
     const int by = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
-    const float sx = h2_scale_of(a.x_amax ? a.x_amax[0] : a.x_amax_static);
+    // (the producer wrote it with device-scope atomics: read it at device scope too -- a scalar-cache line left over from the previous
+    //  replay of a captured step is not good enough)
+    const float sx = h2_scale_of(a.x_amax ? __hip_atomic_load(a.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.x_amax_static);
 
     // ---- loader plan of this lane (the same for every chunk): halo pixel p = lane + 64 r, channels 8 wave .. + 7 of the chunk
     const float* ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)(8 * wave) * d.x_sc;
@@ -459,10 +461,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
 }
 
+__global__ void absmax_zero_kernel(float* __restrict__ amax) { amax[0] = 0.f; }
+
 extern "C" int sda_absmax(const float* x, int64_t numel, float* amax, void* stream) {
     if (!x || !amax || numel <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return SDA_E_BADARG;
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    // (zeroed by a KERNEL: a 4-byte hipMemsetAsync captured into a hipGraph was observed to land after the reduction that follows it
+    //  on replays that start from an idle device -- amax 0, a scale 2^10 too large, inf in the halves)
+    hipLaunchKernelGGL(absmax_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax);
     const int64_t n4 = numel / 4;
     const int64_t want = (n4 + 255) / 256;
     const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));

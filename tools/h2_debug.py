@@ -43,6 +43,16 @@ sampler = sde.sampler((wl['per_gpu'],), steps=1000, corrections=1, tau=0.5)
 if len(sys.argv) > 3 and sys.argv[3] == 'graph':
     engine.launch_conv = real
     sampler.capture()
-for i in range(3):
+for i in range(int(os.environ.get("H2_STEPS", "3"))):
     sampler.step()
+    if os.environ.get('H2_PROBE') and i == int(os.environ['H2_PROBE']):
+        mode = os.environ.get('H2_PROBE_MODE', 'probe')
+        if mode == 'probe':
+            print('probe', ops.clock_probe(dev)['ghz'])
+        elif mode == 'alloc':
+            t = torch.zeros(2048, device=dev, dtype=torch.int64); torch.cuda.synchronize(); print('alloc only', t.data_ptr())
+        elif mode == 'sync':
+            torch.cuda.synchronize(); print('sync only')
+        elif mode == 'matmul':
+            a_ = torch.randn(4096, 4096, device=dev); print('matmul', float((a_ @ a_).sum()))
     print('step', i, 'finite', bool(torch.isfinite(sampler.x).all()), 'max |x|', float(sampler.x.abs().max()), 'launches', count[0])
