@@ -35,22 +35,21 @@
 #include <type_traits>
 
 typedef _Float16 h2_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2_h2 __attribute__((ext_vector_type(2)));
 typedef float h2_f4 __attribute__((ext_vector_type(4)));
 typedef float h2_f16v __attribute__((ext_vector_type(16)));
 
 #define H2_TS 16                       // tile side (pixels)
 #define H2_HS (H2_TS + 2)              // halo side
 #define H2_NPX (H2_HS * H2_HS)         // 324 halo pixels
-#define H2_PXB 160                     // bytes per halo pixel in LDS: 64 hi + 64 lo + 32 pad
-#define H2_ROWB (H2_HS * H2_PXB + 16)   // 2 896 B per halo row (row pad: the two rows of a 32-pixel fragment land on different bank quads)
-#define H2_DUMMY (H2_HS * H2_ROWB)      // 52 128: where loader lanes without a pixel (slots 324 .. 383) store -- never read
-#define H2_TILE (H2_DUMMY + 64 * H2_PXB) // 62 368 B
-#define H2_ASLOT (12 * 64 * 16)         // 12 288 B: one tap's weight fragments
-#define H2_LDS (2 * H2_TILE + 2 * H2_ASLOT)
-#define H2_CK 32                       // channels per chunk
+#define H2_CK 16                       // channels per stage (one K step of the 32x32x16 MFMA)
+#define H2_KQ 96                       // the layer's contraction must be a multiple of this (stages run in sixes: 3 value sets x 2 buffers)
+#define H2_PXB 80                      // bytes per halo pixel in LDS: 32 hi + 32 lo + 16 pad (20 banks: any 16 consecutive pixels cover all 64)
+#define H2_BTILE (H2_NPX * H2_PXB)     // 25 920 B
+#define H2_ASLAB (9 * 3 * 2 * 1024)    // 55 296 B: a stage's weights, [tap][cout fragment][piece][lane] x 16 B
+#define H2_STAGE (H2_ASLAB + H2_BTILE) // 81 216 B
+#define H2_LDS (2 * H2_STAGE)          // 162 432 B of the CU's 163 840
 #define H2_BM 96                       // couts per workgroup
-#define H2_RND ((H2_NPX + 63) / 64)    // 6 loader rounds per wave and chunk
+#define H2_PRND 3                      // loader rounds per producer wave and stage (pixels lane + 64 (2 r + half))
 #define H2_TARGET_EXP 11               // max |s x| in [2^10, 2^11]
 
 // power-of-two scale that puts `amax` into [2^(T-1), 2^T]  (amax = 0 / denormal: 1)
@@ -71,313 +70,343 @@ struct h2_args {
     const float* x_amax;        // device: max |loader output| (NULL: x_amax_static)
     float x_amax_static;
     float* out_amax;            // device (optional): atomically maxed with |out| as uint bits
-    int tiles_x, tiles_y, n_ct, nchunk;
+    int tiles_x, tiles_y, n_ct, nchunk, ntiles;
 };
 
-// ABL (tooling builds, -DSDA_H2_ABLATE + $SDA_H2_ABL; results WRONG): 1 no weight loads in the loop, 2 no loader in the loop, 4 no MFMAs,
-// 8 no epilogue stores -- what each costs, measured by leaving it out (tools/h2_check.py --ablate)
+// barrier of the 4 + 4 waves.  Not __syncthreads(): that also drains vmcnt, and a consumer's epilogue stores (gfx9 counts stores in
+// vmcnt) would be waited for at the next tile's first stage.  Consumers wait for their LDS reads only; producers also for their
+// loads / LDS-DMA (hipcc does not count LDS-DMA: the wait is ours).
+#define H2_BARRIER_CONSUMER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define H2_BARRIER_PRODUCER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// ABL (tooling builds, -DSDA_H2_ABLATE + $SDA_H2_ABL; results WRONG): 1 no weight DMA, 2 no activation loader, 4 no MFMAs,
+// 8 no epilogue stores -- what each costs, measured by leaving it out (tools/h2_check.py)
 template <int LOADER, int ABL = 0>           // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
-__global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
+__global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- tile of this workgroup.  Consecutive logical tiles (all cout tiles of a pixel tile, then the row of pixel tiles) go to ONE
-    // XCD (blockIdx % 8 is the XCD): they share halo lines and weight fragments in that XCD's L2.
-    int t = blockIdx.x;
-    {
-        const int total = gridDim.x;
-        if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
-    }
-    const int ct = t % a.n_ct; t /= a.n_ct;
-    const int bx = t % a.tiles_x; t /= a.tiles_x;
-    const int by = t % a.tiles_y;
-    const int n = t / a.tiles_y;
-    const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
+    // ---- persistent schedule.  Workgroup b lives on XCD b % 8; in pass `it` the G / 8 workgroups of an XCD take G / 8 CONSECUTIVE
+    // logical tiles (all cout tiles of a pixel tile, then the row of pixel tiles): they share halo lines and the weight slabs in that
+    // XCD's L2 while they are hot.
+    const int G = gridDim.x;
+    const bool xwalk = (G & 7) == 0;
+    const int per = G >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    auto tile_of = [&](int it) { return xwalk ? (it * 8 + xcd) * per + slot : it * G + (int)blockIdx.x; };
     // (the producer wrote it with device-scope atomics: read it at device scope too -- a scalar-cache line left over from the previous
     //  replay of a captured step is not good enough)
     const float sx = h2_scale_of(a.x_amax ? __hip_atomic_load(a.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.x_amax_static);
 
-    // ---- loader plan of this lane (the same for every chunk): halo pixel p = lane + 64 r, channels 8 wave .. + 7 of the chunk
-    const float* ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)(8 * wave) * d.x_sc;
-    int goff[H2_RND], lds_wr[H2_RND];
-    unsigned valid = 0;
-    float mean[H2_RND], rstd[H2_RND];
+    if (wave >= 4) {
+        // ================================================================ producers: global -> (loader fusions, split) -> LDS
+        const int pw = wave - 4;
+        const int ch8 = (pw & 1) * 8;                               // this wave's eight channels of a stage
+        const int half = pw >> 1;                                   // ... and its half of the pixel rounds
+        struct plan_t {
+            const float* ximg;                                      // image + channel ch8
+            const float* modp;
+            const unsigned char* wsl;                               // the cout tile's weight slabs
+            unsigned goff[H2_PRND];                                 // BYTE offsets of the pixels (scalar base + 32-bit lane offset loads)
+            float mean[H2_PRND], rstd[H2_PRND];
+            unsigned valid;
+        };
+        int lds_wr[H2_PRND];
 #pragma unroll
-    for (int r = 0; r < H2_RND; ++r) {
-        const int p = lane + 64 * r;
-        const int hy = p / H2_HS, hx = p - hy * H2_HS;
-        int y = oy0 + hy - 1, x = ox0 + hx - 1;
-        bool ok = p < H2_NPX;
-        if (d.circular) {
-            y = y < 0 ? y + d.hs : (y >= d.hs ? y - d.hs : y);
-            x = x < 0 ? x + d.ws : (x >= d.ws ? x - d.ws : x);
-        } else {
-            ok = ok && y >= 0 && y < d.hs && x >= 0 && x < d.ws;
+        for (int r = 0; r < H2_PRND; ++r) {
+            const int p = lane + 64 * (2 * r + half);
+            lds_wr[r] = p < H2_NPX ? H2_ASLAB + p * H2_PXB + (pw & 1) * 16 : -1;      // (+ 32: the low piece)
         }
-        y = ok ? y : 0;
-        x = ok ? x : 0;
-        goff[r] = y * (int)d.x_sy + x * (int)d.x_sx;
-        lds_wr[r] = (p < H2_NPX ? hy * H2_ROWB + hx * H2_PXB : H2_DUMMY + lane * H2_PXB) + wave * 16;     // (+ 64: the low piece)
-        valid |= ok ? (1u << r) : 0u;
-        if (LOADER == 2) {
-            const int64_t sp = (int64_t)n * d.hs * d.ws + (int64_t)y * d.ws + x;
-            mean[r] = d.ln_mean[sp];
-            rstd[r] = d.ln_rstd[sp];
-        }
-    }
-    const float* modp = (LOADER == 2 && d.mod) ? d.mod + (int64_t)n * d.mod_sn + 8 * wave : nullptr;
-
-    float raw[2][H2_RND][8];                                        // the loader's values of two chunks: requested a whole chunk ahead
-    auto load_round = [&](int chunk, int r, float (&v)[8]) {
-        const float* src = ximg + (int64_t)chunk * H2_CK * d.x_sc + goff[r];
+        auto make_plan = [&](int L, plan_t& P) {
+            int t = L;
+            const int ct = t % a.n_ct; t /= a.n_ct;
+            const int bx = t % a.tiles_x; t /= a.tiles_x;
+            const int by = t % a.tiles_y;
+            const int n = t / a.tiles_y;
+            const int oy0 = by * H2_TS, ox0 = bx * H2_TS;
+            P.ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)ch8 * d.x_sc;
+            P.modp = (LOADER == 2 && d.mod) ? d.mod + (int64_t)n * d.mod_sn + ch8 : nullptr;
+            P.wsl = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)ct * a.nchunk * H2_ASLAB;
+            P.valid = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = src[(int64_t)i * d.x_sc];
-    };
-    auto store_round = [&](int chunk, int r, const float (&v)[8], unsigned char* buf) {
-        h2_h8 hi, lo;
-        const bool ok = (valid >> r) & 1u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float u = v[i];
-            if (LOADER == 2) {
-                if (modp) u += modp[chunk * H2_CK + i];
-                u = (u - mean[r]) * rstd[r];
-            }
-            if (LOADER == 1) u = u * sda_sigmoid(u);                 // (SiLU: the launcher admits no other activation here)
-            u = ok ? u * sx : 0.f;
-            const _Float16 h = (_Float16)u;
-            hi[i] = h;
-            lo[i] = (_Float16)(u - (float)h);
-        }
-        *reinterpret_cast<h2_h8*>(buf + lds_wr[r]) = hi;            // (no branch: a conditional store would split the tap's
-        *reinterpret_cast<h2_h8*>(buf + lds_wr[r] + 64) = lo;       //  scheduling region)
-    };
-
-    // ---- consumer addressing.  B fragment f of tap (dy, dx), K step ks: pixel rows 4 wave + 2 f + ((lane & 31) >> 4) + dy, columns
-    // dx + (lane & 15), channels 16 ks + 8 (lane >> 5) ..
-    const int b_rd = (4 * wave + ((lane & 31) >> 4)) * H2_ROWB + (lane & 15) * H2_PXB + (lane >> 5) * 16;
-    // A: [cout tile][chunk][tap][ks][m][piece][lane] x 16 B
-    const h2_h8* wq = reinterpret_cast<const h2_h8*>(a.w) + (int64_t)ct * a.nchunk * (9 * 2 * 3 * 2 * 64) + lane;
-
-    h2_f16v acc[3][2];
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
-
-    // ---- prologue: chunk 0 into buffer 0 (all its requests in flight together), chunk 1 requested
-#pragma unroll
-    for (int r = 0; r < H2_RND; ++r) load_round(0, r, raw[0][r]);
-    const int c1 = a.nchunk > 1 ? 1 : 0;
-#pragma unroll
-    for (int r = 0; r < H2_RND; ++r) load_round(c1, r, raw[1][r]);
-    h2_h8 A[2][2][3][2], B[2][2][2][2];                             // [set][K step][fragment][piece]
-    // weights: global tap g = 9 chunk + tap; its 12 fragments are contiguous in the packing.  This wave's quarter: fragments 3 wave + j.
-    unsigned char* aring = smem + 2 * H2_TILE;
-    const int gtaps = 9 * a.nchunk;
-    h2_h8 aq[3];
-    auto fetch_A = [&](int g) {                                     // global -> registers (quarter)
-        const h2_h8* p = wq + (int64_t)(g < gtaps ? g : gtaps - 1) * (12 * 64) + 3 * wave * 64;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) aq[j] = p[j * 64];
-    };
-    auto stash_A = [&](int slot) {                                  // registers -> ring slot (quarter)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<h2_h8*>(aring + slot * H2_ASLOT + (3 * wave + j) * 1024 + lane * 16) = aq[j];
-    };
-    auto load_A = [&](int slot, h2_h8 (&dst)[2][3][2]) {           // ring slot -> operand registers (all twelve)
-        const unsigned char* p = aring + slot * H2_ASLOT + lane * 16;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                dst[ks][m][0] = *reinterpret_cast<const h2_h8*>(p + ((ks * 3 + m) * 2 + 0) * 1024);
-                dst[ks][m][1] = *reinterpret_cast<const h2_h8*>(p + ((ks * 3 + m) * 2 + 1) * 1024);
-            }
-    };
-    auto load_B = [&](const unsigned char* buf, int tap, h2_h8 (&dst)[2][2][2]) {
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        const unsigned char* p = buf + b_rd + dy * H2_ROWB + dx * H2_PXB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                dst[ks][f][0] = *reinterpret_cast<const h2_h8*>(p + 2 * f * H2_ROWB + ks * 32);
-                dst[ks][f][1] = *reinterpret_cast<const h2_h8*>(p + 2 * f * H2_ROWB + ks * 32 + 64);
-            }
-    };
-    {
-        // (every request of the prologue is in flight before the first use: one round trip, not one per operand)
-        h2_h8 aq1[3];
-        fetch_A(0);
-        const h2_h8* p1 = wq + (int64_t)(gtaps > 1 ? 1 : 0) * (12 * 64) + 3 * wave * 64;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) aq1[j] = p1[j * 64];
-        stash_A(0);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<h2_h8*>(aring + H2_ASLOT + (3 * wave + j) * 1024 + lane * 16) = aq1[j];
-    }
-#pragma unroll
-    for (int r = 0; r < H2_RND; ++r) store_round(0, r, raw[0][r], smem);
-    fetch_A(2);
-    __syncthreads();
-    load_A(0, A[0]);
-    __syncthreads();                                               // (slot 0 is read: tap 0 may overwrite it with tap 2's weights)
-
-    // One chunk = nine taps; P = the operand set tap 0 multiplies with (the sets alternate per tap, so a chunk that starts on set 0
-    // hands over on set 1: the chunk loop below runs in pairs and every index stays a compile-time constant -- no register moves).
-    // The instruction order of a tap is pinned (sched_group_barrier): left alone, the scheduler sinks the next tap's loads to their
-    // first use and every tap starts with an exposed L2 round trip (measured: 3 000 cycles per tap instead of 1 250).
-    auto chunk_body = [&](auto parity, int chunk) {
-        constexpr int P = decltype(parity)::value;
-        const unsigned char* cur = smem + (chunk & 1) * H2_TILE;
-        unsigned char* nxt = smem + ((chunk + 1) & 1) * H2_TILE;
-        // (past the last chunk the loader re-requests / re-stores that chunk into the idle buffer: branch-free)
-        const int cn = chunk + 1 < a.nchunk ? chunk + 1 : chunk, cnn = chunk + 2 < a.nchunk ? chunk + 2 : a.nchunk - 1;
-        load_B(cur, 0, B[P]);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int s = (P + tap) & 1;
-            __builtin_amdgcn_sched_barrier(0);
-            // weights: tap g + 2's quarter (fetched during the previous tap) into the slot tap g's weights were read from, tap g + 3's
-            // requested, tap g + 1's twelve fragments read; B of the next tap (the first tap of the next chunk: after the barrier)
-            if (!(ABL & 1)) {
-                stash_A(s);
-                fetch_A(9 * chunk + tap + 3);
-                load_A(s ^ 1, A[s ^ 1]);
-            }
-            if (tap < 8) load_B(cur, tap + 1, B[s ^ 1]);
-            // this wave's share of the tiles ahead: tap r stores round r of the NEXT chunk (requested a whole chunk ago -- an HBM round trip
-            // under load is 2-3 us, three taps) and requests round r of the chunk after that into the set this chunk's values came from
-            if (tap < H2_RND && !(ABL & 2)) {
-                store_round(cn, tap, raw[P ^ 1][tap], nxt);
-                load_round(cnn, tap, raw[P][tap]);
-            }
-            // small products first (fp32 accumulation)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ABL & 4) {                                     // (keep the operands alive without multiplying)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][ks][m][0][0] + (float)A[s][ks][m][1][0];
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][ks][f][0][0] + (float)B[s][ks][f][1][0];
-                    continue;
+            for (int r = 0; r < H2_PRND; ++r) {
+                const int p = lane + 64 * (2 * r + half);
+                const int hy = p / H2_HS, hx = p - hy * H2_HS;
+                int y = oy0 + hy - 1, x = ox0 + hx - 1;
+                bool ok = p < H2_NPX;
+                if (d.circular) {
+                    y = y < 0 ? y + d.hs : (y >= d.hs ? y - d.hs : y);
+                    x = x < 0 ? x + d.ws : (x >= d.ws ? x - d.ws : x);
+                } else {
+                    ok = ok && y >= 0 && y < d.hs && x >= 0 && x < d.ws;
                 }
-#pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][0], B[s][ks][f][1], acc[m][f], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][1], B[s][ks][f][0], acc[m][f], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][ks][m][0], B[s][ks][f][0], acc[m][f], 0, 0, 0);
-            }
-            // ---- the tap's issue order: 36 MFMAs (32 cycles each) with everything else threaded between them: the ring stores first (the
-            // barrier at the tap's end publishes them), the next tap's A and B reads, the requests, the loader's arithmetic riding along
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            if (tap < H2_RND) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                y = ok ? y : 0;
+                x = ok ? x : 0;
+                P.goff[r] = 4u * (unsigned)(y * (int)d.x_sy + x * (int)d.x_sx);
+                P.valid |= ok ? (1u << r) : 0u;
+                if (LOADER == 2) {
+                    const int64_t sp = (int64_t)n * d.hs * d.ws + (int64_t)y * d.ws + x;
+                    P.mean[r] = d.ln_mean[sp];
+                    P.rstd[r] = d.ln_rstd[sp] * sx;                 // (the power-of-two scale folded in: exact)
+                } else {
+                    P.mean[r] = 0.f;
+                    P.rstd[r] = sx;
                 }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 36, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                       // the ring slot (and, after tap 8, the next chunk's tile) is published
+        };
+        auto load_from = [&](const float* ximg, const unsigned (&goff)[H2_PRND], int chunk, float (&v)[H2_PRND][8]) {
+            if (ABL & 2) return;
+            const char* src = reinterpret_cast<const char*>(ximg + (int64_t)chunk * H2_CK * d.x_sc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const char* ch = src + (int64_t)i * d.x_sc * 4;     // (wave-uniform: an SGPR pair)
+#pragma unroll
+                for (int r = 0; r < H2_PRND; ++r) v[r][i] = *reinterpret_cast<const float*>(ch + goff[r]);
+            }
+        };
+        auto load_stage = [&](const plan_t& P, int chunk, float (&v)[H2_PRND][8]) { load_from(P.ximg, P.goff, chunk, v); };
+        // LDS-DMA by inline asm: hipcc does not count it (the waits are ours, below), and -- unlike the builtin -- it does not make hipcc
+        // drain vmcnt in front of every LDS access and register-load use of the loop.
+        auto dma_weights = [&](const plan_t& P, int chunk, int bufsel) {
+            if (ABL & 1) return;
+            const unsigned char* src = P.wsl + (int64_t)chunk * H2_ASLAB + lane * 16;
+            const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+                (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(smem + bufsel * H2_STAGE)));
+            // 54 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                const int piece = pw + 4 * k;
+                if (k < 13 || piece < 54) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src + piece * 1024), "s"(lds0 + piece * 1024) : "memory");
+                }
+            }
+        };
+        auto convert_stage = [&](const plan_t& P, int chunk, const float (&v)[H2_PRND][8], unsigned char* buf) {
+            if (ABL & 2) return;
+            float mod[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mod[i] = (LOADER == 2 && P.modp) ? P.modp[chunk * H2_CK + i] : 0.f;
+#pragma unroll
+            for (int r = 0; r < H2_PRND; ++r) {
+                h2_h8 hi, lo;
+                const bool ok = (P.valid >> r) & 1u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float u = v[r][i];
+                    if (LOADER == 2) u = ((u + mod[i]) - P.mean[r]) * P.rstd[r];
+                    else if (LOADER == 1) u = (u * sda_sigmoid(u)) * sx;         // (SiLU: the launcher admits no other activation here)
+                    else u = u * sx;
+                    u = ok ? u : 0.f;
+                    const _Float16 h = (_Float16)u;
+                    hi[i] = h;
+                    lo[i] = (_Float16)(u - (float)h);
+                }
+                if (lds_wr[r] >= 0) {
+                    *reinterpret_cast<h2_h8*>(buf + lds_wr[r]) = hi;
+                    *reinterpret_cast<h2_h8*>(buf + lds_wr[r] + 32) = lo;
+                }
+            }
+        };
+        // values a finished wait has landed: hide them from hipcc's own load bookkeeping (beside LDS-DMA it waits vmcnt(0) in front of
+        // the first use of any register load -- here that would drain the NEXT stage's loads, issued at the top of the iteration)
+        auto launder = [&](float (&v)[H2_PRND][8]) {
+#pragma unroll
+            for (int r = 0; r < H2_PRND; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("; landed %0" : "+v"(v[r][i]));
+        };
+        plan_t P0, P1;
+        int it = 0;
+        if (tile_of(0) >= a.ntiles) return;
+        make_plan(tile_of(0), P0);
+        // Three register sets of loader values: a stage's values are requested TWO stages ahead (an HBM round trip under load is 2-3 us,
+        // a stage's multiplies 2.2 us), in program order AFTER the stage's weight DMA -- vmcnt counts in order, so "at most the 24 newest
+        // outstanding" = this stage's DMA has landed and so have the values the NEXT iteration converts.
+        float raw[3][H2_PRND][8];
+        load_stage(P0, 0, raw[0]);
+        load_stage(P0, 1, raw[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        launder(raw[0]);
+        launder(raw[1]);
+        bool more = false;
+        P1 = P0;
+        auto stage = [&](auto set_c, auto buf_c, int chunk) {
+            constexpr int S = decltype(set_c)::value, Bf = decltype(buf_c)::value;
+            unsigned char* buf = smem + Bf * H2_STAGE;
+            dma_weights(P0, chunk, Bf);
+            asm volatile("" ::: "memory");                          // (no register load may be hoisted above the DMA: the count below)
+            // ALWAYS 24 loads (past the last tile: a re-read of this tile, P1 = P0) -- behind a branch, hipcc's own wait in front of the
+            // launder below assumes the path without them and drains the loads just issued
+            const int c2 = chunk + 2;
+            const bool own = c2 < a.nchunk;
+            unsigned goff[H2_PRND];
+#pragma unroll
+            for (int r = 0; r < H2_PRND; ++r) goff[r] = own ? P0.goff[r] : P1.goff[r];
+            load_from(own ? P0.ximg : P1.ximg, goff, own ? c2 : c2 - a.nchunk, raw[(S + 2) % 3]);
+            convert_stage(P0, chunk, raw[S], buf);
+            // in order: ... this stage's DMA | the 24 loads just issued.  (hipcc counts only its own loads: its wait in front of the
+            // launder below is the same vmcnt(24), or stricter.)
+            if (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            launder(raw[(S + 1) % 3]);
+            H2_BARRIER_PRODUCER_LDS();
+        };
+        using c0 = std::integral_constant<int, 0>;
+        using c1 = std::integral_constant<int, 1>;
+        using c2t = std::integral_constant<int, 2>;
+        for (;;) {
+            const int Ln = tile_of(it + 1);
+            more = Ln < a.ntiles;
+            if (more) make_plan(Ln, P1); else P1 = P0;
+            for (int chunk = 0; chunk < a.nchunk; chunk += 6) {     // (nchunk % 6 == 0: every tile starts on set 0 / buffer 0)
+                stage(c0{}, c0{}, chunk);
+                stage(c1{}, c1{}, chunk + 1);
+                stage(c2t{}, c0{}, chunk + 2);
+                stage(c0{}, c1{}, chunk + 3);
+                stage(c1{}, c0{}, chunk + 4);
+                stage(c2t{}, c1{}, chunk + 5);
+            }
+            if (!more) break;
+            P0 = P1;
+            ++it;
         }
-    };
-    {
-        int chunk = 0;
-        for (; chunk + 1 < a.nchunk; chunk += 2) {
-            chunk_body(std::integral_constant<int, 0>{}, chunk);
-            chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
-        }
-        if (chunk < a.nchunk) chunk_body(std::integral_constant<int, 0>{}, chunk);
+        return;
     }
 
-    // ---- epilogue.  acc[m][f][r]: cout co0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel row oy0 + 4 wave + 2 f + ((lane & 31) >> 4),
-    // column ox0 + (lane & 15)
-    const float inv = 1.0f / (sx * a.w_scale);
-    const int64_t osn = (int64_t)d.cout * d.ho * d.wo, osc = (int64_t)d.ho * d.wo;
-    const int64_t obase = (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + ((lane & 31) >> 4)) * d.wo + ox0 + (lane & 15);
+    // ==================================================================== consumers: LDS reads + MFMAs only in the loop
+    // B fragment: MFMA column n = lane & 31 is a pixel of a 2 x 16 patch.  ds_read_b128 serves the lane groups {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} (+ 32) in one LDS cycle each: a group reads 16 CONSECUTIVE pixels of one row (stride 80 B = 20 banks: all 64
+    // banks once), so the columns of a row go to one group's lanes in order.
+    const int n31 = lane & 31;
+    const int prow = ((n31 >= 4 && n31 < 12) || (n31 >= 16 && n31 < 20) || n31 >= 28) ? 1 : 0;
+    const int pcol = prow ? (n31 < 12 ? n31 - 4 : (n31 < 20 ? n31 - 8 : n31 - 16)) : (n31 < 4 ? n31 : (n31 < 16 ? n31 - 8 : n31 - 12));
+    const int b_rd = H2_ASLAB + ((4 * wave + prow) * H2_HS + pcol) * H2_PXB + (lane >> 5) * 16;
+    const int a_rd = lane * 16;
     float amax = 0.f;
-    // (the epilogue's mode is decided ONCE, by uniform branches around three straight-line copies: tested per element the
-    //  compiler emits a branch per store.)  Every operand of the tile is requested before the first store: one round trip.
-    auto epilogue = [&](auto mode, auto with_bias) {
-        constexpr int EPI = decltype(mode)::value;                 // 0 none, 1 x act'(z), 2 + res
-        constexpr bool BIAS = decltype(with_bias)::value;
-        float bias[3][16], opnd[3][2][16];
-        const float* op = EPI == 1 ? d.dact_z : d.res;
+    for (int it = 0;; ++it) {
+        int t = tile_of(it);
+        if (t >= a.ntiles) break;
+        const int ct = t % a.n_ct; t /= a.n_ct;
+        const int bx = t % a.tiles_x; t /= a.tiles_x;
+        const int by = t % a.tiles_y;
+        const int n = t / a.tiles_y;
+        const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
+
+        h2_f16v acc[3][2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias[m][r] = BIAS ? d.bias[co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
-            if (EPI != 0) {
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        opnd[m][f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo];
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[m][f][r] * inv + bias[m][r];
-                    if (EPI == 1) v *= sda_dact(SDA_ACT_SILU, opnd[m][f][r]);
-                    if (EPI == 2) v += opnd[m][f][r];
-                    amax = fmaxf(amax, fabsf(v));
-                    if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo] = v;
+                for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
+
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            H2_BARRIER_CONSUMER();                                  // the stage is published (and the other buffer released)
+            const unsigned char* st = smem + (chunk & 1) * H2_STAGE;
+            h2_h8 A[2][3][2], B[2][2][2];                           // [set][fragment][piece]
+            auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                const unsigned char* pa = st + a_rd + tap * (3 * 2 * 1024);
+                const unsigned char* pb = st + b_rd + (dy * H2_HS + dx) * H2_PXB;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    Bd[f][0] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB);
+                    Bd[f][1] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB + 32);
                 }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    Ad[m][0] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 0) * 1024);
+                    Ad[m][1] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 1) * 1024);
+                }
+            };
+            load_AB(0, A[0], B[0]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int s = tap & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < 8) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
+                if (ABL & 4) {                                      // (keep the operands alive without multiplying)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][f][0][0] + (float)B[s][f][1][0];
+                } else {
+                    // small products first (fp32 accumulation)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f)
+                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][1], acc[m][f], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f)
+                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][1], B[s][f][0], acc[m][f], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f)
+                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][0], acc[m][f], 0, 0, 0);
+                    // the tap's issue order: the next tap's ten operand reads between the first MFMAs
+                    if (tap < 8) {
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    };
-    using h2_c0 = std::integral_constant<int, 0>;
-    using h2_c1 = std::integral_constant<int, 1>;
-    using h2_c2 = std::integral_constant<int, 2>;
-    if (d.dact_z) {
-        if (d.bias) epilogue(h2_c1{}, std::true_type{}); else epilogue(h2_c1{}, std::false_type{});
-    } else if (d.res) {
-        if (d.bias) epilogue(h2_c2{}, std::true_type{}); else epilogue(h2_c2{}, std::false_type{});
-    } else {
-        if (d.bias) epilogue(h2_c0{}, std::true_type{}); else epilogue(h2_c0{}, std::false_type{});
+
+        // ---- epilogue.  acc[m][f][r]: cout co0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel row oy0 + 4 wave + 2 f + prow,
+        // column ox0 + pcol
+        const float inv = 1.0f / (sx * a.w_scale);
+        const int64_t osn = (int64_t)d.cout * d.ho * d.wo, osc = (int64_t)d.ho * d.wo;
+        const int64_t obase = (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * d.wo + ox0 + pcol;
+        // (the epilogue's mode is decided ONCE, by uniform branches around straight-line copies: tested per element the compiler emits a
+        //  branch per store.)  A cout fragment's operands are requested together, before its first store.
+        auto epilogue = [&](auto mode, auto with_bias) {
+            constexpr int EPI = decltype(mode)::value;             // 0 none, 1 x act'(z), 2 + res
+            constexpr bool BIAS = decltype(with_bias)::value;
+            const float* op = EPI == 1 ? d.dact_z : d.res;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float bias[16], opnd[2][16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias[r] = BIAS ? d.bias[co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
+                if (EPI != 0) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            opnd[f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo];
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[m][f][r] * inv + bias[r];
+                        if (EPI == 1) v *= sda_dact(SDA_ACT_SILU, opnd[f][r]);
+                        if (EPI == 2) v += opnd[f][r];
+                        amax = fmaxf(amax, fabsf(v));
+                        if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo] = v;
+                    }
+            }
+        };
+        using h2_c0 = std::integral_constant<int, 0>;
+        using h2_c1 = std::integral_constant<int, 1>;
+        using h2_c2 = std::integral_constant<int, 2>;
+        if (d.dact_z) {
+            if (d.bias) epilogue(h2_c1{}, std::true_type{}); else epilogue(h2_c1{}, std::false_type{});
+        } else if (d.res) {
+            if (d.bias) epilogue(h2_c2{}, std::true_type{}); else epilogue(h2_c2{}, std::false_type{});
+        } else {
+            if (d.bias) epilogue(h2_c0{}, std::true_type{}); else epilogue(h2_c0{}, std::false_type{});
+        }
     }
     if (a.out_amax) {
 #pragma unroll
@@ -387,10 +416,11 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const sda_conv_desc d, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight packing
-// dst (16-byte units): (((((ct * nchunk + chunk) * 9 + tap) * 2 + ks) * 3 + m) * 2 + piece) * 64 + lane  ->  8 halves:
-//   forward  (transpose = 0): W[co = 96 ct + 32 m + (lane & 31)][ci = 32 chunk + 16 ks + 8 (lane >> 5) + i][tap]
+// dst (16-byte units): ((((ct * nchunk + chunk) * 9 + tap) * 3 + m) * 2 + piece) * 64 + lane  ->  8 halves  (chunk: 16 channels):
+//   forward  (transpose = 0): W[co = 96 ct + 32 m + (lane & 31)][ci = 16 chunk + 8 (lane >> 5) + i][tap]
 //   backward (transpose = 1): the operator of the input VJP -- its "cout" is the forward cin and vice versa, taps flipped:
-//                             W[co = 32 chunk + 16 ks + 8 (lane >> 5) + i][ci = 96 ct + 32 m + (lane & 31)][8 - tap]
+//                             W[co = 16 chunk + 8 (lane >> 5) + i][ci = 96 ct + 32 m + (lane & 31)][8 - tap]
+// A (cout tile, chunk) slab is 54 KiB, contiguous: the LDS image of a stage, copied by LDS-DMA.
 __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, int transpose, float scale, h2_h8* __restrict__ dst,
                                int64_t units) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,7 +429,6 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
     int64_t t = u >> 6;
     const int piece = (int)(t & 1); t >>= 1;
     const int m = (int)(t % 3); t /= 3;
-    const int ks = (int)(t & 1); t >>= 1;
     const int tap = (int)(t % 9); t /= 9;
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;     // operator rows / contraction
     const int nchunk = K / H2_CK;
@@ -409,7 +438,7 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
     h2_h8 out;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int k = H2_CK * chunk + 16 * ks + 8 * (lane >> 5) + i;
+        const int k = H2_CK * chunk + 8 * (lane >> 5) + i;
         float v = 0.f;
         if (row < M) {
             const int co = transpose ? k : row, ci = transpose ? row : k, tp = transpose ? 8 - tap : tap;
@@ -423,8 +452,8 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
 
 extern "C" int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose) {
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;
-    if (M <= 0 || K <= 0 || M % H2_BM || K % H2_CK) return 0;
-    return (int64_t)(M / H2_BM) * (K / H2_CK) * 9 * 2 * 3 * 2 * 64 * 16;
+    if (M <= 0 || K <= 0 || M % H2_BM || K % H2_KQ) return 0;
+    return (int64_t)(M / H2_BM) * (K / H2_CK) * H2_ASLAB;
 }
 
 extern "C" float sda_conv_h2_scale(float amax) { return h2_scale_of(amax); }
@@ -482,7 +511,7 @@ static bool h2_ok(const sda_conv_desc* d) {
         d->zins_h != 1 || d->zins_w != 1 || d->pool_h > 1 || d->pool_w > 1)
         return false;
     if (d->cctx != 0 || d->n_inner != 1 || d->x_n_off != 0) return false;
-    if (d->cx % H2_CK || d->cout % H2_BM || d->ho != d->hs || d->wo != d->ws || d->ho % H2_TS || d->wo % H2_TS) return false;
+    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != d->hs || d->wo != d->ws || d->ho % H2_TS || d->wo % H2_TS) return false;
     if (d->out_sn || d->out_sc || d->out_sy || d->out_sx) return false;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return false;
     if (d->mod && !d->ln_mean) return false;
@@ -494,7 +523,7 @@ static bool h2_ok(const sda_conv_desc* d) {
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
     const int64_t tiles = (int64_t)d->n * (d->ho / H2_TS) * (d->wo / H2_TS) * (d->cout / H2_BM);
-    return tiles >= 1 && tiles <= 0x7fffffffLL;
+    return tiles >= 1 && tiles <= 0x3fffffffLL;
 }
 
 extern "C" int sda_conv_h2_supported(const sda_conv_desc* d) { return h2_ok(d) ? 1 : 0; }
@@ -513,7 +542,12 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.nchunk = d->cx / H2_CK;
     if (!(a.w_scale > 0.f) || (!a.x_amax && !(a.x_amax_static > 0.f))) return SDA_E_BADARG;
     const int lds = H2_LDS;
-    const unsigned grid = (unsigned)((int64_t)d->n * a.tiles_x * a.tiles_y * a.n_ct);
+    a.ntiles = (int)((int64_t)d->n * a.tiles_x * a.tiles_y * a.n_ct);
+    // persistent workgroups, one per CU (the stage buffers take the whole LDS); a multiple of 8 keeps the XCD-contiguous tile walk
+    int cus = sda_cu_count();
+    if (cus <= 0) cus = 256;
+    unsigned grid = (unsigned)(a.ntiles < cus ? a.ntiles : cus);
+    if (grid >= 8) grid &= ~7u;
     int rc = SDA_OK;
 #ifdef SDA_H2_ABLATE
     {
@@ -522,7 +556,7 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
         const void* fn = nullptr;
 #define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, v>); \
             if (!d->ln_mean && d->act_in == SDA_ACT_NONE) { if ((rc = sda_raise_dyn_lds(fn, lds, seta[v])) != SDA_OK) return rc; \
-                hipLaunchKernelGGL((conv_h2_kernel<0, v>), dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
+                hipLaunchKernelGGL((conv_h2_kernel<0, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
         switch (abl) {
             H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(15)
             default: break;
@@ -532,15 +566,15 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     if (d->ln_mean) {
         static bool set2[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2>), lds, set2)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<2>, dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, *d, a);
+        hipLaunchKernelGGL(conv_h2_kernel<2>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
     } else if (d->act_in != SDA_ACT_NONE) {
         static bool set1[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<1>), lds, set1)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<1>, dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, *d, a);
+        hipLaunchKernelGGL(conv_h2_kernel<1>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
     } else {
         static bool set0[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0>), lds, set0)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<0>, dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, *d, a);
+        hipLaunchKernelGGL(conv_h2_kernel<0>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
     }
     return sda_launch_status();
 }
