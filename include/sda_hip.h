@@ -134,7 +134,7 @@ typedef struct sda_conv_desc {
      *         bound of it -- sda_absmax of the tensor, or the out_amax of the launch that produced it; NULL: x_amax_static (a bound
      *         known on the host: sqrt(channels) behind a LayerNorm).  The kernel derives the power-of-two input scale from it.
      *   out_amax: optional device scalar, atomically maxed (as uint bits; the caller zeroes it) with max |out| of this launch.
-     * Served by sda_conv_h2 for 3 x 3 / stride 1 / cin % 32 == 0 / cout % 96 == 0 / 16 x 16-tileable planar launches with the loader
+     * Served by sda_conv_h2 for 3 x 3 / stride 1 / cin % 96 == 0 / cout % 96 == 0 / 16 x 16-tileable planar launches with the loader
      * fusions none / activation / (modulation +) LayerNorm and the epilogues bias, x act'(z), + res; sda_conv_igemm ignores the
      * fields.  Error against float64 equals the fp32 Winograd kernel's (3e-7, tools/f16_split_numerics.py). */
     const void* w_h2;

@@ -11,25 +11,36 @@
 // is three v_mfma_f32_32x32x16_f16 (32 cycles each from one wave) per 32 couts x 32 pixels x 16 channels where the fp32 pipe needs sixteen
 // v_mfma_f32_16x16x4_f32 (32 cycles each): 96 cycles against 512, 5.3x per multiply -- more than Winograd F(2x2,3x3) saves (2.25x), so this
 // kernel is a DIRECT convolution: no transforms, no transform-domain round-off, no helper-wave arithmetic.  (The 16x16x32 shape issues
-// only every 25 cycles from a single wave -- profiles/r04_bf16x6_prototype.txt, and this kernel's first version: 28 per MFMA.)  Measured against float64 (tools/f16_split_numerics.py): the same 3e-7 relative error as the
-// fp32 Winograd kernel.
+// only every 25 cycles from a single wave -- profiles/r04_bf16x6_prototype.txt, and this kernel's first version: 28 per MFMA.)
+// Measured against float64 (tools/f16_split_numerics.py, tools/h2_check.py): the error class of the fp32 Winograd kernel
+// (max |err| / max |ref| 1e-7 .. 1.9e-6 over the layer shapes, the fp32 kernels 2e-7 .. 1.9e-6).
 //
-// Structure (one workgroup = 4 waves, one per SIMD, up to 512 registers each; tile = 96 couts x 16 x 16 pixels of one image):
-//   * K loop over chunks of 32 input channels.  The chunk's 18 x 18 halo tile lives in LDS as [pixel][hi: 32 halves | lo: 32 halves]
-//     (+ 32 B pad per pixel and 16 B per halo row: the ds_read_b128 of a 2 x 16-pixel fragment is conflict-free), double buffered, ONE barrier per
-//     chunk.  Every wave fills its quarter of the next chunk's tile while it multiplies the current one: wave w owns channels 8 w .. 8 w + 7
-//     -- global loads (padding / wrap resolved once per tile), the loader fusions of the reference's blocks (time modulation +
-//     LayerNorm, or the activation; sda/nn.py:28,137-139), the split, two 16-byte LDS stores per pixel.  The f16 MFMA leaves three
-//     issue slots per instruction free, and the loader needs ~330 of a chunk's ~1 900.
-//   * per tap and chunk a wave multiplies 2 K steps x 3 cout fragments x 2 pixel fragments (two tile rows each) x 3 products = 36
-//     MFMAs.  B: eight ds_read_b128 (the tap is a pixel offset into the halo tile).  A: the tap's 12 KiB of packed weights
-//     (sda_pack_conv_weight_h2: fragments in lane order) go through a two-slot LDS ring -- every wave fetches a quarter (three
-//     global_load_dwordx4, three taps ahead) and stores it two taps ahead, one barrier per tap, twelve ds_read_b128 per wave one tap
-//     ahead.  (First version: every wave fetched all twelve fragments itself -- 4 x the L1 traffic, and the kernel ran as slowly with
-//     its MFMAs removed: profiles/r05_h2_ablation.txt.)
-//   * epilogue: x 1 / (s_x s_w), + bias, x act'(z) or + residual, 64-byte row segments; optionally max |out| (one atomic per wave)
-//     so that the NEXT h2 launch knows its input scale without a pass over the tensor.
-// Roofline: f16 matrix pipe (2.5 PFLOP/s dense / 3 products); algorithmic bytes: x once per 96-cout tile x 1.27 (halo), out once.
+// Structure (round 5, seventh version; one PERSISTENT workgroup per CU = 4 consumer + 4 producer waves, <= 256 registers each; tile = 96
+// couts x 16 x 16 pixels of one image; csrc/conv_par4.hip is the same pattern on the fp32 pipe):
+//   * K loop in stages of 16 input channels (one K step of the MFMA).  A stage in LDS = the cout tile's weight slab for all nine taps
+//     ([tap][cout fragment][piece][lane] x 16 B = 54 KiB, the packing's own order) + the 18 x 18 halo tile as [pixel][hi: 16 halves |
+//     lo: 16 halves | 16 B pad] (26 KiB); two stage buffers = 162 432 B of the CU's 163 840; ONE barrier per stage.
+//   * producers (one stage ahead of the consumers): the slab by LDS-DMA (inline asm global_load_lds_dwordx4, 54 pieces of 1 KiB over
+//     the four waves; hipcc neither counts it nor drains vmcnt around it), the tile through registers: wave = 8 channels x half of the
+//     halo pixels, lane = pixel -- global loads (padding / wrap resolved once per tile; scalar channel bases + one 32-bit lane offset),
+//     the loader fusions of the reference's blocks (time modulation + LayerNorm, or the activation; sda/nn.py:28,137-139), the split,
+//     two ds_write_b128 per pixel.  A stage's values are REQUESTED TWO STAGES AHEAD (three register sets; an HBM round trip under load
+//     is longer than one stage's 2.2 us of multiplies) and waited for with a counted vmcnt: the loads are issued after the stage's DMA,
+//     so "at most the 24 newest outstanding" = the DMA has landed and so have the next stage's values.
+//   * consumers: per tap 6 + 4 ds_read_b128 (one tap ahead, interleaved 1 : 1 with the first MFMAs) feed 3 cout fragments x 2 pixel
+//     fragments x 3 products = 18 v_mfma_f32_32x32x16_f16; nothing else in the loop (no vector ALU, no vector memory).  The B fragment's
+//     MFMA column -> pixel map follows ds_read_b128's lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: one LDS cycle
+//     each): a group reads 16 consecutive pixels of one halo row at 80 B = 20 banks apart -- all 64 banks once, no row padding
+//     (SQ_LDS_BANK_CONFLICT = 0, profiles/r05_h2_pmc_v7_384ch.txt).
+//   * persistent schedule: workgroup b (XCD b % 8) takes, pass after pass, a run of consecutive logical tiles together with its XCD's
+//     other 31 workgroups (halo lines and weight slabs meet in one L2); the producers run across tile boundaries, so the next tile's
+//     first stage is in LDS when the consumers come back from their epilogue.
+//   * epilogue (consumers): x 1 / (s_x s_w), + bias, x act'(z) or + residual, 64-byte row segments; optionally max |out| (one atomic
+//     per wave and LAUNCH) so that the NEXT h2 launch knows its input scale without a pass over the tensor.
+// Roofline: f16 matrix pipe (2.5 PFLOP/s dense / 3 products).  What that pipe SUSTAINS on this data is less: with full-mantissa random
+// halves in the operands the power-managed clock falls to 1.64 GHz (tools/h2_power_probe.hip: 1 592 TFLOP/s = 0.64 of the nominal
+// peak with this kernel's LDS operand traffic, 2 411 on zeros); the kernel's counters show the matrix pipe busy 0.83 of its cycles
+// at 1.45 GHz (profiles/r05_h2_pmc_v7_384ch.txt).  Algorithmic bytes: x once per 96-cout tile x 1.27 (halo), out once.
 #include "sda_common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
 #pragma unroll
             for (int r = 0; r < H2_PRND; ++r)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) asm volatile("; landed %0" : "+v"(v[r][i]));
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[r][i]));
         };
         plan_t P0, P1;
         int it = 0;
