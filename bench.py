@@ -501,6 +501,53 @@ def launch_plan(gpus, env, argv):
             '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def second_line(args, sde, sampler, b, device, f32_s_per_step):
+    """The OPT-IN line: the same captured step with the block convolutions on the f16 matrix cores (csrc/conv_h2.hip: every fp32
+    operand as two halves, three products, fp32 accumulation), timed like the headline (graph replay, sync on both sides), plus one
+    eager step from the SAME state and noise under both multiplies -- how far apart the two arithmetic routes land."""
+    from sda_amd import ops
+    kw = dict(steps=1000, corrections=args.corrections, tau=args.tau)
+    try:
+        sampler._graph = None
+        del sampler
+        torch.cuda.empty_cache()
+        ops.set_multiply('f32')
+        sa = sde.sampler((b,), **kw)
+        sa.step()
+        xa = sa.x.clone()
+        del sa
+        ops.set_multiply('f16x2')
+        sb = sde.sampler((b,), **kw)
+        sb.step()
+        diff = ((sb.x - xa).abs().max() / xa.abs().max()).item()
+        del sb, xa
+        torch.cuda.empty_cache()
+        s2 = sde.sampler((b,), **kw)
+        note = None
+        if args.graph:
+            try:
+                s2.capture()
+            except Exception as e:  # noqa: BLE001
+                note = f'capture failed, ran eagerly: {type(e).__name__}: {str(e)[:160]}'
+                s2 = sde.sampler((b,), **kw)
+        s2.step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.second_steps):
+            s2.step()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / args.second_steps
+        return {'multiply': 'f16x2', 'dtype': 'f32 emulated as 2 x f16 (three f16 products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulate)',
+                'ms_per_step': dt * 1e3, 'value': 1.0 / dt, 'unit': 'diffusion-steps/s', 'steps': args.second_steps, 'warmup': 1,
+                'speedup_vs_f32_headline': f32_s_per_step / dt, 'samples_finite': bool(torch.isfinite(s2.x).all().item()),
+                'one_step_max_abs_diff_vs_f32_over_max_abs': diff, 'hipgraph_note': note,
+                'note': 'OPT-IN (ops.set_multiply / SDA_MULTIPLY=f16x2); `value` above is the fp32-MFMA headline'}
+    except Exception as e:  # noqa: BLE001 -- the second line must never cost the headline
+        return {'multiply': 'f16x2', 'error': f'{type(e).__name__}: {str(e)[:300]}'}
+    finally:
+        ops.set_multiply('f32')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -524,6 +571,10 @@ def main():
     ap.add_argument('--multiply', default='f32', choices=['f32', 'f16x2'],
                     help="f32 (default, the headline): fp32 MFMAs.  f16x2 (OPT-IN second line): the block convolutions multiply on the f16 matrix "
                          "cores, every fp32 operand as two halves, three products, fp32 accumulation (csrc/conv_h2.hip)")
+    ap.add_argument('--second-line', type=int, default=1,
+                    help="1 (default; N = 1, Kolmogorov-shaped workloads, --multiply f32): after the f32 headline, time the same step with "
+                         "--multiply f16x2 and report it as the `opt_in_f16x2` object of the same JSON line (never `value`)")
+    ap.add_argument('--second-steps', type=int, default=3)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -665,6 +716,8 @@ def main():
             out['kernel_library_override'] = os.environ['SDA_HIP_LIB']
         if prof is not None and prof_steps > 0:
             out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT, probe)
+        if world == 1 and args.second_line and args.multiply == 'f32' and wl['kind'] == 'kolmogorov':
+            out['opt_in_f16x2'] = second_line(args, sde, sampler, b, device, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, args, bool(args.guided), args.corrections)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
