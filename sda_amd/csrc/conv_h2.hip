@@ -82,6 +82,7 @@ struct h2_args {
     float x_amax_static;
     float* out_amax;            // device (optional): atomically maxed with |out| as uint bits
     int tiles_x, tiles_y, n_ct, nchunk, ntiles;
+    int stagger;                // (tooling) start delay of workgroup slot s: (s & 3) * stagger * 8 128 cycles
 };
 
 // barrier of the 4 + 4 waves.  Not __syncthreads(): that also drains vmcnt, and a consumer's epilogue stores (gfx9 counts stores in
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
     //  replay of a captured step is not good enough)
     const float sx = h2_scale_of(a.x_amax ? __hip_atomic_load(a.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.x_amax_static);
 
+#ifdef SDA_H2_ABLATE
+    for (int i = 0; i < (slot & 3) * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     if (wave >= 4) {
         // ================================================================ producers: global -> (loader fusions, split) -> LDS
         const int pw = wave - 4;
@@ -551,6 +555,10 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.tiles_y = d->ho / H2_TS;
     a.n_ct = d->cout / H2_BM;
     a.nchunk = d->cx / H2_CK;
+    a.stagger = 0;
+#ifdef SDA_H2_ABLATE
+    { static const int stg = getenv("SDA_H2_STAGGER") ? atoi(getenv("SDA_H2_STAGGER")) : 0; a.stagger = stg; }
+#endif
     if (!(a.w_scale > 0.f) || (!a.x_amax && !(a.x_amax_static > 0.f))) return SDA_E_BADARG;
     const int lds = H2_LDS;
     a.ntiles = (int)((int64_t)d->n * a.tiles_x * a.tiles_y * a.n_ct);
@@ -569,7 +577,7 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
             if (!d->ln_mean && d->act_in == SDA_ACT_NONE) { if ((rc = sda_raise_dyn_lds(fn, lds, seta[v])) != SDA_OK) return rc; \
                 hipLaunchKernelGGL((conv_h2_kernel<0, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
         switch (abl) {
-            H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(15)
+            H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(11) H2_ABL_CASE(15)
             default: break;
         }
     }
