@@ -324,7 +324,13 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
                    'floor_us_per_step_bracketed_kernels': 1.7 * n_launch}
     return {'bound': 'latency' if latency else 'mfma', 'latency': latency,
             'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F16 if dom == 'h2' else PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-            'frac': d.get('mfma_util'), 'clock': clock, 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
+            'frac': d.get('mfma_util'),
+            # SURVEY 8(d)'s definition (ALGORITHMIC flops of the direct convolution / time / peak) next to the issued one: above 1 for a
+            # Winograd kernel (it issues 1 / 2.25 of them), a third of `frac`'s numerator for the three-product f16 x 2 kernel
+            'frac_algorithmic': None if d.get('algorithmic_tflops') is None else d['algorithmic_tflops'] / (PEAK_MFMA_F16 if dom == 'h2' else PEAK_MFMA_F32),
+            'sustained_note': ('tools/h2_power_probe.hip (profiles/r05_h2_power_probe.txt): on full-mantissa random halves this instruction mix '
+                               'sustains 1 592 TFLOP/s = 0.64 of the quoted peak (power-managed clock 1.64 GHz; 2 411 on zeros)') if dom == 'h2' else None,
+            'clock': clock, 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
             'traffic_is': 'HBM/fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE '
                           '(calibrated on known byte counts in the kernel\'s own access shapes, tools/fetch_calib.hip); compare with '
