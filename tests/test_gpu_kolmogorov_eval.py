@@ -16,6 +16,7 @@
      against two independent runs of the oracle's loop for what the algorithm itself biases.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -24,6 +25,11 @@ from oracle import sda_oracle as O
 from tests.util import oracle_eps_from_module, rel_err
 
 pytestmark = pytest.mark.gpu
+# The oracle runs on the host: one guided K64 evaluation at 64 x 64 costs it ~2.5 s in fp32 and ~5 s in fp64, so the routine suite keeps
+# the chains short (8 free-running steps = 16 guided evaluations deep; 96 trajectories x 64 steps for the statistics: ~3 min in all).
+# SDA_LONG_TESTS=1 runs the long forms (32 steps, B = 1 and 2; 256 trajectories x 128 steps: ~25 min of host time) -- green on the
+# round-5 build, profiles/r05_gputest_237_long_variants.log.
+LONG = os.environ.get('SDA_LONG_TESTS', '0') == '1'
 K64 = dict(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
 
 
@@ -47,7 +53,7 @@ def _sub4(x):
     return x[..., ::4, ::4]
 
 
-@pytest.mark.parametrize('batch', [1, 2])
+@pytest.mark.parametrize('batch', [1, 2] if LONG else [1])
 def test_k64_free_running_guided_hipgraph_vs_oracle(dev, k64, batch):
     import bench
     from sda_amd import observe as Ob
@@ -55,7 +61,7 @@ def test_k64_free_running_guided_hipgraph_vs_oracle(dev, k64, batch):
     from sda_amd.score import GaussianScore, VPSDE
     net, eps_net = k64
     net.to(dev)
-    steps, corr, tau, std, gamma = 32, 1, 0.5, 0.1, 1e-2
+    steps, corr, tau, std, gamma = (32 if LONG else 8), 1, 0.5, 0.1, 1e-2
     event = (6, 2, 64, 64)
     torch.manual_seed(71 + batch)
     x1 = torch.randn((batch,) + event)
@@ -132,7 +138,7 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     from sda_amd.score import GaussianScore, VPSDE
     net, _ = k64
     net.to(dev)
-    B, L, steps, corr, tau, std, gamma = 256, 6, 128, 1, 0.5, 0.1, 1e-2
+    B, L, steps, corr, tau, std, gamma = (256 if LONG else 96), 6, (128 if LONG else 64), 1, 0.5, 0.1, 1e-2
     event = (L, 2, 64, 64)
     torch.manual_seed(80)
     y = torch.randn(_sub4(torch.empty(event)).shape) * math.sqrt(1 + std ** 2)        # y = A x + noise, x ~ N(0, I)
@@ -175,7 +181,7 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     assert z_cal < zcrit, f'oracle run vs oracle run: {z_cal:.1f} sigma -- the yardstick itself is off'
     assert z_s < zcrit, (f'per-trajectory log (A(x) - y).std(): GPU {lg.mean():.3f} vs oracle {la.mean():.3f} ({z_s:.1f} sigma; oracle pair '
                          f'{z_cal:.1f} sigma)')
-    assert abs(lg.std().item() / la.std().item() - 1) < 0.25                                  # and the same dispersion
+    assert abs(lg.std().item() / la.std().item() - 1) < (0.25 if LONG else 0.4)               # and the same dispersion (sd of the ratio ~ 1 / sqrt(B))
     # (c) unobserved pixels keep the prior N(0, 1): mean, and variance as the oracle's loop leaves it
     mask = torch.ones(64, 64, dtype=torch.bool)
     mask[::4, ::4] = False
