@@ -26,7 +26,7 @@ from tests.util import oracle_eps_from_module, rel_err
 
 pytestmark = pytest.mark.gpu
 # The oracle runs on the host: one guided K64 evaluation at 64 x 64 costs it ~2.5 s in fp32 and ~5 s in fp64, so the routine suite keeps
-# the chains short (8 free-running steps = 16 guided evaluations deep; 96 trajectories x 64 steps for the statistics: ~3 min in all).
+# the chains short (8 free-running steps = 16 guided evaluations deep; 64 trajectories x 128 steps for the statistics: ~3 min in all).
 # SDA_LONG_TESTS=1 runs the long forms (32 steps, B = 1 and 2; 256 trajectories x 128 steps: ~25 min of host time) -- green on the
 # round-5 build, profiles/r05_gputest_237_long_variants.log.
 LONG = os.environ.get('SDA_LONG_TESTS', '0') == '1'
@@ -138,7 +138,7 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     from sda_amd.score import GaussianScore, VPSDE
     net, _ = k64
     net.to(dev)
-    B, L, steps, corr, tau, std, gamma = (256 if LONG else 96), 6, (128 if LONG else 64), 1, 0.5, 0.1, 1e-2
+    B, L, steps, corr, tau, std, gamma = (256 if LONG else 64), 6, 128, 1, 0.5, 0.1, 1e-2      # (128 steps: at 64 the reference ALGORITHM's own slope is 0.986, not 0.990)
     event = (L, 2, 64, 64)
     torch.manual_seed(80)
     y = torch.randn(_sub4(torch.empty(event)).shape) * math.sqrt(1 + std ** 2)        # y = A x + noise, x ~ N(0, I)
