@@ -219,17 +219,21 @@ def cpu_baseline(wl, args, guided, corrections):
     torch.set_num_threads(cores)
     # >= 1 untimed warm-up step, then >= 3 timed steps, more while the budget lasts
     xx = one_step(x, 0)
-    steps_done, t_spent, i = 0, 0.0, 1
+    steps_done, t_spent, i, per_step = 0, 0.0, 1, []
     while steps_done < 3 or (t_spent < args.cpu_seconds and steps_done < 50):
         t0 = time.perf_counter()
         xx = one_step(xx, i)
-        t_spent += time.perf_counter() - t0
+        per_step.append(time.perf_counter() - t0)
+        t_spent += per_step[-1]
         steps_done += 1
         i += 1
     sample_steps_per_s = steps_done / t_spent
+    per_step.sort()
     value = sample_steps_per_s * nwin / total_windows        # cost is linear in windows / trajectories
     return dict(value=value, unit='diffusion-steps/s (same per-GPU shard, extrapolated linearly from the sample)',
                 cores=cores, kind='port', cpu_model=_cpu_model(), host_logical_cpus=ncpu, threads_chosen_by=probe,
+                # (how soft the figure is: the spread of the timed steps themselves; box to box it has been +-20 %)
+                sample_step_s={'min': per_step[0], 'median': per_step[len(per_step) // 2], 'max': per_step[-1]},
                 sample=f'{steps_done} timed steps after 1 warm-up step ({t_spent:.1f} s, {t_spent / steps_done:.2f} s/step) of {unit}; '
                        f'guided={int(guided)}, corrections={corrections}; scaled by {nwin}/{total_windows}')
 
