@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 11
+#define SDA_ABI_VERSION 12
 
 enum {
     SDA_OK = 0,
@@ -315,6 +315,12 @@ int sda_ln_apply(const float* x, int n, int c, int hw, const float* mod, int64_t
 int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
                const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res, float* gx,
                void* stream);
+/* (ABI v12) the same, and amax[0] = max |gx| (device scalar, written by this call): the input scale of the OPT-IN f16 x 2 convolution
+ * that reads gx next (sda_conv_desc.x_amax) without an sda_absmax pass -- reduced in the kernel's own epilogue on the U-Net levels'
+ * 16-byte layouts, by an sda_absmax pass over gx otherwise. */
+int sda_ln_bwd_amax(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+                    const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res, float* gx,
+                    float* amax, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TimeEmbedding + every block's `project` Linear in one go (sda/score.py:15-35, sda/nn.py:132-135):

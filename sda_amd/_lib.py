@@ -194,6 +194,8 @@ SIGNATURES = {
     'sda_ln_apply': (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_fp, c_void_p]),
     'sda_ln_bwd': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,
                            c_void_p]),
+    'sda_ln_bwd_amax': (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int64, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,
+                           c_fp, c_void_p]),
     'sda_time_embed': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear_small': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_void_p]),
     'sda_linear': (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_void_p]),

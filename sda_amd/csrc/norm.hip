@@ -429,7 +429,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
                                                                  int64_t nquad, int c, int hw, int w, const float* __restrict__ mod,
                                                                  int64_t mod_sn, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, int unbiased,
-                                                                 const float* __restrict__ res, float* __restrict__ gx) {
+                                                                 const float* __restrict__ res, float* __restrict__ gx,
+                                                                 float* __restrict__ amax) {
     constexpr int QW = 64 / SPLIT;                          // quads per wavefront
     constexpr int WPB = LN_THREADS / 64;
     static_assert(WPB % NW == 0, "cooperating wavefronts must tile the workgroup");
@@ -507,14 +508,15 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
             s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
         }
     }
-    if (!live) return;
+    if (!live && !amax) return;
+    float am = 0.f;
     const float ia = 1.f / (float)c, ib = 1.f / (float)(unbiased ? c - 1 : c);
     const float4 a = make_float4(s1.x * ia, s1.y * ia, s1.z * ia, s1.w * ia);
     const float4 b = make_float4(s2.x * ib, s2.y * ib, s2.z * ib, s2.w * ib);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         const int k = sub + SPLIT * j;
-        if (k < c) {
+        if (k < c && live) {
             const int64_t off = base + (int64_t)k * hw;
             float4 v = make_float4(r4.x * (g[j].x - a.x - hh[j].x * b.x), r4.y * (g[j].y - a.y - hh[j].y * b.y),
                                    r4.z * (g[j].z - a.z - hh[j].z * b.z), r4.w * (g[j].w - a.w - hh[j].w * b.w));
@@ -523,7 +525,16 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_quad_kernel(const float* __
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             ln_st4<SPLIT == 8>(gx + off, v);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
+    }
+    // optional: max |gx| of the launch (as uint bits; zeroed by the launcher) -- the input scale of the f16 x 2 convolution that reads gx
+    // next (csrc/conv_h2.hip), without a pass over the tensor.  One atomic per wavefront, and only while it would still raise the value.
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+        if (lane == 0 && am > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(am));
     }
 }
 
@@ -571,10 +582,38 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_wave_kernel(const float* __
     }
 }
 
+__global__ void ln_amax_zero_kernel(float* __restrict__ amax) { amax[0] = 0.f; }
+
+static int ln_bwd_launch(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+                         const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res,
+                         float* gx, float* amax, bool* amax_served, void* stream);
+
 extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
                           const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res,
                           float* gx, void* stream) {
+    bool served = false;
+    return ln_bwd_launch(gh, x, n, c, h, w, mod, mod_sn, mean, rstd, unbiased, pool_h, pool_w, res, gx, nullptr, &served, stream);
+}
+
+// sda_ln_bwd that also reports amax[0] = max |gx| (device scalar): in the kernel's own epilogue on the 16-byte layouts of the U-Net
+// levels, by an sda_absmax pass over gx otherwise
+extern "C" int sda_ln_bwd_amax(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+                               const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res,
+                               float* gx, float* amax, void* stream) {
+    if (!amax) return SDA_E_BADARG;
+    bool served = false;
+    const int rc = ln_bwd_launch(gh, x, n, c, h, w, mod, mod_sn, mean, rstd, unbiased, pool_h, pool_w, res, gx, amax, &served, stream);
+    if (rc != SDA_OK || served) return rc;
+    if (reinterpret_cast<uintptr_t>(gx) & 15) return SDA_E_UNSUPPORTED;
+    return sda_absmax(gx, (int64_t)n * c * h * w, amax, stream);
+}
+
+static int ln_bwd_launch(const float* gh, const float* x, int n, int c, int h, int w, const float* mod, int64_t mod_sn,
+                         const float* mean, const float* rstd, int unbiased, int pool_h, int pool_w, const float* res,
+                         float* gx, float* amax, bool* amax_served, void* stream) {
     if (!gh || !x || !mean || !rstd || !gx || n <= 0 || c <= 0 || h <= 0 || w <= 0) return SDA_E_BADARG;
+    // (zeroed by a kernel, not a 4-byte memset: see sda_absmax)
+    if (amax) hipLaunchKernelGGL(ln_amax_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax);
     const int shape = pool_h * 10 + pool_w;          // 11: no pooling, 12: 1-D nets (length axis only), 22: 2-D nets
     if (shape != 11 && shape != 12 && shape != 22) return SDA_E_UNSUPPORTED;
     const int64_t npix = (int64_t)n * h * w;
@@ -606,25 +645,25 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         // (lanes per quad x channels per lane: c = 96: 8 x 12, 128-byte runs; c = 192 / 384: 16 x 12 / 16 x 24, 64-byte runs)
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c <= 192 && quad_mode == 4) {            // (A/B: two cooperating wavefronts, 8 lanes x 12 channels each)
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c > 192 && quad_mode == 4) {             // (A/B: four cooperating wavefronts)
             dim3 gr((unsigned)((nquad + 7) / 8));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 4>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 1, 4>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c <= 192 && quad_mode != 3) {
             // 8 lanes x 24 channels: 128-byte runs like the 96-channel level (one wavefront per SIMD -- 376 registers -- but with the
             // residual loads ahead of the reduction it beats 16 x 12's 64-byte runs: 1.21 -> 1.07 ms at 120 windows, 5.0 -> 5.65 TB/s;
             // before that change it lost, 4.48 vs 4.87.  SDA_LN_BWD_QUAD=3 keeps 16 x 12 for A/B.  384 channels as 32 x 12: 3.8 vs 5.0 TB/s)
             dim3 gr((unsigned)((nquad + 31) / 32));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c <= 192) {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         }
     } else if (shape == 11 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
         // lanes per pixel x channels per lane, picked per width from measurements on the Kolmogorov net's three levels
@@ -643,13 +682,13 @@ extern "C" int sda_ln_bwd(const float* gh, const float* x, int n, int c, int h, 
         const int64_t nquad = npix / 4;
         if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c <= 192) {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 12, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else {
             dim3 gr((unsigned)((nquad + 15) / 16));
-            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx);
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 24, 2>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         }
     } else if (shape == 22 && c > 48 && c <= 384 && blocks * 8 <= 0x7fffffffLL) {
         const int hw = h * w;

@@ -590,7 +590,9 @@ class UNetEngine:
         return saved
 
     # -------------------------------------------------------------------------------- backward-data
-    def _block_bwd(self, blk: _Block, g: Tensor, rec, mod_all, lo, per_image):
+    def _block_bwd(self, blk: _Block, g: Tensor, rec, mod_all, lo, per_image, g_amax_in=None):
+        """-> (gradient w.r.t. the block's input, device scalar with its max |.| or None).  g_amax_in: max |g| as its producer reported
+        it (an ln_bwd launch of the previous block / tail); None: an ops.absmax pass when the f16 x 2 route needs the scale."""
         a, mean, rstd, z = rec
         n, c, h, w = a.shape
         mod, mod_sn = self._mod_for(blk, mod_all, lo, per_image)
@@ -599,12 +601,13 @@ class UNetEngine:
                 ops.block1d_eligible(c, h, c1.fwd(), c2.fwd())):
             gx = torch.empty_like(a)
             ops.block1d_bwd(g, a, z, mean, rstd, mod, mod_sn, c1.bwd(), c2.bwd(), c1.circular, blk.act, self.unbiased, gx)
-            return gx
+            return gx, None
         gz = torch.empty_like(a)
         pk2 = c2.bwd()
         g_amax = gz_amax = None
         if getattr(pk2, 'h2', None) is not None and g.is_contiguous():
-            g_amax, gz_amax = ops.absmax(g, pk2.in_amax), pk2.out_amax      # (one streaming read of g: its producer is not an h2 launch)
+            # (the producer's own report, else one streaming read of g)
+            g_amax, gz_amax = (g_amax_in if g_amax_in is not None else ops.absmax(g, pk2.in_amax)), pk2.out_amax
         d2 = launch_conv(pk2, planar_source(g), gz, h, w, circular=c2.circular, dact_z=z, act_d=blk.act, x_amax=g_amax, out_amax=gz_amax)
         if not (d2 is not None and d2.w_h2):
             gz_amax = None
@@ -612,8 +615,14 @@ class UNetEngine:
         c1 = blk.conv1
         launch_conv(c1.bwd(), planar_source(gz), gh, h, w, circular=c1.circular, x_amax=gz_amax)
         gx = torch.empty_like(a)
-        ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, (1, 1), g, gx)
-        return gx
+        gx_amax = None
+        if getattr(pk2, 'h2', None) is not None:
+            # f16 x 2 route: the consumer of gx is (mostly) the previous block's conv2^T -- report max |gx| from this launch
+            gx_amax = getattr(blk, '_gx_amax', None)
+            if gx_amax is None or gx_amax.device != a.device:
+                gx_amax = blk._gx_amax = torch.zeros(1, device=a.device, dtype=torch.float32)
+        ops.ln_bwd(gh, a, h, w, mod, mod_sn, mean, rstd, self.unbiased, (1, 1), g, gx, out_amax=gx_amax)
+        return gx, gx_amax
 
     def backward_chunk(self, saved, g_out: Tensor, src: Source, lo: int, mod_all, per_image: bool, g_in: Tensor):
         """g_out: (n, out_channels, h, w) -> g_in: (n, src.cx, hs, ws)   (context-channel gradients are not formed)."""
@@ -628,6 +637,7 @@ class UNetEngine:
         tl = L[0].tail
         g = torch.empty(n, L[0].C, h, w, device=dev, dtype=torch.float32)
         launch_conv(tl.bwd(), planar_source(g_out), g, h, w, circular=tl.circular)
+        g_amax = None                                    # max |g| as reported by g's producer (ln_bwd launches), f16 x 2 route only
         g_skip = {}
         for lvl in range(D):
             lev = L[lvl]
@@ -653,16 +663,21 @@ class UNetEngine:
                     ghup = torch.empty(n, lev.C, hu, wu, device=dev, dtype=torch.float32)
                     launch_conv(tl.bwd(), planar_source(g), ghup, hu, wu, circular=tl.circular)
                 g = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
+                g_amax = None
+                if ops.MULTIPLY == 'f16x2':
+                    g_amax = getattr(lev, '_g_amax', None)
+                    if g_amax is None or g_amax.device != dev:
+                        g_amax = lev._g_amax = torch.zeros(1, device=dev, dtype=torch.float32)
                 if pooled is not None:
-                    ops.ln_bwd(pooled, a, h, w, None, 0, mean, rstd, self.unbiased, (1, 1), None, g)
+                    ops.ln_bwd(pooled, a, h, w, None, 0, mean, rstd, self.unbiased, (1, 1), None, g, out_amax=g_amax)
                 else:
-                    ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, (uh, uw), None, g)
+                    ops.ln_bwd(ghup, a, h, w, None, 0, mean, rstd, self.unbiased, (uh, uw), None, g, out_amax=g_amax)
             for bi in reversed(range(len(lev.ascent))):
-                g = self._block_bwd(lev.ascent[bi], g, saved['blocks'][('a', lvl, bi)], mod_all, lo, per_image)
+                g, g_amax = self._block_bwd(lev.ascent[bi], g, saved['blocks'][('a', lvl, bi)], mod_all, lo, per_image, g_amax)
         for lvl in reversed(range(D)):
             lev = L[lvl]
             for bi in reversed(range(len(lev.descent))):
-                g = self._block_bwd(lev.descent[bi], g, saved['blocks'][('d', lvl, bi)], mod_all, lo, per_image)
+                g, g_amax = self._block_bwd(lev.descent[bi], g, saved['blocks'][('d', lvl, bi)], mod_all, lo, per_image, g_amax)
             hd = lev.head
             if lvl > 0:
                 hu, wu = dims[lvl - 1]
@@ -694,6 +709,7 @@ class UNetEngine:
                     launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw),
                                 res=skip)
                 g = g2
+                g_amax = None                            # (produced by a convolution of the fp32 families: no report)
             else:
                 launch_conv(hd.bwd(cin_keep=src.cx), planar_source(g), g_in, src.hs, src.ws, circular=hd.circular,
                             zins=(hd.sh, hd.sw))

@@ -470,15 +470,21 @@ def ln_apply(x: Tensor, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: 
 
 
 def ln_bwd(gh: Tensor, x: Tensor, h: int, w: int, mod: Optional[Tensor], mod_sn: int, mean: Tensor, rstd: Tensor,
-           unbiased: bool, pool, res: Optional[Tensor], gx: Tensor):
-    """pool: (pool_h, pool_w) -- the nearest-upsample factors whose backward (cell sums of gh) is fused in; (1, 1) = none."""
-    _dev(gh, x, mod, mean, rstd, res, gx)
+           unbiased: bool, pool, res: Optional[Tensor], gx: Tensor, out_amax: Optional[Tensor] = None):
+    """pool: (pool_h, pool_w) -- the nearest-upsample factors whose backward (cell sums of gh) is fused in; (1, 1) = none.
+    out_amax (device scalar, optional): receives max |gx| -- the input scale of an f16 x 2 convolution that reads gx next."""
+    _dev(gh, x, mod, mean, rstd, res, gx, out_amax)
     n, c = x.shape[0], x.shape[1]
 
     def launch():
-        _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
-                                          rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(),
-                                          _stream()), 'sda_ln_bwd')
+        if out_amax is None:
+            _lib.check(_lib.load().sda_ln_bwd(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
+                                              rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(),
+                                              _stream()), 'sda_ln_bwd')
+        else:
+            _lib.check(_lib.load().sda_ln_bwd_amax(gh.data_ptr(), x.data_ptr(), n, c, h, w, _ptr(mod), mod_sn, mean.data_ptr(),
+                                                   rstd.data_ptr(), int(unbiased), pool[0], pool[1], _ptr(res), gx.data_ptr(),
+                                                   out_amax.data_ptr(), _stream()), 'sda_ln_bwd_amax')
     if conv_profile is not None:
         # read gh (at the pooled resolution), x, res; write gx; + the statistics
         nb = 4.0 * n * h * w * (c * (pool[0] * pool[1] + 2 + (1 if res is not None else 0)) + 2)

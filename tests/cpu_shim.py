@@ -63,7 +63,7 @@ def install(monkeypatch):
         n = u.shape[0]
         y.copy_(((u - mean.reshape(n, 1, -1)) * rstd.reshape(n, 1, -1)).reshape(y.shape))
 
-    def ln_bwd(gh, x, h, w, mod, mod_sn, mean, rstd, unbiased, pool, res, gx):
+    def ln_bwd(gh, x, h, w, mod, mod_sn, mean, rstd, unbiased, pool, res, gx, out_amax=None):
         n, c = x.shape[:2]
         u = _u(x, mod, mod_sn)
         hh = (u - mean.reshape(n, 1, -1)) * rstd.reshape(n, 1, -1)
@@ -77,6 +77,8 @@ def install(monkeypatch):
         if res is not None:
             out = out + res.reshape(n, c, -1)
         gx.copy_(out.reshape(gx.shape))
+        if out_amax is not None:
+            out_amax.fill_(float(gx.abs().max()))
 
     def time_embed(t, freqs, w0, b0, w2, b2):
         ang = t.reshape(-1, 1) * freqs

@@ -216,3 +216,25 @@ def test_h2_free_running_guided_hipgraph_vs_fp32_oracle(dev, k64, f16x2):
     err = rel_err(got.double(), ref32.double())
     print(f'f16x2, K64 @ 64^2, {steps} guided PC steps through the hipGraph vs the fp32 oracle: {err:.2e}')
     assert torch.isfinite(got).all() and err <= 1e-4
+
+
+@pytest.mark.parametrize('c,h,w_,n,pool', [(96, 64, 64, 5, (1, 1)), (192, 64, 96, 3, (1, 1)), (384, 64, 64, 4, (1, 1)), (192, 64, 64, 4, (2, 2)),
+                                           (96, 32, 32, 3, (1, 1)), (40, 64, 64, 5, (1, 1)), (96, 6, 5, 1, (1, 1))])
+def test_ln_bwd_reports_the_max_of_its_output(dev, c, h, w_, n, pool):
+    """sda_ln_bwd_amax (ABI v12): the same gx bit for bit, and amax[0] = max |gx| -- from the kernel's own epilogue on the U-Net levels'
+    layouts (>= 16 384 pixels, 49 .. 384 channels), through an absmax pass on the others (few pixels; 40 channels) -- also when the scalar holds a larger stale value."""
+    from sda_amd import ops
+    torch.manual_seed(c + h)
+    x = torch.randn(n, c, h, w_, device=dev) * 3
+    mod = torch.randn(n, c, device=dev)
+    mean = torch.empty(n * h * w_, device=dev)
+    rstd = torch.empty_like(mean)
+    ops.ln_stats(x, mod, c, 1e-5, True, mean, rstd)
+    gh = torch.randn(n, c, pool[0] * h, pool[1] * w_, device=dev) * 10
+    res = torch.randn(n, c, h, w_, device=dev)
+    gx0, gx1 = torch.empty_like(x), torch.empty_like(x)
+    ops.ln_bwd(gh, x, h, w_, mod, c, mean, rstd, True, pool, res, gx0)
+    amax = torch.full((1,), 1e30, device=dev)
+    ops.ln_bwd(gh, x, h, w_, mod, c, mean, rstd, True, pool, res, gx1, out_amax=amax)
+    assert torch.equal(gx0, gx1)
+    assert amax.item() == gx1.abs().max().item()
