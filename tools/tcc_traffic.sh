@@ -1,7 +1,7 @@
 #!/bin/bash
 # where conv_wino4's (and conv_h2's) fabric traffic beyond the algorithmic bytes comes from.  L2 (TCC) request / hit / miss
 # and fabric-side (EA) read / write request counters of tools/w4_traffic.py's layer launches, one rocprofv3 pass per counter group
-# (counters alone: --kernel-trace only).   usage: tools/r05_tcc.sh <outdir>
+# (counters alone: --kernel-trace only).   usage: tools/tcc_traffic.sh <outdir>
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT="$1"; case "$OUT" in /*) ;; *) OUT="$R/$OUT" ;; esac
@@ -20,4 +20,4 @@ for mode in f32 f16x2; do
   run $mode write WRITE_SIZE
 done
 cd $R
-python tools/r05_tcc_post.py "$OUT"
+python tools/tcc_traffic_post.py "$OUT"

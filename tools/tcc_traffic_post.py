@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Post-processor of tools/r05_tcc.sh: per layer of tools/w4_traffic.py (dispatch order; the first launch of each layer dropped), the
+"""Post-processor of tools/tcc_traffic.sh: per layer of tools/w4_traffic.py (dispatch order; the first launch of each layer dropped), the
 L2 request / hit / miss counts and the fabric-side requests next to the algorithmic bytes."""
 import csv, glob, json, os, sys
 out = sys.argv[1]
