@@ -742,6 +742,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if (!W4_DBG(256)) issue(ci, hissue);
             __builtin_amdgcn_sched_barrier(0);
             W4_STAMP(4);                                       // halo loads
+            // (tooling: what an LDS-DMA of the U slab would impose -- vmcnt retires in order, so waiting for a DMA issued at the top of
+            //  this iteration also waits for every halo / operand load of the earlier iterations; only this iteration's may stay in flight)
+            if (W4_DBG(1024)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NHL + NPF) > 63 ? 63 : (NHL + NPF)) : "memory");
             handoff();                                     // E_q
             W4_STAMP(5);
         };
