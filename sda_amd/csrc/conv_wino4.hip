@@ -36,6 +36,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// U slab: L2 -> registers -> ds_write_b128 (0, shipped) or L2 -> LDS by inline-asm LDS-DMA (1; A/B builds:
+// SDA_EXTRA_HIPCC_FLAGS=-DW4_UDMA=1).  Round 5 built and measured the DMA form (profiles/r05_w4_udma_ab.txt): parity-green, and
+// SLOWER -- plain 96 -> 96 +2 %, x act'(z) +8 %, 384 -> 384 +11 %, the zero-position forms +7 / +8 % -- although leaving the U stores
+// out altogether is worth -1 .. -6 % (profiles/r05_w4_udma_upper_bound.txt): a DMA piece costs the in-order helper ~100+ cycles of
+// issue where a global load + a ds_write_b128 cost ~30, and that time sits in front of the work the consumers' pause waits for.
+#ifndef W4_UDMA
+#define W4_UDMA 0
+#endif
 #define W4_CK 8
 #define W4_BM 96
 #define W4_T 32                        // 8 x 4 Winograd tiles
@@ -54,6 +62,7 @@
 #define W4_VPP (4 * W4_VKQ)            // floats per position pair in a V buffer
 #define W4_VBUF (8 * W4_VPP)           // 4096 floats = 16 KiB
 #define W4_LDS_BYTES ((2 * W4_UBUF + 2 * W4_VBUF + 4 * 2 * W4_HPLANE) * 4)
+#define W4_LDS_ALLOC (W4_LDS_BYTES + (W4_UDMA ? 1024 : 0))      // + the landing KiB of the prologue's dummy DMA
 
 struct Wino4Geom {
     int cin, hv, wv;                   // real input channels, virtual (= output) image size
@@ -520,6 +529,50 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 w4_ld4<2048>(ureg[pp * 6 + 5], sq, lane16);
             }
         };
+        // The same pieces by LDS-DMA (W4_UDMA): global_load_lds_dwordx4 writes [M0 + lane x 16], and both the packing and the stage
+        // buffer are lane-linear 1-KiB pieces, so a piece goes straight to its place -- no registers, no ds_write_b128 (48 per stage
+        // and workgroup through the VGPR -> LDS store path that the consumers' operand reads share), and hipcc does not see it (inline
+        // asm: the waits are counted by hand like every other load of this wave).  Issued where u_store + u_load stood, for the stage
+        // the consumers multiply NEXT, and waited for in front of that iteration's hand-off barrier.
+        // (the instruction's immediate offset is added to the global AND the LDS address: three consecutive KiB per statement, one
+        //  scalar base pair and one M0 value -- twelve separate bases spill scalars into the pause's vector work)
+        auto u_dma3 = [&](const char* src, const float* dst) {
+            const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const float*)dst));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(src), "s"(la) : "memory");
+        };
+        auto u_dma1 = [&](const char* src, const float* dst) {
+            const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) const float*)dst));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(src), "s"(la) : "memory");
+        };
+        auto u_dma = [&](const W4Cur& t, float* ub) {
+            if constexpr (ZPOS) {
+                const char* b0 = reinterpret_cast<const char*>(d.w_wino4_zp + ((int64_t)t.st * g.n_ct + t.ct) * W4_UZP) + pw * 7168;
+                float* dz = ub + pw * 1792;
+                u_dma3(b0, dz);
+                u_dma3(b0 + 3072, dz + 768);
+                u_dma1(b0 + 6144, dz + 1536);
+                return;
+            }
+            const int64_t pstride = (int64_t)g.mtiles * 1024;
+            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                u_dma3(src + pp * pstride, ub + (2 * pw + pp) * W4_UPP);
+                u_dma3(src + pp * pstride + 3072, ub + (2 * pw + pp) * W4_UPP + 768);
+            }
+        };
+        // (prologue only: NUL pieces onto the workgroup's scratch KiB behind the halo planes -- the static wait counts assume a second
+        //  group of U loads there)
+        auto u_dma_dummy = [&]() {
+            const char* src = reinterpret_cast<const char*>(d.w_wino4);
+#pragma unroll
+            for (int m = 0; m < (ZPOS ? 7 : 12); ++m) u_dma1(src, smem + W4_LDS_BYTES / 4);
+        };
 #define W4_WAIT_U(N)                                                                                                           \
     asm volatile("s_waitcnt vmcnt(%14)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
                  "+v"(ureg[6]), "+v"(ureg[7]), "+v"(ureg[8]), "+v"(ureg[9]), "+v"(ureg[10]), "+v"(ureg[11]), "+v"(pfreg[0]),   \
@@ -658,15 +711,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         issue(ci, h1); tag(h1); step_issue();
         issue(ci, h2); tag(h2); step_issue();
         issue(ci, h3); tag(h3);
+#if W4_UDMA
+        u_dma(c2, ubuf);                                   // stage 0's U slab -> buffer 0
+#else
         u_load(c2);
+#endif
         W4_WAIT_HALO(3 * NHL + NUL, h0);
         commit(c2, h0);
         patch_read();
         transform(vbuf);
+#if W4_UDMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        step2();
+        W4Cur cu = c2;                                     // cursor of the stage whose U slab the next iteration copies (stage q + 1)
+        u_dma_dummy();
+#else
         W4_WAIT_U(0);
         u_store(ubuf);
         step2();
         u_load(c2);
+#endif
         W4_WAIT_HALO(NUL, h1);
         commit(c2, h1);
         step2();
@@ -696,6 +760,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 cst = (cst + 1) * (1 - wrap);
             }
             W4_T0();
+#if W4_UDMA
+            // (at most the NHL + NPF loads of the previous iteration's tail are outstanding here: that iteration waited for exactly that
+            //  in front of its hand-off.  The dummy / operand registers pass through a statement, as at the former U wait.)
+            asm volatile("" : "+v"(pfreg[0]), "+v"(pfreg[1]) :: "memory");
+            W4_PIN_EPI();
+            W4_STAMP(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!W4_DBG(256)) u_dma(cu, ub);               // stage q + 1's U slab -> the buffer the hand-off E_(q-1) released
+            __builtin_amdgcn_sched_barrier(0);
+            cu = c2;
+#else
             // the U registers were loaded one iteration ago, before that iteration's halo loads
             W4_WAIT_U(NHL + NPF);
             if (!W4_DBG(16)) u_store(ub);
@@ -704,6 +779,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             __builtin_amdgcn_sched_barrier(0);
             if (!W4_DBG(256)) u_load(c2);                  // (the hand-written wait counts assume both load groups)
             __builtin_amdgcn_sched_barrier(0);
+#endif
             // cursor arithmetic (scalar, ~60 instructions): here, beside the MFMAs, not in the pause
             const W4Cur ccommit = c2;
             step2();
@@ -744,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_STAMP(4);                                       // halo loads
             // (tooling: what an LDS-DMA of the U slab would impose -- vmcnt retires in order, so waiting for a DMA issued at the top of
             //  this iteration also waits for every halo / operand load of the earlier iterations; only this iteration's may stay in flight)
-            if (W4_DBG(1024)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NHL + NPF) > 63 ? 63 : (NHL + NPF)) : "memory");
+            if (W4_UDMA || W4_DBG(1024)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NHL + NPF) > 63 ? 63 : (NHL + NPF)) : "memory");
             handoff();                                     // E_q
             W4_STAMP(5);
         };
@@ -1097,11 +1173,11 @@ extern "C" int sda_w4_trace_read(double* out) {
 
 template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
-    static_assert(W4_LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(W4_LDS_ALLOC <= 160 * 1024, "LDS");
     static bool attr_set[SDA_MAX_DEVICES];
-    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), W4_LDS_BYTES, attr_set);
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), W4_LDS_ALLOC, attr_set);
     if (rc != SDA_OK) return rc;
-    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), dim3(grid), dim3(512), (size_t)W4_LDS_BYTES, stream, *d, g);
+    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), dim3(grid), dim3(512), (size_t)W4_LDS_ALLOC, stream, *d, g);
     return sda_launch_status();
 }
 
