@@ -563,6 +563,14 @@ int sda_conv_h2(const sda_conv_desc* d, void* stream);
 int sda_conv_h2_supported(const sda_conv_desc* d);
 int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int transpose, float w_amax, void* dst, void* stream);
 int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose);
+/* (ABI v12) the f16 x 2 form of a 3 x 3 convolution over a 2 x 2 nearest-up-sampled source (sda_conv_desc.up_h = up_w = 2: the tails,
+ * sda/nn.py:161-169).  Output pixel (2 i + py, 2 j + px) sees only the 2 x 2 source pixels (i - 1 + py + a, j - 1 + px + b): each output
+ * parity class is a 2 x 2-tap convolution of the low-resolution image with the taps that fall on one source pixel summed -- 4 / 9 of the
+ * multiplies.  wsum: [4 classes (2 py + px)][cout][cin][4 taps (2 a + b)], summed in fp32 by the caller (class 0 rows: dy {0} | {1, 2};
+ * class 1 rows: {0, 1} | {2}; columns alike), w_amax = max |wsum|.  A descriptor with up_h = up_w = 2 takes w_h2 = this packing;
+ * served for cin % 96 == 0, cout % 96 == 0, a 16 x 16-tileable SOURCE grid, loader none / (modulation +) LayerNorm, epilogues bias / + res. */
+int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, float w_amax, void* dst, void* stream);
+int64_t sda_conv_h2_up_packed_bytes(int cout, int cin);
 float sda_conv_h2_scale(float amax);
 int sda_absmax(const float* x, int64_t numel, float* amax, void* stream);
 

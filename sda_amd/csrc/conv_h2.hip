@@ -93,8 +93,14 @@ struct h2_args {
 
 // ABL (tooling builds, -DSDA_H2_ABLATE + $SDA_H2_ABL; results WRONG): 1 no weight DMA, 2 no activation loader, 4 no MFMAs,
 // 8 no epilogue stores -- what each costs, measured by leaving it out (tools/h2_check.py)
-template <int LOADER, int ABL = 0>           // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
+// NT: taps per stage.  9 = the 3 x 3 convolution.  4 = UP-SAMPLED source (sda_conv_desc.up_h = up_w = 2, the tails sda/nn.py:161-169):
+// output pixel (2 i + py, 2 j + px) of a 3 x 3 convolution over the nearest-up-sampled image sees only the 2 x 2 source pixels
+// (i - 1 + py + a, j - 1 + px + b), so each output parity class is a 2 x 2-tap convolution of the LOW-resolution tile with the taps that
+// fall on one source pixel pre-summed (sda_pack_conv_weight_h2_up): 4 / 9 of the multiplies.  A tile is then (class, cout tile, 16 x
+// 16 low-resolution pixels); the class only moves the consumers' tile origin by (py, px) and interleaves the stores.
+template <int LOADER, int NT = 9, int ABL = 0>           // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
 __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
+    constexpr int ASLAB = NT * 3 * 2 * 1024;                        // bytes of a stage's weight slab (its LDS region is H2_ASLAB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             const int oy0 = by * H2_TS, ox0 = bx * H2_TS;
             P.ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)ch8 * d.x_sc;
             P.modp = (LOADER == 2 && d.mod) ? d.mod + (int64_t)n * d.mod_sn + ch8 : nullptr;
-            P.wsl = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)ct * a.nchunk * H2_ASLAB;
+            P.wsl = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)ct * a.nchunk * ASLAB;     // (ct: class-major when NT == 4)
             P.valid = 0;
 #pragma unroll
             for (int r = 0; r < H2_PRND; ++r) {
@@ -183,14 +189,15 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         // drain vmcnt in front of every LDS access and register-load use of the loop.
         auto dma_weights = [&](const plan_t& P, int chunk, int bufsel) {
             if (ABL & 1) return;
-            const unsigned char* src = P.wsl + (int64_t)chunk * H2_ASLAB + lane * 16;
+            const unsigned char* src = P.wsl + (int64_t)chunk * ASLAB + lane * 16;
             const unsigned lds0 = __builtin_amdgcn_readfirstlane(
                 (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(smem + bufsel * H2_STAGE)));
-            // 54 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
+            // NT * 6 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
+            constexpr int NPC = NT * 6;
 #pragma unroll
-            for (int k = 0; k < 14; ++k) {
+            for (int k = 0; k < (NPC + 3) / 4; ++k) {
                 const int piece = pw + 4 * k;
-                if (k < 13 || piece < 54) {
+                if (4 * k + 3 < NPC || piece < NPC) {
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(src + piece * 1024), "s"(lds0 + piece * 1024) : "memory");
@@ -302,11 +309,16 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
     for (int it = 0;; ++it) {
         int t = tile_of(it);
         if (t >= a.ntiles) break;
-        const int ct = t % a.n_ct; t /= a.n_ct;
+        const int cta = t % a.n_ct; t /= a.n_ct;
         const int bx = t % a.tiles_x; t /= a.tiles_x;
         const int by = t % a.tiles_y;
         const int n = t / a.tiles_y;
+        // NT == 4: cta = class * (cout tiles) + cout tile; class (py, px) = the output parity this tile writes
+        const int nct1 = NT == 4 ? a.n_ct >> 2 : a.n_ct;
+        const int cls = NT == 4 ? cta / nct1 : 0, ct = NT == 4 ? cta - cls * nct1 : cta;
+        const int cy = cls >> 1, cx = cls & 1;
         const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
+        const int b_rd_t = b_rd + (NT == 4 ? (cy * H2_HS + cx) * H2_PXB : 0);
 
         h2_f16v acc[3][2];
 #pragma unroll
@@ -321,9 +333,9 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             const unsigned char* st = smem + (chunk & 1) * H2_STAGE;
             h2_h8 A[2][3][2], B[2][2][2];                           // [set][fragment][piece]
             auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
-                const int dy = tap / 3, dx = tap - 3 * dy;
+                const int dy = NT == 4 ? tap >> 1 : tap / 3, dx = NT == 4 ? tap & 1 : tap - 3 * dy;
                 const unsigned char* pa = st + a_rd + tap * (3 * 2 * 1024);
-                const unsigned char* pb = st + b_rd + (dy * H2_HS + dx) * H2_PXB;
+                const unsigned char* pb = st + b_rd_t + (dy * H2_HS + dx) * H2_PXB;
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     Bd[f][0] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB);
@@ -337,10 +349,10 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             };
             load_AB(0, A[0], B[0]);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < NT; ++tap) {
                 const int s = tap & 1;
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap < 8) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
+                if (tap < NT - 1) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
                 if (ABL & 4) {                                      // (keep the operands alive without multiplying)
 #pragma unroll
                     for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                         for (int f = 0; f < 2; ++f)
                             acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][0], acc[m][f], 0, 0, 0);
                     // the tap's issue order: the next tap's ten operand reads between the first MFMAs
-                    if (tap < 8) {
+                    if (tap < NT - 1) {
 #pragma unroll
                         for (int k = 0; k < 10; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -381,7 +393,11 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         // column ox0 + pcol
         const float inv = 1.0f / (sx * a.w_scale);
         const int64_t osn = (int64_t)d.cout * d.ho * d.wo, osc = (int64_t)d.ho * d.wo;
-        const int64_t obase = (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * d.wo + ox0 + pcol;
+        // (NT == 4: this tile writes the pixels (2 y + cy, 2 x + cx) of the up-sampled grid: every other pixel of every other row)
+        const int64_t obase = NT == 4
+            ? (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(2 * (oy0 + 4 * wave + prow) + cy) * d.wo + 2 * (ox0 + pcol) + cx
+            : (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * d.wo + ox0 + pcol;
+        constexpr int FROW = NT == 4 ? 4 : 2;                       // output rows between a wave's two pixel fragments
         // (the epilogue's mode is decided ONCE, by uniform branches around straight-line copies: tested per element the compiler emits a
         //  branch per store.)  A cout fragment's operands are requested together, before its first store.
         auto epilogue = [&](auto mode, auto with_bias) {
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                     for (int f = 0; f < 2; ++f)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            opnd[f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo];
+                            opnd[f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * d.wo];
                 }
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                         if (EPI == 1) v *= sda_dact(SDA_ACT_SILU, opnd[f][r]);
                         if (EPI == 2) v += opnd[f][r];
                         amax = fmaxf(amax, fabsf(v));
-                        if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(2 * f) * d.wo] = v;
+                        if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * d.wo] = v;
                     }
             }
         };
@@ -437,14 +453,14 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
 //                             W[co = 16 chunk + 8 (lane >> 5) + i][ci = 96 ct + 32 m + (lane & 31)][8 - tap]
 // A (cout tile, chunk) slab is 54 KiB, contiguous: the LDS image of a stage, copied by LDS-DMA.
 __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, int transpose, float scale, h2_h8* __restrict__ dst,
-                               int64_t units) {
+                               int64_t units, int ntap) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= units) return;
     const int lane = (int)(u & 63);
     int64_t t = u >> 6;
     const int piece = (int)(t & 1); t >>= 1;
     const int m = (int)(t % 3); t /= 3;
-    const int tap = (int)(t % 9); t /= 9;
+    const int tap = (int)(t % ntap); t /= ntap;
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;     // operator rows / contraction
     const int nchunk = K / H2_CK;
     const int chunk = (int)(t % nchunk);
@@ -456,8 +472,8 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
         const int k = H2_CK * chunk + 8 * (lane >> 5) + i;
         float v = 0.f;
         if (row < M) {
-            const int co = transpose ? k : row, ci = transpose ? row : k, tp = transpose ? 8 - tap : tap;
-            v = w[((int64_t)co * cin + ci) * 9 + tp] * scale;
+            const int co = transpose ? k : row, ci = transpose ? row : k, tp = transpose ? ntap - 1 - tap : tap;
+            v = w[((int64_t)co * cin + ci) * ntap + tp] * scale;
         }
         const _Float16 h = (_Float16)v;
         out[i] = piece ? (_Float16)(v - (float)h) : h;
@@ -478,7 +494,24 @@ extern "C" int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int tr
     if (!w || !dst || bytes == 0) return SDA_E_BADARG;
     const int64_t units = bytes / 16;
     hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transpose,
-                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units);
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 9);
+    return sda_launch_status();
+}
+
+// The up-sampled form (conv_h2_kernel<.., 4>): wsum is [4 classes][cout][cin][4 taps] -- class (py, px), tap (a, b): the sum of the 3 x 3
+// taps (dy, dx) that read source pixel (i - 1 + py + a, j - 1 + px + b) of output pixel (2 i + py, 2 j + px), summed in fp32 by the
+// caller -- packed like a convolution with 4 cout rows per class: [class * (cout / 96) + cout tile][chunk][tap][m][piece][lane].
+extern "C" int64_t sda_conv_h2_up_packed_bytes(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cout % H2_BM || cin % H2_KQ) return 0;
+    return (int64_t)4 * (cout / H2_BM) * (cin / H2_CK) * (4 * 3 * 2 * 1024);
+}
+
+extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, float w_amax, void* dst, void* stream) {
+    const int64_t bytes = sda_conv_h2_up_packed_bytes(cout, cin);
+    if (!wsum || !dst || bytes == 0) return SDA_E_BADARG;
+    const int64_t units = bytes / 16;
+    hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsum, 4 * cout, cin, 0,
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 4);
     return sda_launch_status();
 }
 
@@ -522,11 +555,14 @@ extern "C" int sda_absmax(const float* x, int64_t numel, float* amax, void* stre
 // ------------------------------------------------------------------------------------------------------------------- launcher
 static bool h2_ok(const sda_conv_desc* d) {
     if (!d || !d->x || !d->out || !d->w_h2) return false;
-    if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->explicit_pad || d->up_h != 1 || d->up_w != 1 ||
+    const bool up = d->up_h == 2 && d->up_w == 2;                  // (w_h2 is then sda_pack_conv_weight_h2_up's packing)
+    if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->explicit_pad || !(up || (d->up_h == 1 && d->up_w == 1)) ||
         d->zins_h != 1 || d->zins_w != 1 || d->pool_h > 1 || d->pool_w > 1)
         return false;
     if (d->cctx != 0 || d->n_inner != 1 || d->x_n_off != 0) return false;
-    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != d->hs || d->wo != d->ws || d->ho % H2_TS || d->wo % H2_TS) return false;
+    const int us = up ? 2 : 1;
+    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != us * d->hs || d->wo != us * d->ws || d->hs % H2_TS || d->ws % H2_TS) return false;
+    if (up && (d->dact_z || d->act_in != SDA_ACT_NONE)) return false;
     if (d->out_sn || d->out_sc || d->out_sy || d->out_sx) return false;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return false;
     if (d->mod && !d->ln_mean) return false;
@@ -537,7 +573,7 @@ static bool h2_ok(const sda_conv_desc* d) {
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 ||
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
-    const int64_t tiles = (int64_t)d->n * (d->ho / H2_TS) * (d->wo / H2_TS) * (d->cout / H2_BM);
+    const int64_t tiles = (int64_t)d->n * (d->hs / H2_TS) * (d->ws / H2_TS) * (d->cout / H2_BM) * (up ? 4 : 1);
     return tiles >= 1 && tiles <= 0x3fffffffLL;
 }
 
@@ -551,9 +587,10 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.x_amax = d->x_amax;
     a.x_amax_static = d->x_amax_static;
     a.out_amax = d->out_amax;
-    a.tiles_x = d->wo / H2_TS;
-    a.tiles_y = d->ho / H2_TS;
-    a.n_ct = d->cout / H2_BM;
+    const bool up = d->up_h == 2;
+    a.tiles_x = d->ws / H2_TS;                                     // (tiles of the SOURCE grid: the output grid unless up-sampled)
+    a.tiles_y = d->hs / H2_TS;
+    a.n_ct = (d->cout / H2_BM) * (up ? 4 : 1);
     a.nchunk = d->cx / H2_CK;
     a.stagger = 0;
 #ifdef SDA_H2_ABLATE
@@ -573,15 +610,27 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
         static const int abl = getenv("SDA_H2_ABL") ? atoi(getenv("SDA_H2_ABL")) : 0;
         static bool seta[16][SDA_MAX_DEVICES];
         const void* fn = nullptr;
-#define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, v>); \
+#define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, 9, v>); \
             if (!d->ln_mean && d->act_in == SDA_ACT_NONE) { if ((rc = sda_raise_dyn_lds(fn, lds, seta[v])) != SDA_OK) return rc; \
-                hipLaunchKernelGGL((conv_h2_kernel<0, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
+                hipLaunchKernelGGL((conv_h2_kernel<0, 9, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
         switch (abl) {
             H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(11) H2_ABL_CASE(15)
             default: break;
         }
     }
 #endif
+    if (up) {                                                      // (the tails: LayerNorm or plain loader)
+        if (d->ln_mean) {
+            static bool setu2[SDA_MAX_DEVICES];
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2, 4>), lds, setu2)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<2, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+        } else {
+            static bool setu0[SDA_MAX_DEVICES];
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), lds, setu0)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<0, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+        }
+        return sda_launch_status();
+    }
     if (d->ln_mean) {
         static bool set2[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2>), lds, set2)) != SDA_OK) return rc;

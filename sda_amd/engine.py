@@ -205,7 +205,12 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
         # OPT-IN f16 x 2 multiply (ops.MULTIPLY): behind a LayerNorm the loader's output is bounded by sqrt(channels); otherwise the
         # caller says how large the input is (the producing launch's out_amax, or an ops.absmax pass)
         bound = math.sqrt(src['cx']) if ln is not None else x_amax
-        if ops.conv_h2(d, pk, bound, out_amax):
+        packing = None
+        if tuple(up) == (2, 2):                          # the tails: four parity classes of 2 x 2 pre-summed taps (PackedConv.h2_up)
+            packing = pk.h2_up() if ops.H2_UP else None
+            if packing is None:
+                bound = None                             # -> the zero-position Winograd kernel
+        if ops.conv_h2(d, pk, bound, out_amax, packing=packing):
             return d
     if parity4_w is not None:
         # all four parity classes of a stride-2 VJP in one launch: the class-(0,0) descriptor with the concatenated packing

@@ -34,6 +34,10 @@ def set_multiply(mode: str) -> str:
     return prev
 
 
+#: f16 x 2 route: the up-sampled tails on conv_h2's parity-class form (SDA_H2_UP=0: the zero-position Winograd kernel, A/B runs)
+H2_UP = os.environ.get('SDA_H2_UP', '1') != '0'
+
+
 def tensor_version(t) -> int:
     """``t._version`` for cache keys; inference-mode tensors have no version counter (reading it raises) and cannot be written
     in place either, so a constant stands in for them."""
@@ -198,14 +202,17 @@ def absmax(x: Tensor, out: Tensor) -> Tensor:
     return out
 
 
-def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]) -> bool:
+def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor], packing=None) -> bool:
     """Run the launch on the f16 x 2 kernel (csrc/conv_h2.hip) when `pk` carries that packing and the kernel serves the shape.
     x_amax: device scalar (Tensor) or a host bound (float) on the magnitude of what the loader feeds the multiply.  False: not
     served -- the caller runs the fp32 kernels."""
     if getattr(pk, 'h2', None) is None or x_amax is None:
         return False
     lib = _lib.load()
-    desc.w_h2, desc.w_h2_scale = pk.h2.data_ptr(), pk.h2_scale
+    if packing is None:
+        desc.w_h2, desc.w_h2_scale = pk.h2.data_ptr(), pk.h2_scale
+    else:                                                 # (buffer, scale): e.g. PackedConv.h2_up() for an up-sampled source
+        desc.w_h2, desc.w_h2_scale = packing[0].data_ptr(), packing[1]
     if torch.is_tensor(x_amax):
         desc.x_amax, desc.x_amax_static = x_amax.data_ptr(), 0.0
     else:
@@ -223,9 +230,10 @@ def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]
     _lib.check(lib.sda_conv_h2(ctypes.byref(desc), _stream()), 'sda_conv_h2')
     if prof is not None:
         e1.record()
-        prof.records.append((e0, e1, prof.flops(desc), 'h2'))
+        fam = 'h2up' if desc.up_h == 2 else 'h2'            # (the up-sampled form issues 4 of the 9 taps)
+        prof.records.append((e0, e1, prof.flops(desc), fam))
         rd, wr = prof.alg_bytes(desc)
-        b = prof.family_bytes.setdefault('h2', [0.0, 0.0])
+        b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
         b[0] += rd
         b[1] += wr
     return True
@@ -292,6 +300,9 @@ class PackedConv:
         cout, cin = w.shape[0], w.shape[1]
         ks = tuple(w.shape[2:])
         self.kh, self.kw = (1, ks[0]) if len(ks) == 1 else ks
+        self._transpose = bool(transpose)
+        self._w_ref = w if (MULTIPLY == 'f16x2' and len(ks) == 2) else None     # (h2_up() sums taps of the original layout on first use)
+        self._h2_up = None
         if transpose:
             keep = cin if cin_keep is None else cin_keep
             self.k_real, self.m_real = cout, keep          # contraction over forward cout, produces forward cin
@@ -343,6 +354,41 @@ class PackedConv:
                     self.h2_scale = float(lib.sda_conv_h2_scale(w_amax))
                     self.out_amax = torch.zeros(1, device=w.device, dtype=torch.float32)     # max |out| of this layer's last launch
                     self.in_amax = torch.zeros(1, device=w.device, dtype=torch.float32)      # scratch for an absmax pass over its input
+
+    def h2_up(self):
+        """(packing, scale) of the f16 x 2 form over a 2 x 2 nearest-up-sampled source (sda_pack_conv_weight_h2_up), or None: the four
+        output parity classes as 2 x 2-tap convolutions with pre-summed taps.  Built on first use (warm-up, never under capture)."""
+        if self.h2 is None or self._transpose or getattr(self, '_w_ref', None) is None:
+            return None
+        if getattr(self, '_h2_up', None) is None:
+            lib = _lib.load()
+            w = self._w_ref                                    # [cout][cin][3][3]
+            cout, cin = w.shape[0], w.shape[1]
+            nbytes = int(lib.sda_conv_h2_up_packed_bytes(cout, cin))
+            if nbytes <= 0:
+                self._h2_up = False
+            else:
+                rows = (((0,), (1, 2)), ((0, 1), (2,)))       # [parity][a] -> the 3 x 3 tap indices that read source pixel a
+                wsum = torch.empty(4, cout, cin, 4, device=w.device, dtype=torch.float32)
+                for py in range(2):
+                    for px in range(2):
+                        for a_ in range(2):
+                            for b_ in range(2):
+                                acc = None
+                                for dy in rows[py][a_]:
+                                    for dx in rows[px][b_]:
+                                        acc = w[:, :, dy, dx] if acc is None else acc + w[:, :, dy, dx]
+                                wsum[2 * py + px, :, :, 2 * a_ + b_] = acc
+                amax = float(wsum.abs().max())
+                if not (amax > 0.0 and math.isfinite(amax)):
+                    self._h2_up = False
+                else:
+                    buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+                    _lib.check(lib.sda_pack_conv_weight_h2_up(wsum.data_ptr(), cout, cin, amax, buf.data_ptr(), _stream()),
+                               'sda_pack_conv_weight_h2_up')
+                    torch.cuda.current_stream(w.device).synchronize()      # (wsum is a temporary)
+                    self._h2_up = (buf, float(lib.sda_conv_h2_scale(amax)))
+        return self._h2_up or None
 
     def wino4_zp(self) -> Optional[Tensor]:
         """The zero-position packing of `wino4` (None without it): what the up-sampling tails (sda/nn.py:161-169 of the reference) and

@@ -238,3 +238,45 @@ def test_ln_bwd_reports_the_max_of_its_output(dev, c, h, w_, n, pool):
     ops.ln_bwd(gh, x, h, w_, mod, c, mean, rstd, True, pool, res, gx1, out_amax=amax)
     assert torch.equal(gx0, gx1)
     assert amax.item() == gx1.abs().max().item()
+
+
+@pytest.mark.parametrize('cin,cout,hs,ws,n,circular,ln,with_res', [(192, 96, 16, 16, 2, True, True, True), (384, 192, 16, 32, 1, False, True, True),
+                                                                   (96, 96, 32, 16, 3, True, False, False), (192, 96, 48, 16, 1, False, True, False)])
+def test_h2_upsampled_tail_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular, ln, with_res):
+    """The tails (LayerNorm -> Upsample(nearest, 2) -> conv 3 x 3, sda/nn.py:161-169) on conv_h2's parity-class form (four 2 x 2-tap
+    convolutions of the low-resolution tile with pre-summed taps) against float64 and against the zero-position Winograd kernel."""
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(cin + hs + ws)
+    x = torch.randn(n, cin, hs, ws, device=dev) * 1.7 + 0.3
+    w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
+    b = torch.randn(cout, device=dev)
+    pk = ops.PackedConv(w, b)
+    assert pk.h2 is not None and pk.h2_up() is not None
+    out = torch.full((n, cout, 2 * hs, 2 * ws), float('nan'), device=dev)
+    res = torch.randn_like(out) if with_res else None
+    kw = dict(circular=circular, bias=pk.bias, up=(2, 2), res=res)
+    x64 = x.double().cpu()
+    if ln:
+        var, mean = torch.var_mean(x, dim=1, unbiased=True)
+        kw['ln'] = (mean.reshape(-1).contiguous(), (1 / torch.sqrt(var + 1e-5)).reshape(-1).contiguous())
+        v64, m64 = torch.var_mean(x64, dim=1, unbiased=True, keepdim=True)
+        x64 = (x64 - m64) / torch.sqrt(v64 + 1e-5)
+    xu = x64.repeat_interleave(2, -1).repeat_interleave(2, -2)
+    xp = F.pad(xu, (1, 1, 1, 1), mode='circular') if circular else F.pad(xu, (1, 1, 1, 1))
+    ref = F.conv2d(xp, w.double().cpu(), b.double().cpu())
+    if res is not None:
+        ref = ref + res.double().cpu()
+    d = launch_conv(pk, planar_source(x), out, 2 * hs, 2 * ws, x_amax=None if ln else ops.absmax(x, pk.in_amax), **kw)
+    assert d.w_h2 and d.up_h == 2, 'the up-sampled launch was not served by conv_h2'
+    err = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    prev, ops.H2_UP = ops.H2_UP, False
+    try:
+        out32 = torch.empty_like(out)
+        d32 = launch_conv(pk, planar_source(x), out32, 2 * hs, 2 * ws, x_amax=None if ln else ops.absmax(x, pk.in_amax), **kw)
+        assert not d32.w_h2
+    finally:
+        ops.H2_UP = prev
+    err32 = ((out32.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    print(f'up-sampled tail {cin}->{cout} @{hs}x{ws}: f16x2 parity-class form {err:.2e}, zero-position Winograd {err32:.2e} (vs float64, of max |ref|)')
+    assert err < 3e-6
