@@ -571,6 +571,13 @@ int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose);
  * served for cin % 96 == 0, cout % 96 == 0, a 16 x 16-tileable SOURCE grid, loader none / (modulation +) LayerNorm, epilogues bias / + res. */
 int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, float w_amax, void* dst, void* stream);
 int64_t sda_conv_h2_up_packed_bytes(int cout, int cin);
+/* (ABI v12) generic form of the packing: w [rows][k][ntap] (ntap 4 or 9, rows % 96 == 0, k % 96 == 0).  The VJP of an up-sampled tail
+ * summed over the 2 x 2 up-sampling cells (sda_conv_desc.pool_h = pool_w = 2) runs as a 2 x 2-tap convolution over the four parity planes
+ * of the fine-resolution gradient: rows = the forward cin, k = 4 classes x the forward cout (class-major), ntap = 4,
+ * w[ci][class * cout + co][tap] = wsum[class][co][ci][tap] of sda_pack_conv_weight_h2_up.  Served for a 32 x 32-tileable source, plain loader,
+ * no bias / epilogue operand. */
+int sda_pack_conv_weight_h2_rows(const float* w, int rows, int k, int ntap, float w_amax, void* dst, void* stream);
+int64_t sda_conv_h2_rows_packed_bytes(int rows, int k, int ntap);
 float sda_conv_h2_scale(float amax);
 int sda_absmax(const float* x, int64_t numel, float* amax, void* stream);
 

@@ -235,6 +235,8 @@ SIGNATURES = {
     'sda_conv_h2_packed_bytes': (c_int64, [c_int, c_int, c_int]),
     'sda_pack_conv_weight_h2_up': (c_int, [c_fp, c_int, c_int, c_float, c_void_p, c_void_p]),
     'sda_conv_h2_up_packed_bytes': (c_int64, [c_int, c_int]),
+    'sda_pack_conv_weight_h2_rows': (c_int, [c_fp, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'sda_conv_h2_rows_packed_bytes': (c_int64, [c_int, c_int, c_int]),
     'sda_conv_h2_scale': (c_float, [c_float]),
     'sda_absmax': (c_int, [c_fp, c_int64, c_fp, c_void_p]),
     'sda_philox_words': (c_int, [c_fp, c_int64, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),

@@ -82,6 +82,7 @@ struct h2_args {
     float x_amax_static;
     float* out_amax;            // device (optional): atomically maxed with |out| as uint bits
     int tiles_x, tiles_y, n_ct, nchunk, ntiles;
+    int c16;                    // (MODE 2) 16-channel chunks per parity class: nchunk = 4 c16 stages
     int stagger;                // (tooling) start delay of workgroup slot s: (s & 3) * stagger * 8 128 cycles
 };
 
@@ -93,14 +94,21 @@ struct h2_args {
 
 // ABL (tooling builds, -DSDA_H2_ABLATE + $SDA_H2_ABL; results WRONG): 1 no weight DMA, 2 no activation loader, 4 no MFMAs,
 // 8 no epilogue stores -- what each costs, measured by leaving it out (tools/h2_check.py)
-// NT: taps per stage.  9 = the 3 x 3 convolution.  4 = UP-SAMPLED source (sda_conv_desc.up_h = up_w = 2, the tails sda/nn.py:161-169):
+// MODE 0: the 3 x 3 convolution, 9 taps per stage.  MODE 1 = UP-SAMPLED source, 4 taps per stage (sda_conv_desc.up_h = up_w = 2, the tails sda/nn.py:161-169):
 // output pixel (2 i + py, 2 j + px) of a 3 x 3 convolution over the nearest-up-sampled image sees only the 2 x 2 source pixels
 // (i - 1 + py + a, j - 1 + px + b), so each output parity class is a 2 x 2-tap convolution of the LOW-resolution tile with the taps that
 // fall on one source pixel pre-summed (sda_pack_conv_weight_h2_up): 4 / 9 of the multiplies.  A tile is then (class, cout tile, 16 x
 // 16 low-resolution pixels); the class only moves the consumers' tile origin by (py, px) and interleaves the stores.
-template <int LOADER, int NT = 9, int ABL = 0>           // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
+// MODE 2 = the TRANSPOSE of that: the VJP of such a tail, summed over the 2 x 2 up-sampling cells (sda_conv_desc.pool_h = pool_w = 2) --
+//     gx[ci][u][v] = sum over classes, taps, co of  wsum[class][co][ci][a][b]  g[co][2 (u + 1 - py - a) + py][2 (v + 1 - px - b) + px]:
+// a 2 x 2-tap convolution over the four PARITY PLANES of the fine-resolution gradient as 4 x as many input channels.  A stage is then
+// (class, 16 channels): the producers sample the class's plane (stride-2 address plan + a class offset on the scalar base), the
+// consumers shift their tile origin per stage; the output is the low-resolution tensor itself.
+template <int LOADER, int MODE = 0, int ABL = 0>         // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
 __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
+    constexpr int NT = MODE == 0 ? 9 : 4;
     constexpr int ASLAB = NT * 3 * 2 * 1024;                        // bytes of a stage's weight slab (its LDS region is H2_ASLAB)
+    const int PH = MODE == 2 ? d.hs >> 1 : d.hs, PW = MODE == 2 ? d.ws >> 1 : d.ws;      // the grid the tiles walk (MODE 2: a parity plane)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,14 +163,14 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                 int y = oy0 + hy - 1, x = ox0 + hx - 1;
                 bool ok = p < H2_NPX;
                 if (d.circular) {
-                    y = y < 0 ? y + d.hs : (y >= d.hs ? y - d.hs : y);
-                    x = x < 0 ? x + d.ws : (x >= d.ws ? x - d.ws : x);
+                    y = y < 0 ? y + PH : (y >= PH ? y - PH : y);
+                    x = x < 0 ? x + PW : (x >= PW ? x - PW : x);
                 } else {
-                    ok = ok && y >= 0 && y < d.hs && x >= 0 && x < d.ws;
+                    ok = ok && y >= 0 && y < PH && x >= 0 && x < PW;
                 }
                 y = ok ? y : 0;
                 x = ok ? x : 0;
-                P.goff[r] = 4u * (unsigned)(y * (int)d.x_sy + x * (int)d.x_sx);
+                P.goff[r] = 4u * (unsigned)((MODE == 2 ? 2 : 1) * (y * (int)d.x_sy + x * (int)d.x_sx));
                 P.valid |= ok ? (1u << r) : 0u;
                 if (LOADER == 2) {
                     const int64_t sp = (int64_t)n * d.hs * d.ws + (int64_t)y * d.ws + x;
@@ -176,7 +184,9 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         };
         auto load_from = [&](const float* ximg, const unsigned (&goff)[H2_PRND], int chunk, float (&v)[H2_PRND][8]) {
             if (ABL & 2) return;
-            const char* src = reinterpret_cast<const char*>(ximg + (int64_t)chunk * H2_CK * d.x_sc);
+            // (MODE 2: stage = class * c16 + chunk; the class's parity plane starts (py, px) pixels into the image)
+            const int cls = MODE == 2 ? chunk / a.c16 : 0, ck = MODE == 2 ? chunk - cls * a.c16 : chunk;
+            const char* src = reinterpret_cast<const char*>(ximg + (int64_t)ck * H2_CK * d.x_sc + (cls >> 1) * d.x_sy + (cls & 1) * d.x_sx);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const char* ch = src + (int64_t)i * d.x_sc * 4;     // (wave-uniform: an SGPR pair)
@@ -314,11 +324,11 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         const int by = t % a.tiles_y;
         const int n = t / a.tiles_y;
         // NT == 4: cta = class * (cout tiles) + cout tile; class (py, px) = the output parity this tile writes
-        const int nct1 = NT == 4 ? a.n_ct >> 2 : a.n_ct;
-        const int cls = NT == 4 ? cta / nct1 : 0, ct = NT == 4 ? cta - cls * nct1 : cta;
+        const int nct1 = MODE == 1 ? a.n_ct >> 2 : a.n_ct;
+        const int cls = MODE == 1 ? cta / nct1 : 0, ct = MODE == 1 ? cta - cls * nct1 : cta;
         const int cy = cls >> 1, cx = cls & 1;
         const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
-        const int b_rd_t = b_rd + (NT == 4 ? (cy * H2_HS + cx) * H2_PXB : 0);
+        const int b_rd_t = b_rd + (MODE == 1 ? (cy * H2_HS + cx) * H2_PXB : 0);
 
         h2_f16v acc[3][2];
 #pragma unroll
@@ -331,11 +341,14 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
             H2_BARRIER_CONSUMER();                                  // the stage is published (and the other buffer released)
             const unsigned char* st = smem + (chunk & 1) * H2_STAGE;
+            const int scls = MODE == 2 ? chunk / a.c16 : 0;
+            const int b_rd_s = b_rd + ((2 - (scls >> 1)) * H2_HS + (2 - (scls & 1))) * H2_PXB;
             h2_h8 A[2][3][2], B[2][2][2];                           // [set][fragment][piece]
             auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
                 const int dy = NT == 4 ? tap >> 1 : tap / 3, dx = NT == 4 ? tap & 1 : tap - 3 * dy;
                 const unsigned char* pa = st + a_rd + tap * (3 * 2 * 1024);
-                const unsigned char* pb = st + b_rd_t + (dy * H2_HS + dx) * H2_PXB;
+                // (MODE 2: tap (a, b) of class (py, px) reads halo pixel (2 - py - a, 2 - px - b) + the tile pixel)
+                const unsigned char* pb = MODE == 2 ? st + b_rd_s - (dy * H2_HS + dx) * H2_PXB : st + b_rd_t + (dy * H2_HS + dx) * H2_PXB;
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     Bd[f][0] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB);
@@ -392,12 +405,13 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         // ---- epilogue.  acc[m][f][r]: cout co0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel row oy0 + 4 wave + 2 f + prow,
         // column ox0 + pcol
         const float inv = 1.0f / (sx * a.w_scale);
-        const int64_t osn = (int64_t)d.cout * d.ho * d.wo, osc = (int64_t)d.ho * d.wo;
-        // (NT == 4: this tile writes the pixels (2 y + cy, 2 x + cx) of the up-sampled grid: every other pixel of every other row)
-        const int64_t obase = NT == 4
-            ? (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(2 * (oy0 + 4 * wave + prow) + cy) * d.wo + 2 * (ox0 + pcol) + cx
-            : (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * d.wo + ox0 + pcol;
-        constexpr int FROW = NT == 4 ? 4 : 2;                       // output rows between a wave's two pixel fragments
+        const int OH = MODE == 2 ? d.ho >> 1 : d.ho, OW = MODE == 2 ? d.wo >> 1 : d.wo;      // (MODE 2: `out` is the pooled tensor)
+        const int64_t osn = (int64_t)d.cout * OH * OW, osc = (int64_t)OH * OW;
+        // (MODE 1: this tile writes the pixels (2 y + cy, 2 x + cx) of the up-sampled grid: every other pixel of every other row)
+        const int64_t obase = MODE == 1
+            ? (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(2 * (oy0 + 4 * wave + prow) + cy) * OW + 2 * (ox0 + pcol) + cx
+            : (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * OW + ox0 + pcol;
+        constexpr int FROW = MODE == 1 ? 4 : 2;                     // output rows between a wave's two pixel fragments
         // (the epilogue's mode is decided ONCE, by uniform branches around straight-line copies: tested per element the compiler emits a
         //  branch per store.)  A cout fragment's operands are requested together, before its first store.
         auto epilogue = [&](auto mode, auto with_bias) {
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                     for (int f = 0; f < 2; ++f)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            opnd[f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * d.wo];
+                            opnd[f][r] = op[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * OW];
                 }
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                         if (EPI == 1) v *= sda_dact(SDA_ACT_SILU, opnd[f][r]);
                         if (EPI == 2) v += opnd[f][r];
                         amax = fmaxf(amax, fabsf(v));
-                        if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * d.wo] = v;
+                        if (!(ABL & 8) || v == 1.2345e30f) d.out[obase + (int64_t)(32 * m + (r & 3) + 8 * (r >> 2)) * osc + (int64_t)(FROW * f) * OW] = v;
                     }
             }
         };
@@ -515,6 +529,23 @@ extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, 
     return sda_launch_status();
 }
 
+// Generic: w is [rows][k][ntap] (fp32), packed [row tile][k chunk][tap][m][piece][lane]; rows % 96 == 0, k % 96 == 0, ntap 4 or 9.  The
+// pooled tail VJP (conv_h2_kernel<.., 2>) takes rows = the forward cin, k = 4 classes x the forward cout (class-major), 4 taps:
+// w[ci][class * cout + co][2 a + b] = wsum[class][co][ci][2 a + b] of sda_pack_conv_weight_h2_up.
+extern "C" int64_t sda_conv_h2_rows_packed_bytes(int rows, int k, int ntap) {
+    if (rows <= 0 || k <= 0 || rows % H2_BM || k % H2_KQ || (ntap != 4 && ntap != 9)) return 0;
+    return (int64_t)(rows / H2_BM) * (k / H2_CK) * ((int64_t)ntap * 3 * 2 * 1024);
+}
+
+extern "C" int sda_pack_conv_weight_h2_rows(const float* w, int rows, int k, int ntap, float w_amax, void* dst, void* stream) {
+    const int64_t bytes = sda_conv_h2_rows_packed_bytes(rows, k, ntap);
+    if (!w || !dst || bytes == 0) return SDA_E_BADARG;
+    const int64_t units = bytes / 16;
+    hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, k, 0,
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, ntap);
+    return sda_launch_status();
+}
+
 // max |x| over a contiguous tensor into amax[0] (as uint bits; the caller zeroes it): for inputs whose producer did not report it
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ amax) {
     float m = 0.f;
@@ -556,13 +587,15 @@ extern "C" int sda_absmax(const float* x, int64_t numel, float* amax, void* stre
 static bool h2_ok(const sda_conv_desc* d) {
     if (!d || !d->x || !d->out || !d->w_h2) return false;
     const bool up = d->up_h == 2 && d->up_w == 2;                  // (w_h2 is then sda_pack_conv_weight_h2_up's packing)
+    const bool pool = d->pool_h == 2 && d->pool_w == 2;            // (... sda_pack_conv_weight_h2_rows' of the class-major transpose)
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->explicit_pad || !(up || (d->up_h == 1 && d->up_w == 1)) ||
-        d->zins_h != 1 || d->zins_w != 1 || d->pool_h > 1 || d->pool_w > 1)
+        d->zins_h != 1 || d->zins_w != 1 || !(pool || (d->pool_h <= 1 && d->pool_w <= 1)) || (up && pool))
         return false;
     if (d->cctx != 0 || d->n_inner != 1 || d->x_n_off != 0) return false;
-    const int us = up ? 2 : 1;
-    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != us * d->hs || d->wo != us * d->ws || d->hs % H2_TS || d->ws % H2_TS) return false;
+    const int us = up ? 2 : 1, ts = pool ? 2 * H2_TS : H2_TS;
+    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != us * d->hs || d->wo != us * d->ws || d->hs % ts || d->ws % ts) return false;
     if (up && (d->dact_z || d->act_in != SDA_ACT_NONE)) return false;
+    if (pool && (d->dact_z || d->res || d->bias || d->ln_mean || d->act_in != SDA_ACT_NONE)) return false;
     if (d->out_sn || d->out_sc || d->out_sy || d->out_sx) return false;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return false;
     if (d->mod && !d->ln_mean) return false;
@@ -573,7 +606,7 @@ static bool h2_ok(const sda_conv_desc* d) {
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 ||
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
-    const int64_t tiles = (int64_t)d->n * (d->hs / H2_TS) * (d->ws / H2_TS) * (d->cout / H2_BM) * (up ? 4 : 1);
+    const int64_t tiles = (int64_t)d->n * (d->hs / ts) * (d->ws / ts) * (d->cout / H2_BM) * (up ? 4 : 1);
     return tiles >= 1 && tiles <= 0x3fffffffLL;
 }
 
@@ -587,11 +620,12 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.x_amax = d->x_amax;
     a.x_amax_static = d->x_amax_static;
     a.out_amax = d->out_amax;
-    const bool up = d->up_h == 2;
-    a.tiles_x = d->ws / H2_TS;                                     // (tiles of the SOURCE grid: the output grid unless up-sampled)
-    a.tiles_y = d->hs / H2_TS;
+    const bool up = d->up_h == 2, pool = d->pool_h == 2;
+    a.tiles_x = d->ws / (pool ? 2 * H2_TS : H2_TS);                // (tiles of the grid the kernel walks: the source grid, or one of its parity planes)
+    a.tiles_y = d->hs / (pool ? 2 * H2_TS : H2_TS);
     a.n_ct = (d->cout / H2_BM) * (up ? 4 : 1);
-    a.nchunk = d->cx / H2_CK;
+    a.c16 = d->cx / H2_CK;
+    a.nchunk = a.c16 * (pool ? 4 : 1);
     a.stagger = 0;
 #ifdef SDA_H2_ABLATE
     { static const int stg = getenv("SDA_H2_STAGGER") ? atoi(getenv("SDA_H2_STAGGER")) : 0; a.stagger = stg; }
@@ -610,24 +644,30 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
         static const int abl = getenv("SDA_H2_ABL") ? atoi(getenv("SDA_H2_ABL")) : 0;
         static bool seta[16][SDA_MAX_DEVICES];
         const void* fn = nullptr;
-#define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, 9, v>); \
+#define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, 0, v>); \
             if (!d->ln_mean && d->act_in == SDA_ACT_NONE) { if ((rc = sda_raise_dyn_lds(fn, lds, seta[v])) != SDA_OK) return rc; \
-                hipLaunchKernelGGL((conv_h2_kernel<0, 9, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
+                hipLaunchKernelGGL((conv_h2_kernel<0, 0, v>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a); return sda_launch_status(); } break;
         switch (abl) {
             H2_ABL_CASE(1) H2_ABL_CASE(2) H2_ABL_CASE(3) H2_ABL_CASE(4) H2_ABL_CASE(7) H2_ABL_CASE(8) H2_ABL_CASE(11) H2_ABL_CASE(15)
             default: break;
         }
     }
 #endif
+    if (pool) {                                                    // (the tails' VJP: plain loader, no epilogue operand)
+        static bool setp0[SDA_MAX_DEVICES];
+        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 2>), lds, setp0)) != SDA_OK) return rc;
+        hipLaunchKernelGGL((conv_h2_kernel<0, 2>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+        return sda_launch_status();
+    }
     if (up) {                                                      // (the tails: LayerNorm or plain loader)
         if (d->ln_mean) {
             static bool setu2[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2, 4>), lds, setu2)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<2, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2, 1>), lds, setu2)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<2, 1>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
         } else {
             static bool setu0[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), lds, setu0)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<0, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 1>), lds, setu0)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<0, 1>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
         }
         return sda_launch_status();
     }

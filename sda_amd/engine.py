@@ -200,6 +200,10 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                        w_wino4_ptr=None if getattr(pk, 'wino4', None) is None else pk.wino4.data_ptr(),
                        pad=pad, out_strides=out_strides, pool=pool, w_wino4_zp_ptr=None if zp is None else zp.data_ptr())
     if pool != (1, 1):
+        if tuple(pool) == (2, 2) and ops.H2_POOL and x_amax is not None and getattr(pk, 'h2', None) is not None:
+            packing = pk.h2_pool()
+            if packing is not None and ops.conv_h2(d, pk, x_amax, out_amax, packing=packing):
+                return d
         return d if ops.conv_pooled(d) else None
     if getattr(pk, 'h2', None) is not None and parity4_w is None:
         # OPT-IN f16 x 2 multiply (ops.MULTIPLY): behind a LayerNorm the loader's output is bounded by sqrt(channels); otherwise the
@@ -662,7 +666,10 @@ class UNetEngine:
                 pooled = None
                 if ops.POOLED and (uh, uw) == (2, 2) and hu == 2 * h and wu == 2 * w:
                     pooled = torch.empty(n, lev.C, h, w, device=dev, dtype=torch.float32)
-                    if launch_conv(tl.bwd(), planar_source(g), pooled, hu, wu, circular=tl.circular, pool=(2, 2)) is None:
+                    xa = None
+                    if ops.MULTIPLY == 'f16x2' and getattr(tl.bwd(), 'h2', None) is not None and g.is_contiguous():
+                        xa = g_amax if g_amax is not None else ops.absmax(g, tl.bwd().in_amax)     # (the f16 x 2 parity-plane form needs g's scale)
+                    if launch_conv(tl.bwd(), planar_source(g), pooled, hu, wu, circular=tl.circular, pool=(2, 2), x_amax=xa) is None:
                         pooled = None
                 if pooled is None:
                     ghup = torch.empty(n, lev.C, hu, wu, device=dev, dtype=torch.float32)

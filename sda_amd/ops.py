@@ -36,6 +36,8 @@ def set_multiply(mode: str) -> str:
 
 #: f16 x 2 route: the up-sampled tails on conv_h2's parity-class form (SDA_H2_UP=0: the zero-position Winograd kernel, A/B runs)
 H2_UP = os.environ.get('SDA_H2_UP', '1') != '0'
+#: ... and their pooled VJP on the parity-plane form (SDA_H2_POOL=0: the zero-position Winograd kernel)
+H2_POOL = os.environ.get('SDA_H2_POOL', '1') != '0'
 
 
 def tensor_version(t) -> int:
@@ -230,7 +232,7 @@ def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]
     _lib.check(lib.sda_conv_h2(ctypes.byref(desc), _stream()), 'sda_conv_h2')
     if prof is not None:
         e1.record()
-        fam = 'h2up' if desc.up_h == 2 else 'h2'            # (the up-sampled form issues 4 of the 9 taps)
+        fam = 'h2up' if (desc.up_h == 2 or desc.pool_h == 2) else 'h2'      # (the up-sampled / pooled forms issue 4 of the 9 taps)
         prof.records.append((e0, e1, prof.flops(desc), fam))
         rd, wr = prof.alg_bytes(desc)
         b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
@@ -303,6 +305,7 @@ class PackedConv:
         self._transpose = bool(transpose)
         self._w_ref = w if (MULTIPLY == 'f16x2' and len(ks) == 2) else None     # (h2_up() sums taps of the original layout on first use)
         self._h2_up = None
+        self._h2_pool = None
         if transpose:
             keep = cin if cin_keep is None else cin_keep
             self.k_real, self.m_real = cout, keep          # contraction over forward cout, produces forward cin
@@ -355,6 +358,24 @@ class PackedConv:
                     self.out_amax = torch.zeros(1, device=w.device, dtype=torch.float32)     # max |out| of this layer's last launch
                     self.in_amax = torch.zeros(1, device=w.device, dtype=torch.float32)      # scratch for an absmax pass over its input
 
+    def _h2_wsum(self) -> Tensor:
+        """[4 classes (2 py + px)][cout][cin][4 taps (2 a + b)]: the 3 x 3 taps that read ONE source pixel of a 2 x 2 nearest-up-sampled image,
+        summed (fp32) -- output pixel (2 i + py, 2 j + px) sees source rows i - 1 + py + a: py = 0: dy {0} | {1, 2}; py = 1: {0, 1} | {2}."""
+        w = self._w_ref                                        # [cout][cin][3][3], the layer's own layout
+        cout, cin = w.shape[0], w.shape[1]
+        rows = (((0,), (1, 2)), ((0, 1), (2,)))
+        wsum = torch.empty(4, cout, cin, 4, device=w.device, dtype=torch.float32)
+        for py in range(2):
+            for px in range(2):
+                for a_ in range(2):
+                    for b_ in range(2):
+                        acc = None
+                        for dy in rows[py][a_]:
+                            for dx in rows[px][b_]:
+                                acc = w[:, :, dy, dx] if acc is None else acc + w[:, :, dy, dx]
+                        wsum[2 * py + px, :, :, 2 * a_ + b_] = acc
+        return wsum
+
     def h2_up(self):
         """(packing, scale) of the f16 x 2 form over a 2 x 2 nearest-up-sampled source (sda_pack_conv_weight_h2_up), or None: the four
         output parity classes as 2 x 2-tap convolutions with pre-summed taps.  Built on first use (warm-up, never under capture)."""
@@ -362,33 +383,40 @@ class PackedConv:
             return None
         if getattr(self, '_h2_up', None) is None:
             lib = _lib.load()
-            w = self._w_ref                                    # [cout][cin][3][3]
-            cout, cin = w.shape[0], w.shape[1]
+            cout, cin = self._w_ref.shape[0], self._w_ref.shape[1]
             nbytes = int(lib.sda_conv_h2_up_packed_bytes(cout, cin))
-            if nbytes <= 0:
-                self._h2_up = False
-            else:
-                rows = (((0,), (1, 2)), ((0, 1), (2,)))       # [parity][a] -> the 3 x 3 tap indices that read source pixel a
-                wsum = torch.empty(4, cout, cin, 4, device=w.device, dtype=torch.float32)
-                for py in range(2):
-                    for px in range(2):
-                        for a_ in range(2):
-                            for b_ in range(2):
-                                acc = None
-                                for dy in rows[py][a_]:
-                                    for dx in rows[px][b_]:
-                                        acc = w[:, :, dy, dx] if acc is None else acc + w[:, :, dy, dx]
-                                wsum[2 * py + px, :, :, 2 * a_ + b_] = acc
+            self._h2_up = False
+            if nbytes > 0:
+                wsum = self._h2_wsum()
                 amax = float(wsum.abs().max())
-                if not (amax > 0.0 and math.isfinite(amax)):
-                    self._h2_up = False
-                else:
-                    buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+                if amax > 0.0 and math.isfinite(amax):
+                    buf = torch.empty(nbytes, device=wsum.device, dtype=torch.uint8)
                     _lib.check(lib.sda_pack_conv_weight_h2_up(wsum.data_ptr(), cout, cin, amax, buf.data_ptr(), _stream()),
                                'sda_pack_conv_weight_h2_up')
-                    torch.cuda.current_stream(w.device).synchronize()      # (wsum is a temporary)
+                    torch.cuda.current_stream(wsum.device).synchronize()      # (wsum is a temporary)
                     self._h2_up = (buf, float(lib.sda_conv_h2_scale(amax)))
         return self._h2_up or None
+
+    def h2_pool(self):
+        """(packing, scale) for the VJP of such a tail summed over the 2 x 2 up-sampling cells (this object is the layer's backward-data
+        form): a 2 x 2-tap convolution over the four parity planes of the fine-resolution gradient (sda_pack_conv_weight_h2_rows), or None."""
+        if self.h2 is None or not self._transpose or getattr(self, '_w_ref', None) is None:
+            return None
+        if getattr(self, '_h2_pool', None) is None:
+            lib = _lib.load()
+            cout, cin = self._w_ref.shape[0], self._w_ref.shape[1]
+            nbytes = int(lib.sda_conv_h2_rows_packed_bytes(cin, 4 * cout, 4)) if self.m_real == cin else 0
+            self._h2_pool = False
+            if nbytes > 0:
+                wrows = self._h2_wsum().permute(2, 0, 1, 3).reshape(cin, 4 * cout, 4).contiguous()      # [ci][class * cout + co][tap]
+                amax = float(wrows.abs().max())
+                if amax > 0.0 and math.isfinite(amax):
+                    buf = torch.empty(nbytes, device=wrows.device, dtype=torch.uint8)
+                    _lib.check(lib.sda_pack_conv_weight_h2_rows(wrows.data_ptr(), cin, 4 * cout, 4, amax, buf.data_ptr(), _stream()),
+                               'sda_pack_conv_weight_h2_rows')
+                    torch.cuda.current_stream(wrows.device).synchronize()
+                    self._h2_pool = (buf, float(lib.sda_conv_h2_scale(amax)))
+        return self._h2_pool or None
 
     def wino4_zp(self) -> Optional[Tensor]:
         """The zero-position packing of `wino4` (None without it): what the up-sampling tails (sda/nn.py:161-169 of the reference) and

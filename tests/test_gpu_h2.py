@@ -280,3 +280,32 @@ def test_h2_upsampled_tail_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular
     err32 = ((out32.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     print(f'up-sampled tail {cin}->{cout} @{hs}x{ws}: f16x2 parity-class form {err:.2e}, zero-position Winograd {err32:.2e} (vs float64, of max |ref|)')
     assert err < 3e-6
+
+
+@pytest.mark.parametrize('cin,cout,hs,ws,n,circular', [(192, 96, 16, 16, 2, True), (384, 192, 16, 32, 1, False), (96, 96, 32, 16, 3, True),
+                                                       (192, 96, 48, 16, 1, False)])
+def test_h2_pooled_tail_vjp_vs_float64_autograd(dev, f16x2, cin, cout, hs, ws, n, circular):
+    """The VJP of Upsample(nearest, 2) -> conv 3 x 3 (the tails' backward, sda/score.py:394 through sda/nn.py:161-169) on conv_h2's
+    parity-plane form (a 2 x 2-tap convolution over the four parity planes of the fine-resolution gradient, K = 4 x cout) against
+    float64 autograd through the up-sample and against the zero-position Winograd kernel's pooled launch."""
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(cin + hs + 3 * ws)
+    w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
+    pk = ops.PackedConv(w, None, transpose=True)
+    assert pk.h2 is not None and pk.h2_pool() is not None
+    g = torch.randn(n, cout, 2 * hs, 2 * ws, device=dev) * 0.7
+    x64 = torch.zeros(n, cin, hs, ws, dtype=torch.float64, requires_grad=True)
+    xu = x64.repeat_interleave(2, -1).repeat_interleave(2, -2)
+    xp = F.pad(xu, (1, 1, 1, 1), mode='circular') if circular else F.pad(xu, (1, 1, 1, 1))
+    ref, = torch.autograd.grad(F.conv2d(xp, w.double().cpu()), x64, g.double().cpu())
+    out = torch.full((n, cin, hs, ws), float('nan'), device=dev)
+    d = launch_conv(pk, planar_source(g), out, 2 * hs, 2 * ws, circular=circular, pool=(2, 2), x_amax=ops.absmax(g, pk.in_amax))
+    assert d is not None and d.w_h2 and d.pool_h == 2, 'the pooled launch was not served by conv_h2'
+    err = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    out32 = torch.empty_like(out)
+    d32 = launch_conv(pk, planar_source(g), out32, 2 * hs, 2 * ws, circular=circular, pool=(2, 2))
+    assert d32 is not None and not d32.w_h2
+    err32 = ((out32.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    print(f'pooled tail VJP {cout}->{cin} @{hs}x{ws}: f16x2 parity-plane form {err:.2e}, zero-position Winograd {err32:.2e} (vs float64 autograd, of max |ref|)')
+    assert err < 3e-6
