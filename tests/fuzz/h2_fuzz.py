@@ -45,6 +45,48 @@ def ref64(x, w, bias, circular, transpose, ln, mod, act_in, dact_z, res):
     return y
 
 
+def tail_case(rng, dev, idx, form, cin, cout, hs, ws, n, circular, tol):
+    """One launch of the parity-class (up-sampled tail) or parity-plane (its pooled VJP) form against float64; returns 1 on failure."""
+    w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
+    scale = 10.0 ** rng.randint(-3, 3)
+    if form == 'up':
+        ln, with_res = rng.random() < 0.7, rng.random() < 0.5
+        x = torch.randn(n, cin, hs, ws, device=dev) * scale
+        b = torch.randn(cout, device=dev)
+        pk = ops.PackedConv(w, b)
+        out = torch.full((n, cout, 2 * hs, 2 * ws), float('nan'), device=dev)
+        res = torch.randn_like(out) * scale if with_res else None
+        kw = dict(circular=circular, bias=pk.bias, up=(2, 2), res=res)
+        x64 = x.double().cpu()
+        if ln:
+            var, mean = torch.var_mean(x, dim=1, unbiased=True)
+            kw['ln'] = (mean.reshape(-1).contiguous(), (1 / torch.sqrt(var + 1e-5)).reshape(-1).contiguous())
+            v64, m64 = torch.var_mean(x64, dim=1, unbiased=True, keepdim=True)
+            x64 = (x64 - m64) / torch.sqrt(v64 + 1e-5)
+        xu = x64.repeat_interleave(2, -1).repeat_interleave(2, -2)
+        xp = F.pad(xu, (1, 1, 1, 1), mode='circular') if circular else F.pad(xu, (1, 1, 1, 1))
+        ref = F.conv2d(xp, w.double().cpu(), b.double().cpu())
+        if res is not None:
+            ref = ref + res.double().cpu()
+        d = launch_conv(pk, planar_source(x), out, 2 * hs, 2 * ws, x_amax=None if ln else ops.absmax(x, pk.in_amax), **kw)
+        ok = bool(d.w_h2) and d.up_h == 2
+    else:
+        pk = ops.PackedConv(w, None, transpose=True)
+        g = torch.randn(n, cout, 2 * hs, 2 * ws, device=dev) * scale
+        x64 = torch.zeros(n, cin, hs, ws, dtype=torch.float64, requires_grad=True)
+        xu = x64.repeat_interleave(2, -1).repeat_interleave(2, -2)
+        xp = F.pad(xu, (1, 1, 1, 1), mode='circular') if circular else F.pad(xu, (1, 1, 1, 1))
+        ref, = torch.autograd.grad(F.conv2d(xp, w.double().cpu()), x64, g.double().cpu())
+        out = torch.full((n, cin, hs, ws), float('nan'), device=dev)
+        d = launch_conv(pk, planar_source(g), out, 2 * hs, 2 * ws, circular=circular, pool=(2, 2), x_amax=ops.absmax(g, pk.in_amax))
+        ok = d is not None and bool(d.w_h2) and d.pool_h == 2
+    e = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    if not ok or not (e <= tol):
+        print(f'FAIL case {idx}: {form} cin {cin} cout {cout} {hs}x{ws} n {n} {"circ" if circular else "zero"} x~{scale:.0e}: served {ok}, err {e:.2e}')
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
@@ -63,6 +105,12 @@ def main():
         if n * cin * cout * h * w_ > 3.5e9:
             n = 1
         transpose, circular = rng.random() < 0.4, rng.random() < 0.6
+        form = rng.choice(['conv', 'conv', 'conv', 'up', 'pool'])       # up: 2 x 2 up-sampled source (the tails); pool: their VJP summed over the cells
+        if form != 'conv':
+            fails_here = tail_case(rng, dev, idx, form, cin, cout, h, w_, n, circular, args.tol)
+            served += 1
+            fails += fails_here
+            continue
         loader = rng.choice(['plain', 'plain', 'silu', 'ln', 'modln'])
         epi = rng.choice(['none', 'none', 'res', 'dact']) if loader != 'ln' or True else 'none'
         scale = 10.0 ** rng.randint(-4, 4)
