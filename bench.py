@@ -262,10 +262,10 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
         alg = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
         # (zero-position form of conv_wino4: 54 of the 96 multiplies of a Winograd stage are issued)
         # (f16 x 2 direct convolution: three f16 MFMA products per multiply, priced against the f16 matrix peak)
-        issued = alg / 4.0 if name == 'wino4zp' else alg / 2.25 if name.startswith('wino') else 3.0 * alg if name == 'h2' else 3.0 * alg * 4 / 9 if name == 'h2up' else alg
+        issued = alg / 4.0 if name == 'wino4zp' else alg / 2.25 if name.startswith('wino') else 3.0 * alg if name in ('h2', 'h2s2') else 3.0 * alg * 4 / 9 if name == 'h2up' else alg
         fam[name] = {'launches_per_step': r['launches'] / prof_steps, 'ms_per_step': r['ms'] / prof_steps,
                      'share_of_step': r['ms'] * 1e-3 / prof_steps / step_s,
-                     'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / (PEAK_MFMA_F16 if name in ('h2', 'h2up') else PEAK_MFMA_F32),
+                     'algorithmic_tflops': alg, 'issued_mfma_tflops': issued, 'mfma_util': issued / (PEAK_MFMA_F16 if name in ('h2', 'h2up', 'h2s2') else PEAK_MFMA_F32),
                      'avg_launch_ms': r['ms'] / max(1, r['launches']),
                      'avg_launch_gflop_algorithmic': r['flops'] / max(1, r['launches']) / 1e9}
         if name in prof.family_bytes:
@@ -288,6 +288,7 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
             traffic = tracked.get('hbm_bytes_per_launch')
             break
     kernel = {'h2': 'conv_h2_kernel (direct 3x3, fp32 multiply emulated as three f16 products, v_mfma_f32_32x32x16_f16)',
+              'h2s2': 'conv_h2_kernel, stride-2 forms (heads over input parity planes, their VJP as four output parity classes: 1 / 2 / 2 / 4 taps)',
               'h2up': 'conv_h2_kernel, up-sampled form (four output parity classes of 2 x 2 pre-summed taps: 4 of 9 taps issued)',
               'wino4': 'conv_wino4_kernel (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)',
               'wino4zp': 'conv_wino4_kernel, zero-position form (up-sampling tails and their VJP: 9 of 16 Winograd positions)',

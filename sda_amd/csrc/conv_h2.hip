@@ -104,11 +104,22 @@ struct h2_args {
 // a 2 x 2-tap convolution over the four PARITY PLANES of the fine-resolution gradient as 4 x as many input channels.  A stage is then
 // (class, 16 channels): the producers sample the class's plane (stride-2 address plan + a class offset on the scalar base), the
 // consumers shift their tile origin per stage; the output is the low-resolution tensor itself.
+// MODE 3 = the VJP of a STRIDE-2 3 x 3 convolution (the level heads, sda/nn.py:152-159; sda_conv_desc.zins_h = zins_w = 2): output pixel
+// 2 m + p receives tap 1 from g[m] (p = 0) or taps 0, 2 from g[m + 1], g[m] (p = 1) per axis -- the four output parity classes are 1 x 1,
+// 1 x 2, 2 x 1 and 2 x 2-tap convolutions of g (what csrc/conv_par4.hip runs on the fp32 pipe): MODE 1's structure with a per-class tap
+// count.  MODE 4 = that head's FORWARD (stride_h = stride_w = 2): the transpose -- input parity planes as in MODE 2, 1 / 2 / 2 / 4 taps
+// per stage class.  Both issue exactly the 9 taps of the layer.
 template <int LOADER, int MODE = 0, int ABL = 0>         // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
 __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
-    constexpr int NT = MODE == 0 ? 9 : 4;
-    constexpr int ASLAB = NT * 3 * 2 * 1024;                        // bytes of a stage's weight slab (its LDS region is H2_ASLAB)
-    const int PH = MODE == 2 ? d.hs >> 1 : d.hs, PW = MODE == 2 ? d.ws >> 1 : d.ws;      // the grid the tiles walk (MODE 2: a parity plane)
+    constexpr bool PLANES = MODE == 2 || MODE == 4;                 // the producers sample input parity planes; the class changes per STAGE
+    constexpr bool SCATTER = MODE == 1 || MODE == 3;                // a tile writes one output parity class; the class changes per TILE
+    constexpr bool VTAPS = MODE == 3 || MODE == 4;                  // (1 + py) x (1 + px) taps per class instead of 4
+    constexpr int NT = MODE == 0 ? 9 : 4;                           // (most) taps of a stage
+    constexpr int TAPB = 3 * 2 * 1024;                              // bytes of one tap's weight fragments
+    const int PH = PLANES ? d.hs >> 1 : d.hs, PW = PLANES ? d.ws >> 1 : d.ws;            // the grid the tiles walk (PLANES: a parity plane)
+    // taps of class c = 2 py + px, and the taps of the classes before it
+    auto cls_nt = [](int c) { return VTAPS ? (1 + (c >> 1)) * (1 + (c & 1)) : NT; };
+    auto cls_cum = [](int c) { return VTAPS ? ((0x5310 >> (4 * c)) & 15) : NT * c; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         struct plan_t {
             const float* ximg;                                      // image + channel ch8
             const float* modp;
-            const unsigned char* wsl;                               // the cout tile's weight slabs
+            int ct;                                                 // cout tile (SCATTER: class * cout tiles + cout tile)
             unsigned goff[H2_PRND];                                 // BYTE offsets of the pixels (scalar base + 32-bit lane offset loads)
             float mean[H2_PRND], rstd[H2_PRND];
             unsigned valid;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             const int oy0 = by * H2_TS, ox0 = bx * H2_TS;
             P.ximg = d.x + (int64_t)n * d.x_sn_outer + (int64_t)ch8 * d.x_sc;
             P.modp = (LOADER == 2 && d.mod) ? d.mod + (int64_t)n * d.mod_sn + ch8 : nullptr;
-            P.wsl = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)ct * a.nchunk * ASLAB;     // (ct: class-major when NT == 4)
+            P.ct = ct;
             P.valid = 0;
 #pragma unroll
             for (int r = 0; r < H2_PRND; ++r) {
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                 }
                 y = ok ? y : 0;
                 x = ok ? x : 0;
-                P.goff[r] = 4u * (unsigned)((MODE == 2 ? 2 : 1) * (y * (int)d.x_sy + x * (int)d.x_sx));
+                P.goff[r] = 4u * (unsigned)((PLANES ? 2 : 1) * (y * (int)d.x_sy + x * (int)d.x_sx));
                 P.valid |= ok ? (1u << r) : 0u;
                 if (LOADER == 2) {
                     const int64_t sp = (int64_t)n * d.hs * d.ws + (int64_t)y * d.ws + x;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         auto load_from = [&](const float* ximg, const unsigned (&goff)[H2_PRND], int chunk, float (&v)[H2_PRND][8]) {
             if (ABL & 2) return;
             // (MODE 2: stage = class * c16 + chunk; the class's parity plane starts (py, px) pixels into the image)
-            const int cls = MODE == 2 ? chunk / a.c16 : 0, ck = MODE == 2 ? chunk - cls * a.c16 : chunk;
+            const int cls = PLANES ? chunk / a.c16 : 0, ck = PLANES ? chunk - cls * a.c16 : chunk;
             const char* src = reinterpret_cast<const char*>(ximg + (int64_t)ck * H2_CK * d.x_sc + (cls >> 1) * d.x_sy + (cls & 1) * d.x_sx);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -197,17 +208,32 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         auto load_stage = [&](const plan_t& P, int chunk, float (&v)[H2_PRND][8]) { load_from(P.ximg, P.goff, chunk, v); };
         // LDS-DMA by inline asm: hipcc does not count it (the waits are ours, below), and -- unlike the builtin -- it does not make hipcc
         // drain vmcnt in front of every LDS access and register-load use of the loop.
+        // a stage's weight slab: [MODE 0] cout tile, chunk; [SCATTER] class (of the tile), cout tile, chunk; [MODE 2] cout tile, stage;
+        // [MODE 4] class (of the stage), cout tile, chunk -- classes outermost, each with its own tap count
+        auto slab_of = [&](const plan_t& P, int chunk, int& nt) -> const unsigned char* {
+            const unsigned char* w0 = reinterpret_cast<const unsigned char*>(a.w);
+            if (MODE == 0 || MODE == 2) { nt = NT; return w0 + ((int64_t)P.ct * a.nchunk + chunk) * (NT * TAPB); }
+            if (SCATTER) {
+                const int nct1 = a.n_ct >> 2, cls = P.ct / nct1, ct = P.ct - cls * nct1;
+                nt = cls_nt(cls);
+                return w0 + ((int64_t)cls_cum(cls) * nct1 * a.nchunk + ((int64_t)ct * a.nchunk + chunk) * nt) * TAPB;
+            }
+            const int cls = chunk / a.c16, ck = chunk - cls * a.c16;                       // MODE 4
+            nt = cls_nt(cls);
+            return w0 + ((int64_t)cls_cum(cls) * a.n_ct * a.c16 + ((int64_t)P.ct * a.c16 + ck) * nt) * TAPB;
+        };
         auto dma_weights = [&](const plan_t& P, int chunk, int bufsel) {
             if (ABL & 1) return;
-            const unsigned char* src = P.wsl + (int64_t)chunk * ASLAB + lane * 16;
+            int nt;
+            const unsigned char* src = slab_of(P, chunk, nt) + lane * 16;
             const unsigned lds0 = __builtin_amdgcn_readfirstlane(
                 (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(smem + bufsel * H2_STAGE)));
-            // NT * 6 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
-            constexpr int NPC = NT * 6;
+            // nt * 6 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
+            const int npc = nt * 6;
 #pragma unroll
-            for (int k = 0; k < (NPC + 3) / 4; ++k) {
+            for (int k = 0; k < (NT * 6 + 3) / 4; ++k) {
                 const int piece = pw + 4 * k;
-                if (4 * k + 3 < NPC || piece < NPC) {
+                if (piece < npc) {
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(src + piece * 1024), "s"(lds0 + piece * 1024) : "memory");
@@ -323,12 +349,11 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         const int bx = t % a.tiles_x; t /= a.tiles_x;
         const int by = t % a.tiles_y;
         const int n = t / a.tiles_y;
-        // NT == 4: cta = class * (cout tiles) + cout tile; class (py, px) = the output parity this tile writes
-        const int nct1 = MODE == 1 ? a.n_ct >> 2 : a.n_ct;
-        const int cls = MODE == 1 ? cta / nct1 : 0, ct = MODE == 1 ? cta - cls * nct1 : cta;
+        // SCATTER: cta = class * (cout tiles) + cout tile; class (py, px) = the output parity this tile writes
+        const int nct1 = SCATTER ? a.n_ct >> 2 : a.n_ct;
+        const int cls = SCATTER ? cta / nct1 : 0, ct = SCATTER ? cta - cls * nct1 : cta;
         const int cy = cls >> 1, cx = cls & 1;
         const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
-        const int b_rd_t = b_rd + (MODE == 1 ? (cy * H2_HS + cx) * H2_PXB : 0);
 
         h2_f16v acc[3][2];
 #pragma unroll
@@ -341,65 +366,79 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
             H2_BARRIER_CONSUMER();                                  // the stage is published (and the other buffer released)
             const unsigned char* st = smem + (chunk & 1) * H2_STAGE;
-            const int scls = MODE == 2 ? chunk / a.c16 : 0;
-            const int b_rd_s = b_rd + ((2 - (scls >> 1)) * H2_HS + (2 - (scls & 1))) * H2_PXB;
+            // the stage's tap geometry: tap (ta, tb) reads halo pixel (oyb + ta oys, oxb + tb oxs) + the tile pixel
+            //   MODE 0: the 3 x 3 window.   MODE 1 (class of the tile): (py + ta, px + tb).   MODE 2 (class of the stage): (2 - py - ta, ..).
+            //   MODE 3 (tile): 1 + py taps, (1 + py - ta): tap 0 = forward tap 0 from g[m + 1], tap 1 = forward tap 2 from g[m]; one tap: tap 1, g[m].
+            //   MODE 4 (stage): 1 + py taps, py ? (ta) : (1): plane 0 gives tap 1 at row i; plane 1 gives tap 0 at row i - 1 and tap 2 at row i.
+            const int scls = PLANES ? chunk / a.c16 : cls;
+            const int spy = scls >> 1, spx = scls & 1;
+            const int nx = VTAPS ? 1 + spx : (NT == 9 ? 3 : 2);
+            const int oyb = MODE == 1 ? spy : MODE == 2 ? 2 - spy : MODE == 3 ? 1 + spy : MODE == 4 ? 1 - spy : 0;
+            const int oxb = MODE == 1 ? spx : MODE == 2 ? 2 - spx : MODE == 3 ? 1 + spx : MODE == 4 ? 1 - spx : 0;
+            const int ost = (MODE == 2 || MODE == 3) ? -1 : 1;
+            const int nt = cls_nt(scls);                            // (wave-uniform; VTAPS: 1, 2 or 4 of the body's 4 taps run)
             h2_h8 A[2][3][2], B[2][2][2];                           // [set][fragment][piece]
-            auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
-                const int dy = NT == 4 ? tap >> 1 : tap / 3, dx = NT == 4 ? tap & 1 : tap - 3 * dy;
-                const unsigned char* pa = st + a_rd + tap * (3 * 2 * 1024);
-                // (MODE 2: tap (a, b) of class (py, px) reads halo pixel (2 - py - a, 2 - px - b) + the tile pixel)
-                const unsigned char* pb = MODE == 2 ? st + b_rd_s - (dy * H2_HS + dx) * H2_PXB : st + b_rd_t + (dy * H2_HS + dx) * H2_PXB;
+            auto stage_body = [&](auto ntc_) {
+                constexpr int NTc = decltype(ntc_)::value;
+                auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
+                    const int ta = NTc == 9 ? tap / 3 : VTAPS ? (nx == 1 ? tap : tap >> 1) : tap >> 1;
+                    const int tb = NTc == 9 ? tap - 3 * ta : VTAPS ? (nx == 1 ? 0 : tap & 1) : tap & 1;
+                    const unsigned char* pa = st + a_rd + tap * TAPB;
+                    const unsigned char* pb = st + b_rd + ((oyb + ta * ost) * H2_HS + (oxb + tb * ost)) * H2_PXB;
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    Bd[f][0] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB);
-                    Bd[f][1] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB + 32);
-                }
+                    for (int f = 0; f < 2; ++f) {
+                        Bd[f][0] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB);
+                        Bd[f][1] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB + 32);
+                    }
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    Ad[m][0] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 0) * 1024);
-                    Ad[m][1] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 1) * 1024);
+                    for (int m = 0; m < 3; ++m) {
+                        Ad[m][0] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 0) * 1024);
+                        Ad[m][1] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 1) * 1024);
+                    }
+                };
+                load_AB(0, A[0], B[0]);
+#pragma unroll
+                for (int tap = 0; tap < NTc; ++tap) {
+                    const int s = tap & 1;
+                    if (VTAPS && tap >= nt) break;                  // (wave-uniform: this class has 1, 2 or 4 taps)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap < NTc - 1 && (!VTAPS || tap + 1 < nt)) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
+                    if (ABL & 4) {                                  // (keep the operands alive without multiplying)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][f][0][0] + (float)B[s][f][1][0];
+                    } else {
+                        // small products first (fp32 accumulation)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+#pragma unroll
+                            for (int f = 0; f < 2; ++f)
+                                acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][1], acc[m][f], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+#pragma unroll
+                            for (int f = 0; f < 2; ++f)
+                                acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][1], B[s][f][0], acc[m][f], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+#pragma unroll
+                            for (int f = 0; f < 2; ++f)
+                                acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][0], acc[m][f], 0, 0, 0);
+                        // the tap's issue order: the next tap's ten operand reads between the first MFMAs
+                        if (tap < NTc - 1) {
+#pragma unroll
+                            for (int k = 0; k < 10; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            load_AB(0, A[0], B[0]);
-#pragma unroll
-            for (int tap = 0; tap < NT; ++tap) {
-                const int s = tap & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap < NT - 1) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
-                if (ABL & 4) {                                      // (keep the operands alive without multiplying)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][f][0][0] + (float)B[s][f][1][0];
-                } else {
-                    // small products first (fp32 accumulation)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int f = 0; f < 2; ++f)
-                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][1], acc[m][f], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int f = 0; f < 2; ++f)
-                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][1], B[s][f][0], acc[m][f], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < 3; ++m)
-#pragma unroll
-                        for (int f = 0; f < 2; ++f)
-                            acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][0], acc[m][f], 0, 0, 0);
-                    // the tap's issue order: the next tap's ten operand reads between the first MFMAs
-                    if (tap < NT - 1) {
-#pragma unroll
-                        for (int k = 0; k < 10; ++k) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            stage_body(std::integral_constant<int, NT>{});
         }
 
         // ---- epilogue.  acc[m][f][r]: cout co0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), pixel row oy0 + 4 wave + 2 f + prow,
@@ -407,11 +446,11 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         const float inv = 1.0f / (sx * a.w_scale);
         const int OH = MODE == 2 ? d.ho >> 1 : d.ho, OW = MODE == 2 ? d.wo >> 1 : d.wo;      // (MODE 2: `out` is the pooled tensor)
         const int64_t osn = (int64_t)d.cout * OH * OW, osc = (int64_t)OH * OW;
-        // (MODE 1: this tile writes the pixels (2 y + cy, 2 x + cx) of the up-sampled grid: every other pixel of every other row)
-        const int64_t obase = MODE == 1
+        // (SCATTER: this tile writes the pixels (2 y + cy, 2 x + cx) of the fine grid: every other pixel of every other row)
+        const int64_t obase = SCATTER
             ? (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(2 * (oy0 + 4 * wave + prow) + cy) * OW + 2 * (ox0 + pcol) + cx
             : (int64_t)n * osn + (int64_t)(co0 + 4 * (lane >> 5)) * osc + (int64_t)(oy0 + 4 * wave + prow) * OW + ox0 + pcol;
-        constexpr int FROW = MODE == 1 ? 4 : 2;                     // output rows between a wave's two pixel fragments
+        constexpr int FROW = SCATTER ? 4 : 2;                     // output rows between a wave's two pixel fragments
         // (the epilogue's mode is decided ONCE, by uniform branches around straight-line copies: tested per element the compiler emits a
         //  branch per store.)  A cout fragment's operands are requested together, before its first store.
         auto epilogue = [&](auto mode, auto with_bias) {
@@ -533,7 +572,7 @@ extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, 
 // pooled tail VJP (conv_h2_kernel<.., 2>) takes rows = the forward cin, k = 4 classes x the forward cout (class-major), 4 taps:
 // w[ci][class * cout + co][2 a + b] = wsum[class][co][ci][2 a + b] of sda_pack_conv_weight_h2_up.
 extern "C" int64_t sda_conv_h2_rows_packed_bytes(int rows, int k, int ntap) {
-    if (rows <= 0 || k <= 0 || rows % H2_BM || k % H2_KQ || (ntap != 4 && ntap != 9)) return 0;
+    if (rows <= 0 || k <= 0 || rows % H2_BM || k % H2_KQ || (ntap != 1 && ntap != 2 && ntap != 4 && ntap != 9)) return 0;
     return (int64_t)(rows / H2_BM) * (k / H2_CK) * ((int64_t)ntap * 3 * 2 * 1024);
 }
 
@@ -586,16 +625,21 @@ extern "C" int sda_absmax(const float* x, int64_t numel, float* amax, void* stre
 // ------------------------------------------------------------------------------------------------------------------- launcher
 static bool h2_ok(const sda_conv_desc* d) {
     if (!d || !d->x || !d->out || !d->w_h2) return false;
-    const bool up = d->up_h == 2 && d->up_w == 2;                  // (w_h2 is then sda_pack_conv_weight_h2_up's packing)
-    const bool pool = d->pool_h == 2 && d->pool_w == 2;            // (... sda_pack_conv_weight_h2_rows' of the class-major transpose)
-    if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->explicit_pad || !(up || (d->up_h == 1 && d->up_w == 1)) ||
-        d->zins_h != 1 || d->zins_w != 1 || !(pool || (d->pool_h <= 1 && d->pool_w <= 1)) || (up && pool))
+    const bool up = d->up_h == 2 && d->up_w == 2;                  // MODE 1 (w_h2 = sda_pack_conv_weight_h2_up's packing)
+    const bool pool = d->pool_h == 2 && d->pool_w == 2;            // MODE 2 (sda_pack_conv_weight_h2_rows of the class-major transpose)
+    const bool zins = d->zins_h == 2 && d->zins_w == 2;            // MODE 3 (the four classes' sda_pack_conv_weight_h2_rows packings, back to back)
+    const bool s2 = d->stride_h == 2 && d->stride_w == 2;          // MODE 4 (the same, forward orientation)
+    if (d->kh != 3 || d->kw != 3 || d->explicit_pad || (int)up + (int)pool + (int)zins + (int)s2 > 1) return false;
+    if (!(s2 || (d->stride_h == 1 && d->stride_w == 1)) || !(up || (d->up_h == 1 && d->up_w == 1)) ||
+        !(zins || (d->zins_h == 1 && d->zins_w == 1)) || !(pool || (d->pool_h <= 1 && d->pool_w <= 1)))
         return false;
     if (d->cctx != 0 || d->n_inner != 1 || d->x_n_off != 0) return false;
-    const int us = up ? 2 : 1, ts = pool ? 2 * H2_TS : H2_TS;
-    if (d->cx % H2_KQ || d->cout % H2_BM || d->ho != us * d->hs || d->wo != us * d->ws || d->hs % ts || d->ws % ts) return false;
+    const int ts = (pool || s2) ? 2 * H2_TS : H2_TS;               // source pixels per tile side
+    if (d->cx % H2_KQ || d->cout % H2_BM || d->hs % ts || d->ws % ts) return false;
+    if (s2 ? (2 * d->ho != d->hs || 2 * d->wo != d->ws) : (d->ho != ((up || zins) ? 2 : 1) * d->hs || d->wo != ((up || zins) ? 2 : 1) * d->ws)) return false;
     if (up && (d->dact_z || d->act_in != SDA_ACT_NONE)) return false;
     if (pool && (d->dact_z || d->res || d->bias || d->ln_mean || d->act_in != SDA_ACT_NONE)) return false;
+    if ((zins || s2) && (d->dact_z || d->ln_mean || d->act_in != SDA_ACT_NONE)) return false;
     if (d->out_sn || d->out_sc || d->out_sy || d->out_sx) return false;
     if ((d->ln_mean == nullptr) != (d->ln_rstd == nullptr)) return false;
     if (d->mod && !d->ln_mean) return false;
@@ -606,7 +650,7 @@ static bool h2_ok(const sda_conv_desc* d) {
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 ||
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
-    const int64_t tiles = (int64_t)d->n * (d->hs / ts) * (d->ws / ts) * (d->cout / H2_BM) * (up ? 4 : 1);
+    const int64_t tiles = (int64_t)d->n * (d->hs / ts) * (d->ws / ts) * (d->cout / H2_BM) * ((up || zins) ? 4 : 1);
     return tiles >= 1 && tiles <= 0x3fffffffLL;
 }
 
@@ -620,12 +664,13 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     a.x_amax = d->x_amax;
     a.x_amax_static = d->x_amax_static;
     a.out_amax = d->out_amax;
-    const bool up = d->up_h == 2, pool = d->pool_h == 2;
-    a.tiles_x = d->ws / (pool ? 2 * H2_TS : H2_TS);                // (tiles of the grid the kernel walks: the source grid, or one of its parity planes)
-    a.tiles_y = d->hs / (pool ? 2 * H2_TS : H2_TS);
-    a.n_ct = (d->cout / H2_BM) * (up ? 4 : 1);
+    const bool up = d->up_h == 2, pool = d->pool_h == 2, zins = d->zins_h == 2, s2 = d->stride_h == 2;
+    const bool planes = pool || s2;
+    a.tiles_x = d->ws / (planes ? 2 * H2_TS : H2_TS);              // (tiles of the grid the kernel walks: the source grid, or one of its parity planes)
+    a.tiles_y = d->hs / (planes ? 2 * H2_TS : H2_TS);
+    a.n_ct = (d->cout / H2_BM) * ((up || zins) ? 4 : 1);
     a.c16 = d->cx / H2_CK;
-    a.nchunk = a.c16 * (pool ? 4 : 1);
+    a.nchunk = a.c16 * (planes ? 4 : 1);
     a.stagger = 0;
 #ifdef SDA_H2_ABLATE
     { static const int stg = getenv("SDA_H2_STAGGER") ? atoi(getenv("SDA_H2_STAGGER")) : 0; a.stagger = stg; }
@@ -653,6 +698,18 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
         }
     }
 #endif
+    if (zins || s2) {                                              // (the stride-2 heads and their VJP: plain loader)
+        if (zins) {
+            static bool setz[SDA_MAX_DEVICES];
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 3>), lds, setz)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<0, 3>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+        } else {
+            static bool sets[SDA_MAX_DEVICES];
+            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), lds, sets)) != SDA_OK) return rc;
+            hipLaunchKernelGGL((conv_h2_kernel<0, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
+        }
+        return sda_launch_status();
+    }
     if (pool) {                                                    // (the tails' VJP: plain loader, no epilogue operand)
         static bool setp0[SDA_MAX_DEVICES];
         if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 2>), lds, setp0)) != SDA_OK) return rc;

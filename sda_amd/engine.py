@@ -214,6 +214,10 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
             packing = pk.h2_up() if ops.H2_UP else None
             if packing is None:
                 bound = None                             # -> the zero-position Winograd kernel
+        elif tuple(zins) == (2, 2) or tuple(stride) == (2, 2):      # the stride-2 heads / their VJP: per-class tap lists
+            packing = (pk.h2_zins() if tuple(zins) == (2, 2) else pk.h2_s2()) if ops.H2_S2 else None
+            if packing is None:
+                bound = None                             # -> the fp32 direct kernels
         if ops.conv_h2(d, pk, bound, out_amax, packing=packing):
             return d
     if parity4_w is not None:
@@ -557,7 +561,10 @@ class UNetEngine:
             else:
                 ho, wo = conv_out_size(h, hd.kh, hd.sh), conv_out_size(w, hd.kw, hd.sw)
                 a2 = torch.empty(n, lev.C, ho, wo, device=dev, dtype=torch.float32)
-                launch_conv(pk, planar_source(a), a2, ho, wo, circular=hd.circular, stride=(hd.sh, hd.sw), bias=pk.bias)
+                xa = None
+                if ops.MULTIPLY == 'f16x2' and ops.H2_S2 and (hd.sh, hd.sw) == (2, 2) and getattr(pk, 'h2', None) is not None and a.is_contiguous():
+                    xa = ops.absmax(a, pk.in_amax)       # (the f16 x 2 parity-plane form needs its input's scale: one streaming read)
+                launch_conv(pk, planar_source(a), a2, ho, wo, circular=hd.circular, stride=(hd.sh, hd.sw), bias=pk.bias, x_amax=xa)
                 a = a2
             h, w = ho, wo
             dims.append((h, w))
@@ -699,7 +706,14 @@ class UNetEngine:
                 skip = g_skip.pop(lvl - 1)
                 classes = hd.bwd_parity() if PARITY_SPLIT and hu % hd.sh == 0 and wu % hd.sw == 0 else None
                 done = False
-                if classes is not None and ops.PARITY4:
+                if (ops.MULTIPLY == 'f16x2' and ops.H2_S2 and (hd.sh, hd.sw) == (2, 2) and g.is_contiguous() and skip.is_contiguous() and
+                        skip.shape == g2.shape and g.shape[2] % 16 == 0 and g.shape[3] % 16 == 0 and hd.bwd().h2_zins() is not None):
+                    # f16 x 2 route: the four output parity classes as 1 / 2 / 2 / 4-tap convolutions of g on conv_h2 (PackedConv.h2_zins).
+                    # (Were the launch not served after all, launch_conv has run the general zero-insertion kernel: correct, slower.)
+                    xa = g_amax if g_amax is not None else ops.absmax(g, hd.bwd().in_amax)
+                    done = launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw), res=skip,
+                                       x_amax=xa) is not None
+                if not done and classes is not None and ops.PARITY4:
                     w4 = hd.bwd_parity4()
                     # (the one-launch kernel addresses the skip gradient with the OUTPUT strides: same layout required)
                     if w4 is not None and skip.is_contiguous() and skip.shape == g2.shape:

@@ -38,6 +38,8 @@ def set_multiply(mode: str) -> str:
 H2_UP = os.environ.get('SDA_H2_UP', '1') != '0'
 #: ... and their pooled VJP on the parity-plane form (SDA_H2_POOL=0: the zero-position Winograd kernel)
 H2_POOL = os.environ.get('SDA_H2_POOL', '1') != '0'
+#: ... and the stride-2 heads with their VJP on the per-class tap lists (SDA_H2_S2=0: the fp32 direct / conv_par4 kernels)
+H2_S2 = os.environ.get('SDA_H2_S2', '1') != '0'
 
 
 def tensor_version(t) -> int:
@@ -186,7 +188,8 @@ def conv_igemm(desc: ConvDesc):
         _lib.check(lib.sda_conv_igemm(ctypes.byref(desc), _stream()), 'sda_conv_igemm')
         e1.record()
         fam = CONV_FAMILIES[max(0, conv_path(desc))]
-        prof.records.append((e0, e1, prof.flops(desc), fam))
+        # (a zero-insertion launch multiplies a quarter of what its fine-resolution output size says: 9 taps per SOURCE pixel)
+        prof.records.append((e0, e1, prof.flops(desc) / (4.0 if desc.zins_h == 2 else 1.0), fam))
         rd, wr = prof.alg_bytes(desc)
         b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
         b[0] += rd
@@ -232,8 +235,10 @@ def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]
     _lib.check(lib.sda_conv_h2(ctypes.byref(desc), _stream()), 'sda_conv_h2')
     if prof is not None:
         e1.record()
-        fam = 'h2up' if (desc.up_h == 2 or desc.pool_h == 2) else 'h2'      # (the up-sampled / pooled forms issue 4 of the 9 taps)
-        prof.records.append((e0, e1, prof.flops(desc), fam))
+        # (the up-sampled / pooled forms issue 4 of the 9 taps; the stride-2 forms all 9, at a quarter of the fine-resolution pixels)
+        fam = 'h2up' if (desc.up_h == 2 or desc.pool_h == 2) else 'h2s2' if (desc.zins_h == 2 or desc.stride_h == 2) else 'h2'
+        # (a zero-insertion launch multiplies a quarter of what its fine-resolution output size says: 9 taps per SOURCE pixel)
+        prof.records.append((e0, e1, prof.flops(desc) / (4.0 if desc.zins_h == 2 else 1.0), fam))
         rd, wr = prof.alg_bytes(desc)
         b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
         b[0] += rd
@@ -306,6 +311,8 @@ class PackedConv:
         self._w_ref = w if (MULTIPLY == 'f16x2' and len(ks) == 2) else None     # (h2_up() sums taps of the original layout on first use)
         self._h2_up = None
         self._h2_pool = None
+        self._h2_zins = None
+        self._h2_s2 = None
         if transpose:
             keep = cin if cin_keep is None else cin_keep
             self.k_real, self.m_real = cout, keep          # contraction over forward cout, produces forward cin
@@ -417,6 +424,48 @@ class PackedConv:
                     torch.cuda.current_stream(wrows.device).synchronize()
                     self._h2_pool = (buf, float(lib.sda_conv_h2_scale(amax)))
         return self._h2_pool or None
+
+    def _h2_classes(self, vjp: bool):
+        """(packing, scale) of a STRIDE-2 3 x 3 layer on conv_h2's per-class tap lists (csrc/conv_h2.hip MODE 3 / 4): class (py, px) has the
+        taps dy in ((1,), (0, 2))[py], dx alike -- 1 / 2 / 2 / 4 of the layer's 9 -- packed class after class by
+        sda_pack_conv_weight_h2_rows; vjp: rows = forward cin, K = forward cout (the input VJP), else the forward orientation."""
+        lib = _lib.load()
+        w = self._w_ref                                        # [cout][cin][3][3]
+        cout, cin = w.shape[0], w.shape[1]
+        rows, k = (cin, cout) if vjp else (cout, cin)
+        sizes = [int(lib.sda_conv_h2_rows_packed_bytes(rows, k, (1 + (c >> 1)) * (1 + (c & 1)))) for c in range(4)]
+        amax = float(w.abs().max())
+        if min(sizes) <= 0 or not (amax > 0.0 and math.isfinite(amax)):
+            return False
+        buf = torch.empty(sum(sizes), device=w.device, dtype=torch.uint8)
+        taps = ((1,), (0, 2))
+        off = 0
+        for c in range(4):
+            wc = torch.stack([w[:, :, dy, dx] for dy in taps[c >> 1] for dx in taps[c & 1]], dim=-1)      # [cout][cin][nt]
+            if vjp:
+                wc = wc.permute(1, 0, 2)
+            wc = wc.contiguous()
+            _lib.check(lib.sda_pack_conv_weight_h2_rows(wc.data_ptr(), rows, k, wc.shape[-1], amax, buf[off:].data_ptr(), _stream()),
+                       'sda_pack_conv_weight_h2_rows')
+            torch.cuda.current_stream(w.device).synchronize()  # (wc is a temporary)
+            off += sizes[c]
+        return (buf, float(lib.sda_conv_h2_scale(amax)))
+
+    def h2_zins(self):
+        """The input VJP of a stride-2 3 x 3 layer (this object is its backward-data form) on conv_h2's parity-class form, or None."""
+        if self.h2 is None or not self._transpose or getattr(self, '_w_ref', None) is None or self.m_real != self._w_ref.shape[1]:
+            return None
+        if getattr(self, '_h2_zins', None) is None:
+            self._h2_zins = self._h2_classes(True)
+        return self._h2_zins or None
+
+    def h2_s2(self):
+        """A stride-2 3 x 3 layer on conv_h2's parity-plane form (forward), or None."""
+        if self.h2 is None or self._transpose or getattr(self, '_w_ref', None) is None:
+            return None
+        if getattr(self, '_h2_s2', None) is None:
+            self._h2_s2 = self._h2_classes(False)
+        return self._h2_s2 or None
 
     def wino4_zp(self) -> Optional[Tensor]:
         """The zero-position packing of `wino4` (None without it): what the up-sampling tails (sda/nn.py:161-169 of the reference) and

@@ -309,3 +309,47 @@ def test_h2_pooled_tail_vjp_vs_float64_autograd(dev, f16x2, cin, cout, hs, ws, n
     err32 = ((out32.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     print(f'pooled tail VJP {cout}->{cin} @{hs}x{ws}: f16x2 parity-plane form {err:.2e}, zero-position Winograd {err32:.2e} (vs float64 autograd, of max |ref|)')
     assert err < 3e-6
+
+
+@pytest.mark.parametrize('cin,cout,hs,ws,n,circular', [(96, 192, 32, 32, 2, True), (192, 384, 32, 64, 1, False), (96, 96, 64, 32, 3, True),
+                                                       (96, 192, 96, 32, 1, False)])
+def test_h2_stride2_head_and_its_vjp_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular):
+    """The level heads (3 x 3, stride 2: sda/nn.py:152-159) on conv_h2's per-class tap lists: forward over the four input parity planes
+    (MODE 4), input VJP as four output parity classes of 1 / 2 / 2 / 4 taps with the skip gradient added (MODE 3) -- against float64
+    (convolution / autograd) and against the fp32 kernels (direct implicit GEMM, conv_par4's zero-insertion form)."""
+    from sda_amd import ops
+    from sda_amd.engine import launch_conv, planar_source
+    torch.manual_seed(cin + hs + 5 * ws)
+    w = (torch.rand(cout, cin, 3, 3, device=dev) * 2 - 1) / math.sqrt(cin * 9)
+    b = torch.randn(cout, device=dev)
+    x = torch.randn(n, cin, hs, ws, device=dev) * 1.3
+    # ---- forward
+    pk = ops.PackedConv(w, b)
+    assert pk.h2_s2() is not None
+    x64 = x.double().cpu().requires_grad_(True)
+    xp = F.pad(x64, (1, 1, 1, 1), mode='circular') if circular else F.pad(x64, (1, 1, 1, 1))
+    ref = F.conv2d(xp, w.double().cpu(), b.double().cpu(), stride=2)
+    out = torch.full((n, cout, hs // 2, ws // 2), float('nan'), device=dev)
+    d = launch_conv(pk, planar_source(x), out, hs // 2, ws // 2, circular=circular, stride=(2, 2), bias=pk.bias, x_amax=ops.absmax(x, pk.in_amax))
+    assert d.w_h2 and d.stride_h == 2, 'the stride-2 launch was not served by conv_h2'
+    err = ((out.double().cpu() - ref.detach()).abs().max() / ref.abs().max()).item()
+    out32 = torch.empty_like(out)
+    d32 = launch_conv(pk, planar_source(x), out32, hs // 2, ws // 2, circular=circular, stride=(2, 2), bias=pk.bias)
+    assert not d32.w_h2
+    err32 = ((out32.double().cpu() - ref.detach()).abs().max() / ref.abs().max()).item()
+    # ---- input VJP (+ the skip gradient)
+    pkt = ops.PackedConv(w, None, transpose=True)
+    assert pkt.h2_zins() is not None
+    g = torch.randn(n, cout, hs // 2, ws // 2, device=dev) * 0.4
+    skip = torch.randn(n, cin, hs, ws, device=dev)
+    gref, = torch.autograd.grad(ref, x64, g.double().cpu())
+    gref = gref + skip.double().cpu()
+    gx = torch.full((n, cin, hs, ws), float('nan'), device=dev)
+    dz = launch_conv(pkt, planar_source(g), gx, hs, ws, circular=circular, zins=(2, 2), res=skip, x_amax=ops.absmax(g, pkt.in_amax))
+    assert dz.w_h2 and dz.zins_h == 2, 'the stride-2 VJP was not served by conv_h2'
+    gerr = ((gx.double().cpu() - gref).abs().max() / gref.abs().max()).item()
+    gx32 = torch.empty_like(gx)
+    launch_conv(pkt, planar_source(g), gx32, hs, ws, circular=circular, zins=(2, 2), res=skip)
+    gerr32 = ((gx32.double().cpu() - gref).abs().max() / gref.abs().max()).item()
+    print(f'stride-2 head {cin}->{cout} @{hs}x{ws}: forward f16x2 {err:.2e} (fp32 kernel {err32:.2e}); VJP f16x2 {gerr:.2e} (fp32 kernel {gerr32:.2e})')
+    assert err < 3e-6 and gerr < 3e-6
