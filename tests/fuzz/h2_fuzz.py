@@ -70,6 +70,28 @@ def tail_case(rng, dev, idx, form, cin, cout, hs, ws, n, circular, tol):
             ref = ref + res.double().cpu()
         d = launch_conv(pk, planar_source(x), out, 2 * hs, 2 * ws, x_amax=None if ln else ops.absmax(x, pk.in_amax), **kw)
         ok = bool(d.w_h2) and d.up_h == 2
+    elif form in ('s2', 'zins'):
+        b = torch.randn(cout, device=dev)
+        x = torch.randn(n, cin, 2 * hs, 2 * ws, device=dev) * scale
+        x64 = x.double().cpu().requires_grad_(True)
+        xp = F.pad(x64, (1, 1, 1, 1), mode='circular') if circular else F.pad(x64, (1, 1, 1, 1))
+        y64 = F.conv2d(xp, w.double().cpu(), b.double().cpu() if form == 's2' else None, stride=2)
+        if form == 's2':
+            pk = ops.PackedConv(w, b)
+            ref = y64.detach()
+            out = torch.full((n, cout, hs, ws), float('nan'), device=dev)
+            d = launch_conv(pk, planar_source(x), out, hs, ws, circular=circular, stride=(2, 2), bias=pk.bias, x_amax=ops.absmax(x, pk.in_amax))
+            ok = bool(d.w_h2) and d.stride_h == 2
+        else:
+            pk = ops.PackedConv(w, None, transpose=True)
+            g = torch.randn(n, cout, hs, ws, device=dev) * scale
+            skip = torch.randn(n, cin, 2 * hs, 2 * ws, device=dev) * scale if rng.random() < 0.6 else None
+            ref, = torch.autograd.grad(y64, x64, g.double().cpu())
+            if skip is not None:
+                ref = ref + skip.double().cpu()
+            out = torch.full((n, cin, 2 * hs, 2 * ws), float('nan'), device=dev)
+            d = launch_conv(pk, planar_source(g), out, 2 * hs, 2 * ws, circular=circular, zins=(2, 2), res=skip, x_amax=ops.absmax(g, pk.in_amax))
+            ok = bool(d.w_h2) and d.zins_h == 2
     else:
         pk = ops.PackedConv(w, None, transpose=True)
         g = torch.randn(n, cout, 2 * hs, 2 * ws, device=dev) * scale
@@ -105,7 +127,7 @@ def main():
         if n * cin * cout * h * w_ > 3.5e9:
             n = 1
         transpose, circular = rng.random() < 0.4, rng.random() < 0.6
-        form = rng.choice(['conv', 'conv', 'conv', 'up', 'pool'])       # up: 2 x 2 up-sampled source (the tails); pool: their VJP summed over the cells
+        form = rng.choice(['conv', 'conv', 'conv', 'up', 'pool', 's2', 'zins'])   # up / pool: the tails and their VJP; s2 / zins: the stride-2 heads and theirs
         if form != 'conv':
             fails_here = tail_case(rng, dev, idx, form, cin, cout, h, w_, n, circular, args.tol)
             served += 1
