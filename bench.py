@@ -50,6 +50,10 @@ WORKLOADS = {
                                'over 8 GPUs = 16 trajectories/GPU', kind='kolmogorov', size=256, L=64, per_gpu=16, state=2),
     'kolmogorov64': dict(desc='BASELINE configs[2]: Kolmogorov 32x2x64x64, reference Kolmogorov net, batch 32 on 1 GPU',
                          kind='kolmogorov', size=64, L=32, per_gpu=32, state=2),
+    # the reference's own DEFAULT widths (experiments/kolmogorov/utils.py:52 make_score(): window 3, (64, 128, 256)) -- none a multiple of 96
+    'kolmogorov64_default': dict(desc='make_score() defaults of experiments/kolmogorov/utils.py:49-57 (window 3, hidden_channels (64, 128, 256), '
+                                      'blocks (3, 3, 3)): Kolmogorov 32x2x64x64, batch 32 on 1 GPU', kind='kolmogorov', size=64, L=32, per_gpu=32,
+                                 state=2, net=dict(window=3, embedding=64, hidden_channels=(64, 128, 256), hidden_blocks=(3, 3, 3))),
     'qg128': dict(desc='BASELINE configs[4]: QG-shaped 32x4x128x128 (4 state channels), K64-style net, batch 64 over 8 GPUs '
                        '= 8 trajectories/GPU', kind='kolmogorov', size=128, L=32, per_gpu=8, state=4),
     'lorenz63': dict(desc='BASELINE configs[0]: Lorenz-63, L=64, 1-D ScoreUNet (64,)/(3,), batch 1', kind='lorenz', L=64,
@@ -101,9 +105,10 @@ def build_model(wl, device):
     if wl['kind'] == 'kolmogorov':
         from sda_amd.experiments.kolmogorov import LocalScoreUNet
         from sda_amd.utils import ACTIVATIONS
-        net = MCScoreNet(wl['state'], order=K64['window'] // 2)
-        net.kernel = LocalScoreUNet(channels=K64['window'] * wl['state'], size=wl['size'], embedding=K64['embedding'],
-                                    hidden_channels=K64['hidden_channels'], hidden_blocks=K64['hidden_blocks'],
+        nk = {**K64, **wl.get('net', {})}
+        net = MCScoreNet(wl['state'], order=nk['window'] // 2)
+        net.kernel = LocalScoreUNet(channels=nk['window'] * wl['state'], size=wl['size'], embedding=nk['embedding'],
+                                    hidden_channels=nk['hidden_channels'], hidden_blocks=nk['hidden_blocks'],
                                     kernel_size=3, activation=ACTIVATIONS['SiLU'], spatial=2, padding_mode='circular')
         event = (wl['L'], wl['state'], wl['size'], wl['size'])
         A = Ob.Subsample.space(4)                    # x[..., ::4, ::4] with a hand-written adjoint: no autograd through A
@@ -149,8 +154,10 @@ def cpu_baseline(wl, args, guided, corrections):
     sched = O.Schedule()
     if wl['kind'] == 'kolmogorov':
         size, state = wl['size'], wl['state']
-        order = 2
-        cfg = O.UNetConfig(5 * state + 1, 5 * state, 64, (96, 192, 384), (3, 3, 3), 3, 2, 'SiLU', 2, 'circular')
+        nk = {**K64, **wl.get('net', {})}
+        order = nk['window'] // 2
+        cfg = O.UNetConfig(nk['window'] * state + 1, nk['window'] * state, nk['embedding'], tuple(nk['hidden_channels']),
+                           tuple(nk['hidden_blocks']), 3, 2, 'SiLU', 2, 'circular')
         sd = O.init_score_unet(0, 'kernel.', cfg)
         forcing = O.kolmogorov_forcing(size)
         nwin = max(1, int(args.cpu_windows))
@@ -161,7 +168,7 @@ def cpu_baseline(wl, args, guided, corrections):
         def net(xx, tt):
             return O.mc_score_net(lambda a, b, c=None: O.score_unet(sd, 'kernel.', cfg, a, b, forcing), order, xx, tt)
         total_windows = wl['per_gpu'] * (wl['L'] - 2 * order)
-        unit = f'1 trajectory x {nwin} windows of {state * 5}x{size}x{size}'
+        unit = f'1 trajectory x {nwin} windows of {state * nk["window"]}x{size}x{size}'
     else:
         state = wl['state']
         cfg = O.UNetConfig(state, state, 32, (64,), (3,), 3, 2, 'SiLU', 1, 'zeros')
@@ -302,6 +309,7 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
               'block1d_fwd': 'block1d_fwd_kernel (fused 1-D residual block, v_mfma_f32_16x16x4_f32)',
               'block1d_bwd': 'block1d_bwd_kernel (fused 1-D residual block VJP, v_mfma_f32_16x16x4_f32)'}.get(dom, dom)
     d = conv.get(dom, {})
+    is_h2 = dom in ('h2', 'h2up', 'h2s2')             # (one predicate for peak, frac_algorithmic and the note: ADVICE r5)
     # the clock `frac` was measured at.  The peak is quoted at 2.4 GHz; the boxes of the pool sustain 2.17-2.29 GHz under this kernel
     # (power-limited, data dependent), so the same build reads 0.70-0.73 depending on the box.  Two readings: the matrix-core
     # stream's own clock on THIS box (sda_clock_probe, run after the warm-up steps), and the dominant kernel's clock = its cycles per
@@ -329,13 +337,13 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
                    'step_us': step_s * 1e6, 'launch_floor_us': 1.7,
                    'floor_us_per_step_bracketed_kernels': 1.7 * n_launch}
     return {'bound': 'latency' if latency else 'mfma', 'latency': latency,
-            'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F16 if dom == 'h2' else PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+            'kernel': kernel, 'achieved': d.get('issued_mfma_tflops'), 'peak': PEAK_MFMA_F16 if is_h2 else PEAK_MFMA_F32, 'unit': 'TFLOP/s',
             'frac': d.get('mfma_util'),
             # SURVEY 8(d)'s definition (ALGORITHMIC flops of the direct convolution / time / peak) next to the issued one: above 1 for a
             # Winograd kernel (it issues 1 / 2.25 of them), a third of `frac`'s numerator for the three-product f16 x 2 kernel
-            'frac_algorithmic': None if d.get('algorithmic_tflops') is None else d['algorithmic_tflops'] / (PEAK_MFMA_F16 if dom == 'h2' else PEAK_MFMA_F32),
+            'frac_algorithmic': None if d.get('algorithmic_tflops') is None else d['algorithmic_tflops'] / (PEAK_MFMA_F16 if is_h2 else PEAK_MFMA_F32),
             'sustained_note': ('tools/h2_power_probe.hip (profiles/r05_h2_power_probe.txt): on full-mantissa random halves this instruction mix '
-                               'sustains 1 592 TFLOP/s = 0.64 of the quoted peak (power-managed clock 1.64 GHz; 2 411 on zeros)') if dom == 'h2' else None,
+                               'sustains 1 592 TFLOP/s = 0.64 of the quoted peak (power-managed clock 1.64 GHz; 2 411 on zeros)') if is_h2 else None,
             'clock': clock, 'traffic': traffic, 'traffic_source': os.path.basename(tfile) if traffic is not None else None,
             'achieved_is': 'ISSUED fp32 MFMA flops of the dominant kernel (algorithmic / 2.25 for Winograd) / its HIP-event time',
             'traffic_is': 'HBM/fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE '
@@ -542,7 +550,8 @@ def second_line(args, sde, sampler, b, device, f32_s_per_step):
             except Exception as e:  # noqa: BLE001
                 note = f'capture failed, ran eagerly: {type(e).__name__}: {str(e)[:160]}'
                 s2 = sde.sampler((b,), **kw)
-        s2.step()
+        for _ in range(max(1, args.second_warmup)):
+            s2.step()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(args.second_steps):
@@ -550,7 +559,7 @@ def second_line(args, sde, sampler, b, device, f32_s_per_step):
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / args.second_steps
         return {'multiply': 'f16x2', 'dtype': 'f32 emulated as 2 x f16 (three f16 products per multiply on v_mfma_f32_32x32x16_f16, fp32 accumulate)',
-                'ms_per_step': dt * 1e3, 'value': 1.0 / dt, 'unit': 'diffusion-steps/s', 'steps': args.second_steps, 'warmup': 1,
+                'ms_per_step': dt * 1e3, 'value': 1.0 / dt, 'unit': 'diffusion-steps/s', 'steps': args.second_steps, 'warmup': max(1, args.second_warmup),
                 'speedup_vs_f32_headline': f32_s_per_step / dt, 'samples_finite': bool(torch.isfinite(s2.x).all().item()),
                 'one_step_max_abs_diff_vs_f32_over_max_abs': diff, 'hipgraph_note': note,
                 'note': 'OPT-IN (ops.set_multiply / SDA_MULTIPLY=f16x2); `value` above is the fp32-MFMA headline'}
@@ -558,6 +567,85 @@ def second_line(args, sde, sampler, b, device, f32_s_per_step):
         return {'multiply': 'f16x2', 'error': f'{type(e).__name__}: {str(e)[:300]}'}
     finally:
         ops.set_multiply('f32')
+
+
+OTHER_CONFIGS = (('lorenz63', 'configs[0]', 20, 100), ('lorenz96', 'configs[1]', 20, 100), ('kolmogorov64', 'configs[2]', 1, 5),
+                 ('qg128', 'configs[4]', 1, 5), ('kolmogorov64_default', "the reference's default widths (64, 128, 256)", 1, 5))
+
+
+def other_configs(args, device):
+    """Every OTHER BASELINE configuration, bounded, in the same JSON line (`other_configs`): the same job as `--workload NAME` at N = 1
+    (same model, inputs, guidance, corrections, captured hipGraph), `warmup` untimed + `steps` timed replays bracketed by device syncs,
+    then one eager step under HIP events for the dominant kernel family and its fraction of its roofline.  Runs after the headline's
+    timed region and never touches it; a failure is reported in place of the entry."""
+    from sda_amd import ops, parallel
+    from sda_amd.score import GaussianScore, VPSDE
+    out, t_all = {}, time.perf_counter()
+    for name, label, warm, steps in OTHER_CONFIGS:
+        t_cfg = time.perf_counter()
+        try:
+            wl = dict(WORKLOADS[name])
+            b, _, lo = partition(wl['per_gpu'], 'weak', 0, 1)
+            net, event, A = build_model(wl, device)
+            score = SyntheticScore(net)
+            inner = VPSDE(score, shape=())
+            object.__setattr__(score, '_sched', inner)
+            y, x_init = rank_inputs(wl, event, 'weak', 0, 1)
+            eps_mod = GaussianScore(y, A=A, std=0.1, sde=inner) if args.guided else score
+            sde = VPSDE(eps_mod, shape=event).to(device)
+            sde.initial_noise = x_init
+            if args.corrections > 0:
+                sde.noise_source = parallel.KeyedNoise((lo, lo + b), event, 2, args.corrections, device)
+            sampler = sde.sampler((b,), steps=1000, corrections=args.corrections, tau=args.tau)
+            graph = True
+            try:
+                sampler.capture()
+            except Exception:  # noqa: BLE001
+                graph = False
+                sampler = sde.sampler((b,), steps=1000, corrections=args.corrections, tau=args.tau)
+            for _ in range(warm):
+                sampler.step()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sampler.step()
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t0) / steps
+            sampler._graph = None
+            prof = ops.ConvProfile()
+            ops.conv_profile = prof
+            sampler.step()
+            torch.cuda.synchronize(device)
+            ops.conv_profile = None
+            a2 = argparse.Namespace(**vars(args))
+            a2.workload = name
+            rf = roofline_report(prof, 1, dt, a2, ROOT, None)
+            fams = rf['families']
+            conv = {k: v for k, v in fams.items() if 'issued_mfma_tflops' in v}
+            dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
+            entry = {'config': label, 'description': wl['desc'], 'ms_per_step': dt * 1e3, 'value': 1.0 / dt, 'unit': 'diffusion-steps/s',
+                     'steps': steps, 'warmup': warm, 'hipgraph_step': graph, 'per_gpu_batch': b, 'guided': bool(args.guided),
+                     'corrections': args.corrections, 'samples_finite': bool(torch.isfinite(sampler.x).all().item()),
+                     'dominant_family': dom, 'dominant_kernel': rf['kernel'], 'bound': rf['bound'],
+                     'dominant_share_of_step': None if dom is None else conv[dom]['share_of_step'],
+                     'dominant_mfma_frac_issued': None if dom is None else conv[dom]['mfma_util'],
+                     'dominant_algorithmic_tflops': None if dom is None else conv[dom]['algorithmic_tflops'],
+                     'all_conv_algorithmic_tflops': rf['all_conv_algorithmic_tflops'],
+                     'families': {k: {'share_of_step': v['share_of_step'], 'ms_per_step': v['ms_per_step'],
+                                      **({'algorithmic_tflops': v['algorithmic_tflops'], 'mfma_util': v['mfma_util']} if 'mfma_util' in v else
+                                         {'frac_of_8TBps': v.get('frac_of_8TBps')})} for k, v in fams.items()},
+                     'wall_s': None}
+            del sampler, sde, eps_mod, inner, score, net, prof
+        except Exception as e:  # noqa: BLE001 -- the extra lines must never cost the headline
+            ops.conv_profile = None
+            entry = {'config': label, 'error': f'{type(e).__name__}: {str(e)[:300]}'}
+        torch.cuda.empty_cache()
+        entry['wall_s'] = time.perf_counter() - t_cfg
+        out[name] = entry
+    out['total_wall_s'] = time.perf_counter() - t_all
+    out['note'] = ('same job as `bench.py --workload NAME` at N = 1, fewer timed steps; fp32 multiply; timed outside the headline region; '
+                   'dominant_mfma_frac_issued = issued fp32 MFMA flops / time / 157.3 TFLOP/s (latency-bound 1-D nets: see `bound`)')
+    return out
 
 
 def main():
@@ -586,7 +674,14 @@ def main():
     ap.add_argument('--second-line', type=int, default=1,
                     help="1 (default; N = 1, Kolmogorov-shaped workloads, --multiply f32): after the f32 headline, time the same step with "
                          "--multiply f16x2 and report it as the `opt_in_f16x2` object of the same JSON line (never `value`)")
-    ap.add_argument('--second-steps', type=int, default=3)
+    ap.add_argument('--second-steps', type=int, default=8)
+    ap.add_argument('--second-warmup', type=int, default=1)
+    ap.add_argument('--other-configs', type=int, default=-1,
+                    help="1: add the bounded `other_configs` object (every other BASELINE configuration + the reference's default-width net, "
+                         "<= ~60 s in total) to the line; default: on for the default workload at N = 1, off otherwise")
+    ap.add_argument('--force-pg', type=int, default=0,
+                    help="1: initialise the process group (and issue the final all-gather through it) even at WORLD_SIZE = 1 -- first contact "
+                         "of RCCL, the HSA IPC setting and libsda_hip.so in one process on a 1-GPU box (tests/test_gpu_rccl.py)")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to exercise the launch path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -607,8 +702,13 @@ def main():
     dev_index = local_rank % max(ndev, 1)            # one rank per GPU on a real node; wraps only in 1-GPU dry runs
     device = torch.device('cuda', dev_index)
     torch.cuda.set_device(device)
-    if world > 1:
+    pg_live = world > 1 or bool(args.force_pg)
+    if pg_live:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)                          # nccl == RCCL on ROCm
         else:
@@ -642,7 +742,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if pg_live:
             dist.barrier()
             torch.cuda.synchronize(device)           # the RCCL barrier is itself stream work
 
@@ -673,7 +773,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ops.conv_profile = None
-    if world > 1:
+    if pg_live:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -694,7 +794,7 @@ def main():
     finite = bool(torch.isfinite(sampler.x).all().item())
     # the one collective of the job: gather the samples (after the loop; not part of a step)
     t1 = time.perf_counter()
-    gathered = parallel.all_gather_samples(sampler.x, global_batch)
+    gathered = parallel.all_gather_samples(sampler.x, global_batch, always_collective=pg_live)
     sync()
     gather_ms = (time.perf_counter() - t1) * 1e3
     assert gathered.shape[0] == global_batch
@@ -719,8 +819,8 @@ def main():
                        'observation': 'fused Subsample (hand-written adjoint; no autograd through A)',
                        'corrector_noise': 'row-keyed Philox (sda_randn_rows)',
                        'parallelism': f'dp{world} (batch-sharded, no in-loop collective)',
-                       'ranks_seen': dist.get_world_size() if world > 1 else 1,
-                       'backend': (args.backend + (' (RCCL)' if args.backend == 'nccl' else '')) if world > 1 else None},
+                       'ranks_seen': dist.get_world_size() if pg_live else 1, 'process_group_live': pg_live,
+                       'backend': (args.backend + (' (RCCL)' if args.backend == 'nccl' else '')) if pg_live else None},
             'wallclock_per_1000_steps_s': elapsed / args.steps * 1000,
             'samples_finite': finite, 'final_allgather_ms': gather_ms,
         }
@@ -730,11 +830,17 @@ def main():
             out['roofline'] = roofline_report(prof, prof_steps, elapsed / args.steps, args, ROOT, probe)
         if world == 1 and args.second_line and args.multiply == 'f32' and wl['kind'] == 'kolmogorov':
             out['opt_in_f16x2'] = second_line(args, sde, sampler, b, device, elapsed / args.steps)
+        want_other = args.other_configs == 1 or (args.other_configs < 0 and args.workload == 'kolmogorov256' and args.multiply == 'f32')
+        if world == 1 and want_other:
+            sampler = gathered = None                # (the shard's state, its graph pool and the gathered copy: 50+ GB back to the allocator)
+            sde.initial_noise = None
+            torch.cuda.empty_cache()
+            out['other_configs'] = other_configs(args, device)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, args, bool(args.guided), args.corrections)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg_live:
         dist.destroy_process_group()
 
 

@@ -34,7 +34,10 @@ def install_as_sda() -> None:
     the import system load second copies of the submodules (distinct classes) on ``import sda.<name>``."""
     me = sys.modules[__name__]
     sys.modules['sda'] = me
-    importlib.import_module('.mcs', __name__)
+    # every public submodule is imported BEFORE aliasing: a later `import sda.parallel` must find the one copy, not load a second
+    for sub in ('mcs', 'nn', 'score', 'utils', 'observe', 'parallel', 'metrics', 'ops', 'engine', 'mlp', 'fused1d', 'experiments',
+                'experiments.kolmogorov', 'experiments.lorenz'):
+        importlib.import_module('.' + sub, __name__)
     for full, mod in list(sys.modules.items()):
         if full.startswith(__name__ + '.') and mod is not None:
             sys.modules['sda.' + full[len(__name__) + 1:]] = mod

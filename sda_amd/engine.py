@@ -175,8 +175,10 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                 zins=(1, 1), bias: Optional[Tensor] = None, mod: Optional[Tensor] = None, mod_sn: int = 0,
                 ln=None, act_in: int = 0, dact_z: Optional[Tensor] = None, act_d: int = 0, res: Optional[Tensor] = None,
                 ctx: Optional[Tensor] = None, cctx: int = 0, ctx_sn: int = 0, pad=None, parity4_w: Optional[Tensor] = None,
-                pool=(1, 1), x_amax=None, out_amax: Optional[Tensor] = None):
-    """pool != (1, 1): `out` is the pooled tensor [n][cout][ho / pool_h][wo / pool_w] (cell sums; sda_conv_desc.pool_h / pool_w);
+                pool=(1, 1), x_amax=None, out_amax: Optional[Tensor] = None, h2_only: bool = False):
+    """h2_only: launch only if the f16 x 2 kernel serves the descriptor, else return None WITHOUT launching (the caller has a faster
+    fp32 form than the general kernel: the stride-2 head's VJP).
+    pool != (1, 1): `out` is the pooled tensor [n][cout][ho / pool_h][wo / pool_w] (cell sums; sda_conv_desc.pool_h / pool_w);
     returns None when no kernel serves the pooled form (the caller runs the plain launch and pools in its reader)."""
     out_strides = (0, 0, 0, 0)
     if not out.is_contiguous():                      # an interleaved view of the real output (parity-split VJP)
@@ -220,6 +222,8 @@ def launch_conv(pk: PackedConv, src: dict, out: Tensor, ho: int, wo: int, *, cir
                 bound = None                             # -> the fp32 direct kernels
         if ops.conv_h2(d, pk, bound, out_amax, packing=packing):
             return d
+    if h2_only:
+        return None
     if parity4_w is not None:
         # all four parity classes of a stride-2 VJP in one launch: the class-(0,0) descriptor with the concatenated packing
         d.w = parity4_w.data_ptr()
@@ -709,10 +713,10 @@ class UNetEngine:
                 if (ops.MULTIPLY == 'f16x2' and ops.H2_S2 and (hd.sh, hd.sw) == (2, 2) and g.is_contiguous() and skip.is_contiguous() and
                         skip.shape == g2.shape and g.shape[2] % 16 == 0 and g.shape[3] % 16 == 0 and hd.bwd().h2_zins() is not None):
                     # f16 x 2 route: the four output parity classes as 1 / 2 / 2 / 4-tap convolutions of g on conv_h2 (PackedConv.h2_zins).
-                    # (Were the launch not served after all, launch_conv has run the general zero-insertion kernel: correct, slower.)
+                    # (h2_only: a descriptor the kernel refuses after all launches nothing here and takes the fp32 parity-class forms below)
                     xa = g_amax if g_amax is not None else ops.absmax(g, hd.bwd().in_amax)
                     done = launch_conv(hd.bwd(), planar_source(g), g2, hu, wu, circular=hd.circular, zins=(hd.sh, hd.sw), res=skip,
-                                       x_amax=xa) is not None
+                                       x_amax=xa, h2_only=True) is not None
                 if not done and classes is not None and ops.PARITY4:
                     w4 = hd.bwd_parity4()
                     # (the one-launch kernel addresses the skip gradient with the OUTPUT strides: same layout required)

@@ -64,8 +64,10 @@ def _passthrough():
     mod = importlib.util.module_from_spec(spec)
     try:
         spec.loader.exec_module(mod)
-    except ImportError as e:          # jax (or another simulator dependency) is not installed
-        UNAVAILABLE = f'{path} could not be imported: {e}'
+    except Exception as e:  # noqa: BLE001 -- jax (or another simulator dependency) is missing (ImportError) or mismatched: a jax / jaxlib
+        # version skew raises RuntimeError / AttributeError at import time.  Drivers that only SAMPLE never touch a simulator, so
+        # install_as_sda() must survive any of them; the placeholders below say what happened when a chain is instantiated
+        UNAVAILABLE = f'{path} could not be imported: {type(e).__name__}: {e}'
         return {}
     SOURCE = path
     return {k: v for k, v in vars(mod).items() if not k.startswith('_')}

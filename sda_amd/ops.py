@@ -189,7 +189,7 @@ def conv_igemm(desc: ConvDesc):
         e1.record()
         fam = CONV_FAMILIES[max(0, conv_path(desc))]
         # (a zero-insertion launch multiplies a quarter of what its fine-resolution output size says: 9 taps per SOURCE pixel)
-        prof.records.append((e0, e1, prof.flops(desc) / (4.0 if desc.zins_h == 2 else 1.0), fam))
+        prof.records.append((e0, e1, prof.flops(desc) / float(max(1, desc.zins_h) * max(1, desc.zins_w)), fam))
         rd, wr = prof.alg_bytes(desc)
         b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
         b[0] += rd
@@ -238,7 +238,7 @@ def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]
         # (the up-sampled / pooled forms issue 4 of the 9 taps; the stride-2 forms all 9, at a quarter of the fine-resolution pixels)
         fam = 'h2up' if (desc.up_h == 2 or desc.pool_h == 2) else 'h2s2' if (desc.zins_h == 2 or desc.stride_h == 2) else 'h2'
         # (a zero-insertion launch multiplies a quarter of what its fine-resolution output size says: 9 taps per SOURCE pixel)
-        prof.records.append((e0, e1, prof.flops(desc) / (4.0 if desc.zins_h == 2 else 1.0), fam))
+        prof.records.append((e0, e1, prof.flops(desc) / float(max(1, desc.zins_h) * max(1, desc.zins_w)), fam))
         rd, wr = prof.alg_bytes(desc)
         b = prof.family_bytes.setdefault(fam, [0.0, 0.0])
         b[0] += rd

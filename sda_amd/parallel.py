@@ -79,13 +79,16 @@ class KeyedNoise:
                               draw_add=correction)
 
 
-def all_gather_samples(local: Tensor, batch: int) -> Tensor:
+def all_gather_samples(local: Tensor, batch: int, always_collective: bool = False) -> Tensor:
     """Concatenate every rank's samples along dim 0 (ranks may hold unequal shares).  One collective, after the loop.
+
+    ``always_collective``: issue the collective even in a one-rank group (a copy otherwise skipped) -- how a 1-GPU box exercises
+    the RCCL call the 8-GPU job ends with (tests/test_gpu_rccl.py, ``bench.py --force-pg 1``).
 
     Equal shares (every configuration of BASELINE.json): one ``all_gather_into_tensor`` straight into the result -- no padding
     copy, no list of per-rank buffers (537 MB per rank at configs[3]).  Unequal shares: padded list gather."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return local
     sizes = [shard_range(batch, r, ws) for r in range(ws)]
     counts = [hi - lo for lo, hi in sizes]

@@ -90,19 +90,31 @@ def _context_only_override(kernel: 'ScoreUNet', shape, t: Tensor, c: Optional[Te
     an exception on the placeholder) answers ``(False, None)`` and the caller runs the override for real."""
     if type(kernel).forward is ScoreUNet.forward:
         return True, kernel._context(c)
+    key = (type(kernel), tuple(shape))
+    if key in _not_context_only:                 # (a refused override is not executed a second time per evaluation: its side effects fire once)
+        return False, None
     ph = torch.empty(shape, device='meta')
     out = torch.empty(shape, device='meta')
+    # in-place arithmetic keeps object identity (`x.mul_(0.5); return super().forward(x, t, c)`, `out = super()...; out.mul_(2)`):
+    # the version counters of the placeholder, the result and t tell (meta tensors carry them)
+    v_ph, v_out, v_t = ph._version, out._version, t._version if isinstance(t, Tensor) else None
     _probe.calls, _probe.out = [], out
     try:
         res = type(kernel).forward(kernel, ph, t, c)
         calls = _probe.calls
     except Exception:  # noqa: BLE001 -- an override that cannot digest the placeholder simply takes the generic path
+        _not_context_only.add(key)
         return False, None
     finally:
         _probe.calls, _probe.out = None, None
-    if len(calls) == 1 and res is out and calls[0][0] is kernel and calls[0][1] is ph and calls[0][2] is t:
+    untouched = ph._version == v_ph and out._version == v_out and (v_t is None or t._version == v_t)
+    if untouched and len(calls) == 1 and res is out and calls[0][0] is kernel and calls[0][1] is ph and calls[0][2] is t:
         return True, kernel._context(calls[0][3])
+    _not_context_only.add(key)
     return False, None
+
+
+_not_context_only = set()                        # (kernel class, unfolded shape) whose override was probed and refused
 
 
 class ScoreUNet(nn.Module):

