@@ -45,7 +45,10 @@
 #define W4_UDMA 0
 #endif
 #define W4_CK 8
-#define W4_BM 96
+// cout tile = 32 MF output channels (MF = cout fragments of 16 per consumer wave): MF = 3 -> 96 (the reference's training widths
+// (96, 192, 384), kolmogorov/train.py:19), MF = 2 -> 64 (its DEFAULT widths (64, 128, 256), kolmogorov/utils.py:52: round 6).  A
+// 128-cout tile (MF = 4) would need 256 accumulator registers per consumer; 128 / 256 couts run as 2 / 4 tiles of 64.
+#define W4_BM_OF(MF) (32 * (MF))
 #define W4_T 32                        // 8 x 4 Winograd tiles
 #define W4_HC 18                       // halo columns (16 pixels + 2)
 #define W4_HRW 10                      // halo rows (8 pixels + 2)
@@ -53,21 +56,25 @@
                                        // 32-lane half reads with ds_read_b64 cover the 64 banks exactly once
 #define W4_HPLANE (W4_HRW * W4_HS)     // 240 floats per channel
 #define W4_NSLOT 3                     // ceil(18 * 10 / 64) halo positions per lane and channel
-#define W4_UPP (6 * 64 * 4)            // floats per position PAIR in a U buffer: [cout fragment 6][lane 64][h 2][k4 2]
-#define W4_UBUF (8 * W4_UPP)           // 12288 floats = 48 KiB
-#define W4_UZP 7168                    // floats of a stage's U slab in the zero-position packing (sda_pack_conv_weight_wino4_zp): the full pairs
-                                       // 0 / 2 / 6 at 0 / 1536 / 3072, the live halves of pairs 1 and 3 interleaved at 4608, pair 7's at 6144
-                                       // (float2 per lane), zero padding from 6912 -- 28 KiB, seven 1-KiB pieces per helper wave
+#define W4_UPP_OF(MF) (2 * (MF) * 64 * 4)   // floats per position PAIR in a U buffer: [cout fragment 2 MF][lane 64][h 2][k4 2]  (1536 | 1024)
+#define W4_UBUF_OF(MF) (8 * W4_UPP_OF(MF))  // 12288 floats = 48 KiB | 8192 floats = 32 KiB
+// floats of a stage's U slab in the zero-position packing (sda_pack_conv_weight_wino4_zp): the full pairs 0 / 2 / 6 at 0 / UPP / 2 UPP,
+// the live halves of pairs 1 and 3 interleaved at 3 UPP, pair 7's at 4 UPP (float2 per lane: UPP / 2), zero padding behind it up to a
+// whole number of 1-KiB pieces per helper wave: MF = 3: 6912 -> 7168 floats (28 KiB, seven pieces per helper), MF = 2: 4608 -> 5120
+// (20 KiB, five pieces per helper)
+#define W4_NULZ_OF(MF) ((MF) == 3 ? 7 : 5)
+#define W4_UZP_OF(MF) (W4_NULZ_OF(MF) * 4 * 256)
 #define W4_VKQ 128                     // floats per kq plane of V: [k4 2][tile 32][h 2]
 #define W4_VPP (4 * W4_VKQ)            // floats per position pair in a V buffer
 #define W4_VBUF (8 * W4_VPP)           // 4096 floats = 16 KiB
-#define W4_LDS_BYTES ((2 * W4_UBUF + 2 * W4_VBUF + 4 * 2 * W4_HPLANE) * 4)
-#define W4_LDS_ALLOC (W4_LDS_BYTES + (W4_UDMA ? 1024 : 0))      // + the landing KiB of the prologue's dummy DMA
+#define W4_LDS_BYTES_OF(MF) ((2 * W4_UBUF_OF(MF) + 2 * W4_VBUF + 4 * 2 * W4_HPLANE) * 4)     // 135.5 KiB | 103.5 KiB
+#define W4_LDS_ALLOC_OF(MF) (W4_LDS_BYTES_OF(MF) + (W4_UDMA ? 1024 : 0))      // + the landing KiB of the prologue's dummy DMA
 
 struct Wino4Geom {
     int cin, hv, wv;                   // real input channels, virtual (= output) image size
     int bx_n, by_n;                    // 16 x 8-pixel blocks per image
     int n_ct, grid, nstage, debug, mtiles;
+    int mf;                            // cout fragments per consumer wave: cout tile = 32 mf (3: cout % 96 == 0, else 2: cout % 64 == 0)
     int walk;                          // 1: the workgroups of an XCD walk its tile range interleaved (tile = slot + j * per_xcd), 0: each a contiguous sub-range
     int sc, sx, sy, sn;                // a workgroup's step from one tile to its next, as (cout tiles, columns, rows, images): mixed-radix digits
     long long* trace;                  // (tooling builds only) per-wave phase cycle sums
@@ -93,7 +100,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
         return SDA_E_UNSUPPORTED;
     if (d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx) return SDA_E_UNSUPPORTED;
-    if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || d->cout % W4_BM || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
+    if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || (d->cout % 96 && d->cout % 64) || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
     if ((d->ho & 7) || (d->wo & 15) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
     // pooled output (2 x 2 cell sums at half resolution): plain launches without an epilogue operand only
@@ -119,12 +126,16 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
         return SDA_E_UNSUPPORTED;
     // 32-bit BYTE offsets inside one image (channel base included)
     if ((int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 30)) return SDA_E_UNSUPPORTED;
-    if ((int64_t)48 * d->ho * d->wo * 4 >= (1LL << 31)) return SDA_E_UNSUPPORTED;            // (epilogue buffer descriptors)
+    if ((int64_t)48 * d->ho * d->wo * 4 >= (1LL << 31)) return SDA_E_UNSUPPORTED;            // (epilogue buffer descriptors: <= 48 planes)
     if ((int64_t)d->cout * d->ho * d->wo >= (1LL << 30) || (int64_t)d->n * d->hs * d->ws >= (1LL << 31)) return SDA_E_UNSUPPORTED;
     g->cin = d->cx + d->cctx;
     g->hv = d->ho; g->wv = d->wo;
     g->bx_n = d->wo / 16; g->by_n = d->ho / 8;
-    g->n_ct = d->cout / W4_BM;
+    g->mf = d->cout % 96 == 0 ? 3 : 2;
+#if W4_UDMA
+    if (g->mf != 3) return SDA_E_UNSUPPORTED;          // (the measured-and-rejected DMA form exists for the 96-cout tile only)
+#endif
+    g->n_ct = d->cout / W4_BM_OF(g->mf);
     g->mtiles = d->cout / 16;
     const int64_t total = (int64_t)g->bx_n * g->by_n * d->n * g->n_ct;
     if (total > 0x3fffffffLL || total < 1) return SDA_E_UNSUPPORTED;
@@ -241,10 +252,20 @@ __host__ __device__ constexpr bool w4_dead(int p) { return ZP != 0 && ((p >> 2) 
 //          start at even pixels, so patch rows / columns 1, 2 are the same source pixel);
 //      2 = the output is summed over its 2 x 2 cells (sda_conv_desc.pool_h / pool_w: the input VJP of such a tail, the VJP of
 //          the upsample fused into the epilogue): one value per (cout, tile), written at half resolution.
-template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0>
+// MF:  cout fragments (16 couts each) per consumer wave: the workgroup tile is 32 MF couts x 32 Winograd tiles (W4_BM_OF above).  MF = 2
+//      keeps everything of the MF = 3 design -- same helpers, same V side, same two barriers per stage -- with 8 instead of 12 MFMAs and 4
+//      instead of 5 LDS reads per consumer step, a 32-KiB U slab (8 loads per helper) and the epilogue operand loaded in a TWO-slot
+//      window of eight pairs each (the 64-channel level has only eight K-stages per tile: see epi_issue).
+template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0, int MF = 3>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
+    static_assert(MF == 2 || MF == 3, "cout tile = 64 or 96");
     constexpr bool ZPOS = ZP != 0;                         // 9 live Winograd positions of 16 (see ZP above)
     constexpr bool EPI = EPM == 1;
+    constexpr int W4_BM = W4_BM_OF(MF), W4_UPP = W4_UPP_OF(MF), W4_UBUF = W4_UBUF_OF(MF), W4_UZP = W4_UZP_OF(MF);
+    constexpr int W4_LDS_BYTES = W4_LDS_BYTES_OF(MF);
+    constexpr int NULZ = W4_NULZ_OF(MF);                   // 1-KiB pieces of the position-packed slab per helper
+    constexpr int NUF = 4 * MF;                            // 1-KiB pieces of the full slab per helper (two position pairs x 2 MF fragments)
+    (void)W4_BM; (void)W4_UZP; (void)W4_LDS_BYTES; (void)NULZ; (void)NUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -494,8 +515,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 *reinterpret_cast<f32x2*>(dst + (2 * a + 1) * W4_VPP) = o23;       // positions 4 a + 2, 4 a + 3
             }
         };
-        // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 12 KiB = 12 wave-wide dwordx4 (one per cout fragment and pair)
-        f32x4 ureg[12];
+        // U slab, position pairs 2 pw and 2 pw + 1 of a stage: 4 MF KiB = 4 MF wave-wide dwordx4 (one per cout fragment and pair)
+        f32x4 ureg[12];                                    // (MF = 2 uses the first 8; W4_WAIT_U names all twelve)
+        if constexpr (MF != 3) {
+#pragma unroll
+            for (int m = NUF; m < 12; ++m) ureg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // ZP: 9 of the 16 positions are multiplied; the slab comes position-packed (W4_UZP: 28 KiB instead of the 36 KiB of the six pairs
         // that hold a live position) and in the stage buffer's own order -- helper pw copies the linear pieces 7 pw .. 7 pw + 6.  The
         // up-sampled / pooled layers are vector-memory bound on the helper side (two workgroups' U, halo and operand loads share the CU's
@@ -503,30 +528,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // (profiles/r04_zp_packed_u.txt).
         auto u_load = [&](const W4Cur& t) {
             const int64_t pstride = (int64_t)g.mtiles * 1024;         // bytes between position pairs
+            // (the immediate offset field reaches 4095: one scalar base per three consecutive 1-KiB pieces)
             if constexpr (ZPOS) {
-                const char* b0 = reinterpret_cast<const char*>(d.w_wino4_zp + ((int64_t)t.st * g.n_ct + t.ct) * W4_UZP) + pw * 7168;
+                const char* b0 = reinterpret_cast<const char*>(d.w_wino4_zp + ((int64_t)t.st * g.n_ct + t.ct) * W4_UZP) + pw * (NULZ * 1024);
                 const char* b1 = b0 + 3072;
-                const char* b2 = b0 + 6144;
                 w4_ld4<0>(ureg[0], b0, lane16);
                 w4_ld4<1024>(ureg[1], b0, lane16);
                 w4_ld4<2048>(ureg[2], b0, lane16);
                 w4_ld4<0>(ureg[3], b1, lane16);
                 w4_ld4<1024>(ureg[4], b1, lane16);
-                w4_ld4<2048>(ureg[5], b1, lane16);
-                w4_ld4<0>(ureg[6], b2, lane16);
+                if constexpr (NULZ == 7) {
+                    const char* b2 = b0 + 6144;
+                    w4_ld4<2048>(ureg[5], b1, lane16);
+                    w4_ld4<0>(ureg[6], b2, lane16);
+                }
                 return;
             }
-            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 6 * t.ct) * 256);
+            const char* src = reinterpret_cast<const char*>(d.w_wino4 + ((int64_t)(t.st * 8 + 2 * pw) * g.mtiles + 2 * MF * t.ct) * 256);
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const char* sp = src + pp * pstride;
-                const char* sq = sp + 3072;
-                w4_ld4<0>(ureg[pp * 6 + 0], sp, lane16);
-                w4_ld4<1024>(ureg[pp * 6 + 1], sp, lane16);
-                w4_ld4<2048>(ureg[pp * 6 + 2], sp, lane16);
-                w4_ld4<0>(ureg[pp * 6 + 3], sq, lane16);
-                w4_ld4<1024>(ureg[pp * 6 + 4], sq, lane16);
-                w4_ld4<2048>(ureg[pp * 6 + 5], sq, lane16);
+                w4_ld4<0>(ureg[pp * 2 * MF + 0], sp, lane16);
+                w4_ld4<1024>(ureg[pp * 2 * MF + 1], sp, lane16);
+                w4_ld4<2048>(ureg[pp * 2 * MF + 2], sp, lane16);
+                if constexpr (MF == 3) {
+                    const char* sq = sp + 3072;
+                    w4_ld4<0>(ureg[pp * 6 + 3], sq, lane16);
+                    w4_ld4<1024>(ureg[pp * 6 + 4], sq, lane16);
+                    w4_ld4<2048>(ureg[pp * 6 + 5], sq, lane16);
+                } else {
+                    w4_ld4<3072>(ureg[pp * 4 + 3], sp, lane16);
+                }
             }
         };
         // The same pieces by LDS-DMA (W4_UDMA): global_load_lds_dwordx4 writes [M0 + lane x 16], and both the packing and the stage
@@ -550,6 +582,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                          : "=&s"(keep) : "v"(lane16), "s"(src), "s"(la) : "memory");
         };
         auto u_dma = [&](const W4Cur& t, float* ub) {
+            static_assert(!W4_UDMA || MF == 3, "the DMA form of the U slab exists for the 96-cout tile only");
             if constexpr (ZPOS) {
                 const char* b0 = reinterpret_cast<const char*>(d.w_wino4_zp + ((int64_t)t.st * g.n_ct + t.ct) * W4_UZP) + pw * 7168;
                 float* dz = ub + pw * 1792;
@@ -571,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         auto u_dma_dummy = [&]() {
             const char* src = reinterpret_cast<const char*>(d.w_wino4);
 #pragma unroll
-            for (int m = 0; m < (ZPOS ? 7 : 12); ++m) u_dma1(src, smem + W4_LDS_BYTES / 4);
+            for (int m = 0; m < (ZPOS ? NULZ : NUF); ++m) u_dma1(src, smem + W4_LDS_BYTES / 4);
         };
 #define W4_WAIT_U(N)                                                                                                           \
     asm volatile("s_waitcnt vmcnt(%14)" : "+v"(ureg[0]), "+v"(ureg[1]), "+v"(ureg[2]), "+v"(ureg[3]), "+v"(ureg[4]), "+v"(ureg[5]), \
@@ -580,16 +613,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     W4_PIN_EPI()
         auto u_store = [&](float* ub) {
             if constexpr (ZPOS) {
-                float* dz = ub + pw * 1792 + lane * 4;
+                float* dz = ub + pw * (NULZ * 256) + lane * 4;
 #pragma unroll
-                for (int m = 0; m < 7; ++m) *reinterpret_cast<f32x4*>(dz + m * 256) = ureg[m];
+                for (int m = 0; m < NULZ; ++m) *reinterpret_cast<f32x4*>(dz + m * 256) = ureg[m];
                 return;
             }
             float* dst = ub + (2 * pw) * W4_UPP + lane * 4;
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int m = 0; m < 6; ++m) *reinterpret_cast<f32x4*>(dst + pp * W4_UPP + m * 256) = ureg[pp * 6 + m];
+                for (int m = 0; m < 2 * MF; ++m) *reinterpret_cast<f32x4*>(dst + pp * W4_UPP + m * 256) = ureg[pp * 2 * MF + m];
         };
         // hand-off: this wave's LDS writes have landed; its global loads stay in flight across the barrier
         auto handoff = [&]() {
@@ -606,7 +639,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // on the weights, so that the hand-counted vmcnt values do not depend on the launch.
         const float* const pf_t = d.res ? d.res : d.dact_z;
         const unsigned pf_off = (unsigned)(((pw * 8 + (lane >> 3)) * (d.ho * d.wo) + (lane & 7) * d.wo) * 4);
-        float pfreg[EPI ? 8 : 2] = {0.f, 0.f};
+        constexpr int NPF = EPI ? (MF == 3 ? 4 : 8) : 1;   // loads per iteration: the operand window's (EPI) / one prefetch touch
+        float pfreg[2 * NPF] = {0.f, 0.f};
         // EPI launches: the helpers LOAD the operand instead (wave pw for consumer wave pw, lane for lane: the 24 8-byte pairs
         // the consumer lane's epilogue needs -- plane 16 m + r, rows 0 / 1 of its 2 x 2 output block), four pairs per iteration
         // while the issue cursor is in the tile's last six stages, into 48 registers that wait for the tile's end.  There the
@@ -615,22 +649,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // inverse transform) and X2 (operand read; the helper refills the buffer).  A consumer-side global load would queue
         // behind everything the helpers have in flight on the CU's vector-memory path: ~1 us per dependent round trip, three
         // of them per tile.  Outside the window the four loads are issued all the same (dummies on the weights: static counts).
-        f32x2 eop[EPI ? 24 : 1];
+        // MF = 2 (64-cout tile): 16 pairs (plane 16 m + r, m < 2), loaded in a window of the tile's last TWO stages, eight pairs per
+        // iteration -- the window may only open once the previous tile's operand has left these registers (epi_store, when the
+        // consumers enter the new tile: the issue cursor is then at stage 5 of it), and a 64-channel layer has eight stages per tile.
+        constexpr int NEOP = 8 * MF;
+        f32x2 eop[EPI ? NEOP : 1];
 #pragma unroll
-        for (int j = 0; j < (EPI ? 24 : 1); ++j) eop[j] = f32x2{0.f, 0.f};
+        for (int j = 0; j < (EPI ? NEOP : 1); ++j) eop[j] = f32x2{0.f, 0.f};
         const int e_hw = d.ho * d.wo;
         const int e_t = 16 * (pw & 1) + (lane & 15);
         const unsigned e_lo0 = (unsigned)(((4 * (lane >> 4)) * e_hw + 2 * (e_t >> 3) * d.wo + 2 * (e_t & 7)) * 4);
         const unsigned e_lo1 = e_lo0 + (unsigned)d.wo * 4u;
-        const int e_first = g.nstage - 6;
+        constexpr int EWIN = MF == 3 ? 6 : 2;              // window slots (stages) of a tile's operand loads
+        const int e_first = g.nstage - EWIN;
 #define W4_PIN_EPI()                                                                                                           \
     do {                                                                                                                       \
-        if constexpr (EPI) {                                                                                                   \
+        if constexpr (EPI && MF == 3) {                                                                                        \
             asm volatile("" : "+v"(pfreg[2]), "+v"(pfreg[3]), "+v"(pfreg[4]), "+v"(pfreg[5]), "+v"(pfreg[6]), "+v"(pfreg[7]) :: "memory"); \
             asm volatile("" : "+v"(eop[0]), "+v"(eop[1]), "+v"(eop[2]), "+v"(eop[3]), "+v"(eop[4]), "+v"(eop[5]), "+v"(eop[6]),     \
                          "+v"(eop[7]), "+v"(eop[8]), "+v"(eop[9]), "+v"(eop[10]), "+v"(eop[11]) :: "memory");                        \
             asm volatile("" : "+v"(eop[12]), "+v"(eop[13]), "+v"(eop[14]), "+v"(eop[15]), "+v"(eop[16]), "+v"(eop[17]),            \
                          "+v"(eop[18]), "+v"(eop[19]), "+v"(eop[20]), "+v"(eop[21]), "+v"(eop[22]), "+v"(eop[23]) :: "memory");     \
+        } else if constexpr (EPI) {                                                                                            \
+            asm volatile("" : "+v"(pfreg[2]), "+v"(pfreg[3]), "+v"(pfreg[4]), "+v"(pfreg[5]), "+v"(pfreg[6]), "+v"(pfreg[7]),       \
+                         "+v"(pfreg[8]), "+v"(pfreg[9]), "+v"(pfreg[10]), "+v"(pfreg[11]), "+v"(pfreg[12]), "+v"(pfreg[13]),        \
+                         "+v"(pfreg[14]), "+v"(pfreg[15]) :: "memory");                                                             \
+            asm volatile("" : "+v"(eop[0]), "+v"(eop[1]), "+v"(eop[2]), "+v"(eop[3]), "+v"(eop[4]), "+v"(eop[5]), "+v"(eop[6]),     \
+                         "+v"(eop[7]), "+v"(eop[8]), "+v"(eop[9]), "+v"(eop[10]), "+v"(eop[11]), "+v"(eop[12]), "+v"(eop[13]),       \
+                         "+v"(eop[14]), "+v"(eop[15]) :: "memory");                                                                 \
         }                                                                                                                      \
     } while (0)
         // One straight-line statement per window slot K (its four loads are skipped INSIDE the asm text unless k == K): a C++
@@ -641,8 +687,39 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                  "global_load_dwordx2 %2, %5, %8\n\tglobal_load_dwordx2 %3, %6, %8\n.Lw4epi%=:"                                 \
                  : "+v"(eop[4 * K + 0]), "+v"(eop[4 * K + 1]), "+v"(eop[4 * K + 2]), "+v"(eop[4 * K + 3])                      \
                  : "s"(k), "v"(e_lo0), "v"(e_lo1), "s"(b0), "s"(b1) : "memory", "scc")
+        // MF = 2: slot K = cout fragment K of the consumer -- planes 16 K + 0 .. 3 (four scalar bases), rows 0 / 1: pairs 8 K + 2 r + row
+#define W4_EPI_SLOT8(K)                                                                                                        \
+    asm volatile("s_cmp_lg_u32 %8, " #K "\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"                                           \
+                 "global_load_dwordx2 %0, %9, %11\n\tglobal_load_dwordx2 %1, %10, %11\n\t"                                      \
+                 "global_load_dwordx2 %2, %9, %12\n\tglobal_load_dwordx2 %3, %10, %12\n\t"                                      \
+                 "global_load_dwordx2 %4, %9, %13\n\tglobal_load_dwordx2 %5, %10, %13\n\t"                                      \
+                 "global_load_dwordx2 %6, %9, %14\n\tglobal_load_dwordx2 %7, %10, %14\n.Lw4epi%=:"                               \
+                 : "+v"(eop[8 * K + 0]), "+v"(eop[8 * K + 1]), "+v"(eop[8 * K + 2]), "+v"(eop[8 * K + 3]),                      \
+                   "+v"(eop[8 * K + 4]), "+v"(eop[8 * K + 5]), "+v"(eop[8 * K + 6]), "+v"(eop[8 * K + 7])                       \
+                 : "s"(k), "v"(e_lo0), "v"(e_lo1), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : "memory", "scc")
+        auto epi_issue8 = [&](const W4Cur& t, float& dm0, float& dm1, float& dm2, float& dm3, float& dm4, float& dm5, float& dm6, float& dm7) {
+            if constexpr (EPI && MF == 2) {
+                const int k = t.st - e_first;              // window slot = cout fragment: planes 16 k + 0 .. 3
+                const int kc = k < 0 ? 0 : k;
+                const int64_t ps = (int64_t)e_hw * 4;
+                const char* b0 = reinterpret_cast<const char*>(pf_t + ((int64_t)t.n * d.cout + W4_BM * t.ct + 16 * MF * (pw >> 1)) * e_hw +
+                                                               (8 * t.by) * d.wo + 16 * t.bx) + (16 * kc) * ps;
+                const char* b1 = b0 + ps;
+                const char* b2 = b1 + ps;
+                const char* b3 = b2 + ps;
+                W4_EPI_SLOT8(0); W4_EPI_SLOT8(1);
+                // outside the window: eight dummy loads on the weights (the hand-counted vmcnt values are static)
+                asm volatile("s_cmp_lt_u32 %8, 2\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"
+                             "global_load_dword %0, %9, %10\n\tglobal_load_dword %1, %9, %10\n\t"
+                             "global_load_dword %2, %9, %10\n\tglobal_load_dword %3, %9, %10\n\t"
+                             "global_load_dword %4, %9, %10\n\tglobal_load_dword %5, %9, %10\n\t"
+                             "global_load_dword %6, %9, %10\n\tglobal_load_dword %7, %9, %10\n.Lw4epi%=:"
+                             : "+v"(dm0), "+v"(dm1), "+v"(dm2), "+v"(dm3), "+v"(dm4), "+v"(dm5), "+v"(dm6), "+v"(dm7)
+                             : "s"(k), "v"(lane16), "s"(reinterpret_cast<const char*>(d.w_wino4)) : "memory", "scc");
+            }
+        };
         auto epi_issue = [&](const W4Cur& t, float& dm0, float& dm1, float& dm2, float& dm3) {
-            if constexpr (EPI) {
+            if constexpr (EPI && MF == 3) {
                 const int k = t.st - e_first;              // window slot: planes 16 (k >> 1) + 2 (k & 1) and the next one
                 const int kc = k < 0 ? 0 : k;
                 const int64_t ps = (int64_t)e_hw * 4;
@@ -661,9 +738,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // the tile's operand: registers -> LDS (the U buffer of stage q + 1, free since the hand-off E_(q-1)), X1, X2
         auto epi_store = [&](int q) {
             if constexpr (EPI) {
-                float* rb = ubuf + ((q + 1) & 1) * W4_UBUF + (pw * 24 * 64 + lane) * 2;
+                float* rb = ubuf + ((q + 1) & 1) * W4_UBUF + (pw * NEOP * 64 + lane) * 2;
 #pragma unroll
-                for (int j = 0; j < 24; ++j) *reinterpret_cast<f32x2*>(rb + j * 128) = eop[j];
+                for (int j = 0; j < NEOP; ++j) *reinterpret_cast<f32x2*>(rb + j * 128) = eop[j];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();              // X1
                 asm volatile("" ::: "memory");
@@ -672,10 +749,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             }
         };
         int cst = 0;                                       // stage-in-tile of the consumers' stage q
-        const int pf_first = g.nstage > 3 ? g.nstage - 3 : 0;
+        const int pf_first = g.nstage > MF ? g.nstage - MF : 0;
         auto prefetch = [&](const W4Cur& t, float& dst) {
             const int k = t.st - pf_first;
-            if (pf_t && k >= 0 && k < 3) {
+            if (pf_t && k >= 0 && k < MF) {
                 const float* base = pf_t + ((int64_t)t.n * d.cout + W4_BM * t.ct + 32 * k) * ((int64_t)d.ho * d.wo) +
                                     (8 * t.by) * d.wo + 16 * t.bx;
                 w4_ld1(dst, reinterpret_cast<const char*>(base), pf_off);
@@ -702,7 +779,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         };
         W4_TRACE_DECL;
         constexpr int NHL = 2 * NSL + (LN ? 2 * NSL : 0) + (MOD ? 2 : 0);   // loads per halo set (+ its LN / modulation operands)
-        constexpr int NUL = ZPOS ? 7 : 12, NPF = EPI ? 4 : 1;   // loads per helper's share of the U slab / per prefetch (EPI: operand loads)
+        constexpr int NUL = ZPOS ? NULZ : NUF;             // loads per helper's share of the U slab (NPF above: per prefetch / operand window slot)
         // ---- prologue: V and U of stage 0 into the buffers 0; the halo of stage 1 committed; U of stage 1 and the halo sets
         // of stages 2, 3, 4 in flight
         Halo h0, h1, h2, h3;
@@ -735,7 +812,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         commit(c2, h1);
         step2();
         step_issue();
-        if constexpr (EPI) epi_issue(ci, pfreg[4], pfreg[5], pfreg[6], pfreg[7]);
+        if constexpr (EPI && MF == 3) epi_issue(ci, pfreg[4], pfreg[5], pfreg[6], pfreg[7]);
+        else if constexpr (EPI) epi_issue8(ci, pfreg[8], pfreg[9], pfreg[10], pfreg[11], pfreg[12], pfreg[13], pfreg[14], pfreg[15]);
         else prefetch(ci, pfreg[1]);
         issue(ci, h0); tag(h0);
         handoff();
@@ -813,7 +891,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
             W4_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (EPI) epi_issue(ci, pfreg[4 * PAR], pfreg[4 * PAR + 1], pfreg[4 * PAR + 2], pfreg[4 * PAR + 3]);
+            if constexpr (EPI && MF == 3) epi_issue(ci, pfreg[4 * PAR], pfreg[4 * PAR + 1], pfreg[4 * PAR + 2], pfreg[4 * PAR + 3]);
+            else if constexpr (EPI) epi_issue8(ci, pfreg[8 * PAR], pfreg[8 * PAR + 1], pfreg[8 * PAR + 2], pfreg[8 * PAR + 3], pfreg[8 * PAR + 4],
+                                               pfreg[8 * PAR + 5], pfreg[8 * PAR + 6], pfreg[8 * PAR + 7]);
             else prefetch(ci, pfreg[PAR]);
             if (!W4_DBG(256)) issue(ci, hissue);
             __builtin_amdgcn_sched_barrier(0);
