@@ -24,7 +24,8 @@
 //   * the epilogue operand (residual / skip tensor, or z of x act'(z)) reaches the consumers through the helpers' registers
 //     and the U buffer the tile's last hand-off released (EPI kernels): a consumer-side global load queues behind everything
 //     the helpers have in flight on the CU's vector-memory path.
-//   * workgroup tile = 96 couts x (8 x 4 Winograd tiles = 16 x 8 output pixels of one image); K-stage = 8 input channels;
+//   * workgroup tile = 96 couts (64 for widths that are multiples of 64 but not of 96: template parameter MF, round 6) x (8 x 4
+//     Winograd tiles = 16 x 8 output pixels of one image); K-stage = 8 input channels;
 //     two (U 48 KiB + V 16 KiB) stage buffers + wave-private halo planes = 135.5 KiB of LDS; persistent over an XCD-contiguous
 //     tile range.  The stage pipeline runs across tiles (a stage's halo addresses / liveness / LayerNorm statistics are
 //     derived when its loads are issued and travel with them in registers), so only the epilogue itself is not covered by MFMAs.
@@ -74,10 +75,10 @@ struct Wino4Geom {
     int cin, hv, wv;                   // real input channels, virtual (= output) image size
     int bx_n, by_n;                    // 16 x 8-pixel blocks per image
     int n_ct, grid, nstage, debug, mtiles;
-    int mf;                            // cout fragments per consumer wave: cout tile = 32 mf (3: cout % 96 == 0, else 2: cout % 64 == 0)
     int walk;                          // 1: the workgroups of an XCD walk its tile range interleaved (tile = slot + j * per_xcd), 0: each a contiguous sub-range
     int sc, sx, sy, sn;                // a workgroup's step from one tile to its next, as (cout tiles, columns, rows, images): mixed-radix digits
     long long* trace;                  // (tooling builds only) per-wave phase cycle sums
+    int mf;                            // cout fragments per consumer wave: cout tile = 32 mf (3: cout % 96 == 0, else 2: cout % 64 == 0); host side only
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -923,14 +924,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     // positions 2 s, 2 s + 1 and both K quads;  B fragments: V[s][kq][k4][16 wn + li][h], two 8-byte reads (one ds_read2_b64).  (ds_read_b128 moves 256 B per LDS
     // clock, ds_read2_b64 half of that: tools/w4_feed_gen.py -- the cheaper read is also worth ~5 % of shader clock here,
     // the kernel runs at the power limit.)
-    int ard = (3 * wm * 64 + lane) * 4;
+    int ard = (MF * wm * 64 + lane) * 4;
     int brd = kq * W4_VKQ + (16 * wn + li) * 2;
-    f32x4 acc[16][3];
+    f32x4 acc[16][MF];
     if constexpr (ZPOS) {                                  // (never written: constants for the epilogue, no registers)
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < MF; ++m)
                 if (w4_dead<ZP>(p)) acc[p][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     W4_TRACE_DECL;
@@ -942,8 +943,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
     // FIRST: the tile's first stage starts its accumulators from the C operand instead of reading them -- zero, or the bias
     // for position p = 5 = (xi, nu) = (1, 1): A^T e_11 A is the all-ones 2 x 2 block, so a bias placed there comes out of the
     // inverse transform added to every output pixel (no zero-fill and no bias adds in the epilogue).
-    f32x4 av[2][3];
-    f32x2 av7[3];                                          // (ZP: step 7's A operands, position 15 alone)
+    f32x4 av[2][MF];
+    f32x2 av7[MF];                                         // (ZP: step 7's A operands, position 15 alone)
     f32x2 bv[2][2];                                        // [buffer][k4] -> (h = 0, h = 1)
     auto fetch = [&](int qq, int s, int buf) {
         const float* ua = ubuf + (qq & 1) * W4_UBUF + ard;
@@ -958,21 +959,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             // positions 3 and 7 ((k4 0, k4 1) of position 3, then of position 7: step 3 finds its operands where a full pair has them),
             // step 7 the 8-byte values of position 15
             if (s == 7) {
-                const float* u7 = ubuf + (qq & 1) * W4_UBUF + 6144 + (ard >> 1);
+                const float* u7 = ubuf + (qq & 1) * W4_UBUF + 4 * W4_UPP + (ard >> 1);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) av7[m] = *reinterpret_cast<const f32x2*>(u7 + m * 128);
+                for (int m = 0; m < MF; ++m) av7[m] = *reinterpret_cast<const f32x2*>(u7 + m * 128);
             } else {
-                const int off = s == 0 ? 0 : (s == 2 ? 1536 : (s == 6 ? 3072 : 4608));
+                const int off = s == 0 ? 0 : (s == 2 ? W4_UPP : (s == 6 ? 2 * W4_UPP : 3 * W4_UPP));
 #pragma unroll
-                for (int m = 0; m < 3; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + off + m * 256);
+                for (int m = 0; m < MF; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + off + m * 256);
             }
             return;
         }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + s * W4_UPP + m * 256);
+        for (int m = 0; m < MF; ++m) av[buf][m] = *reinterpret_cast<const f32x4*>(ua + s * W4_UPP + m * 256);
     };
     fetch(0, 0, 0);
-    auto stage = [&](auto FIRST_, const f32x4 (&binit)[3]) {
+    auto stage = [&](auto FIRST_, const f32x4 (&binit)[MF]) {
         constexpr bool FIRST = decltype(FIRST_)::value;
         w4_static_for<0, 8>([&](auto S) {
             constexpr int s = decltype(S)::value;
@@ -980,7 +981,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             // executed steps 0 1 2 3 6 7 still alternate between the two operand buffers
             if constexpr (ZPOS && (s == 4 || s == 5)) return;
             constexpr int sn = (ZPOS && s == 3) ? 6 : s + 1;
-            constexpr int nmfma = (w4_dead<ZP>(2 * s) ? 0 : 6) + (w4_dead<ZP>(2 * s + 1) ? 0 : 6);
+            constexpr int nmfma = (w4_dead<ZP>(2 * s) ? 0 : 2 * MF) + (w4_dead<ZP>(2 * s + 1) ? 0 : 2 * MF);
             if constexpr (sn < 8) fetch(q, sn, sn & 1);
             else fetch(q + 1, 0, 0);
             // MFMA order (k4, m, h): the two MFMAs of one accumulator are SIX apart.  (Round 2 ran (m, k4, h) -- two apart, so that
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
 #pragma unroll
             for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int p = 2 * s + h;
@@ -1007,7 +1008,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             // pin the software pipeline: the four LDS reads of the NEXT step are spread between this step's MFMAs (a read
             // issued right behind an MFMA costs the stream nothing, a group of four ~12 cycles) -- except in step 6, whose
             // reads must have returned at the hand-off barrier that follows it
-            if constexpr (s == 6) {
+            if constexpr (MF == 2) {
+                // 64-cout tile: 4 LDS reads (2 x b128 of U, 2 x b64 of V) per 8 (full step) / 4 (half step) MFMAs, spread alike
+                if constexpr (s == 6) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                } else if constexpr (nmfma == 4) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+            } else if constexpr (s == 6) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
             } else if constexpr (nmfma == 6) {
@@ -1062,22 +1085,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         ++q;
     };
     for (int tl = 0; tl < my_tiles; ++tl) {
-        // bias of this lane's couts: 96 ct + 48 wm + 16 m + 4 kq + (0..3)
+        // bias of this lane's couts: 32 MF ct + 16 MF wm + 16 m + 4 kq + (0..3)
         // (per-lane addresses are rebuilt from a lane id the compiler cannot hoist out of the tile loop: kept live across the
         // multiply they are spilled, and a consumer's scratch reload queues behind everything the helpers have in flight)
-        f32x4 binit[3];
+        f32x4 binit[MF];
         int lane_b;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
         if constexpr (EPM == 2) {
             // (the generic epilogue is the register-hungriest: the two LDS read offsets are rebuilt per tile as well, instead of
             // being spilled around it -- the next tile's first operands were fetched before the epilogue, from the old copies)
-            ard = (3 * wm * 64 + lane_b) * 4;
+            ard = (MF * wm * 64 + lane_b) * 4;
             brd = (lane_b >> 4) * W4_VKQ + (16 * wn + (lane_b & 15)) * 2;
         }
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+        for (int m = 0; m < MF; ++m) {
             binit[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 48 * wm + 16 * m + 4 * (lane_b >> 4));
+            if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 16 * MF * wm + 16 * m + 4 * (lane_b >> 4));
         }
         stage(std::true_type{}, binit);
         for (int st = 1; st < g.nstage; ++st) {
@@ -1085,7 +1108,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         }
         {
             // ---- epilogue of tile c0: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
-            //      cout = 96 ct + 48 wm + 16 m + 4 kq + r,  tile = 16 wn + li.  The arithmetic runs on the f32x4 fragments
+            //      cout = 32 MF ct + 16 MF wm + 16 m + 4 kq + r,  tile = 16 wn + li.  The arithmetic runs on the f32x4 fragments
             //      (four couts at once: register pairs -> packed adds, no shuffling); memory goes through buffer
             //      instructions: one descriptor per tile (this wave's 48 cout planes of image n), a per-lane byte offset
             //      and a scalar offset per cout -- no 64-bit vector address arithmetic.
@@ -1097,8 +1120,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             const int t = 16 * wn + li_e;
             const int oy = 8 * tt.by + 2 * (t >> 3), ox = 16 * tt.bx + 2 * (t & 7);
             const int lo0 = ((4 * kq_e) * hw_o + oy * d.wo + ox) * 4, lo1 = lo0 + d.wo * 4;
-            const int64_t sbase = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 48 * wm) * hw_o;
-            const int plane_bytes = 48 * hw_o * 4;
+            const int64_t sbase = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 16 * MF * wm) * hw_o;
+            const int plane_bytes = 16 * MF * hw_o * 4;
             auto rsrc_of = [&](const float* p) {
                 return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + sbase), (short)0, plane_bytes, 0x00020000);
             };
@@ -1112,10 +1135,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const auto r_z = rsrc_of(DACT ? d.dact_z : d.out);
                 const auto r_res = rsrc_of(RES ? d.res : d.out);
                 // EPI: the operand pairs of this lane in the U buffer the last stage released: [wave][pair 24][lane]
-                const float* el = ubuf + ((q + 1) & 1) * W4_UBUF + (wave * 24 * 64 + lane_e) * 2;
-                f32x2 el0[8], el1[8];
+                const float* el = ubuf + ((q + 1) & 1) * W4_UBUF + (wave * 8 * MF * 64 + lane_e) * 2;
+                f32x2 el0[4 * (MF - 1)], el1[4 * (MF - 1)];
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
+                for (int m = 0; m < MF; ++m) {
                     if constexpr (EPM != 0) __builtin_amdgcn_sched_barrier(0);       // (one fragment at a time: register pressure)
                     // rows (xi): s0 = M0 + M1 + M2, s1 = M1 - M2 - M3 for each nu;  columns (nu): the same combination
                     f32x4 s0[4], s1[4];
@@ -1140,7 +1163,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     if constexpr (EPI) {
                         if (m == 1) {
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) {
+                            for (int r = 0; r < 4 * (MF - 1); ++r) {
                                 el0[r] = *reinterpret_cast<const f32x2*>(el + ((4 + r) * 2 + 0) * 128);
                                 el1[r] = *reinterpret_cast<const f32x2*>(el + ((4 + r) * 2 + 1) * 128);
                             }
@@ -1201,10 +1224,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 // (A bias seeded at position (1, 1) arrives with weight 4: once per summed pixel.)
                 const int wo_p = d.wo >> 1, hw_p = (d.ho >> 1) * wo_p;
                 const int lo_p = ((4 * kq_e) * hw_p + (4 * tt.by + (t >> 3)) * wo_p + 8 * tt.bx + (t & 7)) * 4;
-                const int64_t sbase_p = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 48 * wm) * hw_p;
-                const auto r_p = __builtin_amdgcn_make_buffer_rsrc(d.out + sbase_p, (short)0, 48 * hw_p * 4, 0x00020000);
+                const int64_t sbase_p = ((int64_t)tt.n * d.cout + W4_BM * tt.ct + 16 * MF * wm) * hw_p;
+                const auto r_p = __builtin_amdgcn_make_buffer_rsrc(d.out + sbase_p, (short)0, 16 * MF * hw_p * 4, 0x00020000);
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
+                for (int m = 0; m < MF; ++m) {
                     const f32x4 c0v = (acc[0][m] + 2.f * acc[4][m]) - acc[12][m];
                     const f32x4 c1v = (acc[1][m] + 2.f * acc[5][m]) - acc[13][m];
                     const f32x4 c3v = (acc[3][m] + 2.f * acc[7][m]) - acc[15][m];
@@ -1251,14 +1274,24 @@ extern "C" int sda_w4_trace_read(double* out) {
 }
 #endif
 
+template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP, int MF>
+static int wino4_launch_mf(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
+    static_assert(W4_LDS_ALLOC_OF(MF) <= 160 * 1024, "LDS");
+    static bool attr_set[SDA_MAX_DEVICES];
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP, MF>), W4_LDS_ALLOC_OF(MF), attr_set);
+    if (rc != SDA_OK) return rc;
+    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP, MF>), dim3(grid), dim3(512), (size_t)W4_LDS_ALLOC_OF(MF), stream, *d, g);
+    return sda_launch_status();
+}
+
+// (the 64-cout tile ships for the product variants only: the tooling variants VAR != 0 study the 96-cout kernel)
 template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
-    static_assert(W4_LDS_ALLOC <= 160 * 1024, "LDS");
-    static bool attr_set[SDA_MAX_DEVICES];
-    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), W4_LDS_ALLOC, attr_set);
-    if (rc != SDA_OK) return rc;
-    hipLaunchKernelGGL((conv_wino4_kernel<MOD, LN, SILU, EPI, VAR, ZP>), dim3(grid), dim3(512), (size_t)W4_LDS_ALLOC, stream, *d, g);
-    return sda_launch_status();
+    if constexpr (VAR == 0 && !W4_UDMA) {
+        if (g.mf == 2) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 2>(d, g, grid, stream);
+    }
+    if (g.mf != 3) return SDA_E_UNSUPPORTED;
+    return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 3>(d, g, grid, stream);
 }
 
 // the four loader configurations of the reference U-Net have a kernel: plain (backward-data convolutions), modulation +
@@ -1272,9 +1305,10 @@ static int wino4_config(const sda_conv_desc* d) {
 
 static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
     // the epilogue operand through the helpers (EPI, mode 1): one operand, tiles of at least twelve stages (the six-stage load
-    // window of a tile must open after the previous tile's operand has left the registers), SiLU' if it is an act' launch
+    // window of a tile must open after the previous tile's operand has left the registers: not before stage 5), SiLU' if it is an
+    // act' launch.  The 64-cout tile loads its 16 pairs in a two-stage window: tiles of at least eight stages (64 input channels).
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12 &&
+    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= (g.mf == 3 ? 12 : 8) &&
                      (!d->dact_z || d->act_d == SDA_ACT_SILU);
     return epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
 }
@@ -1380,7 +1414,8 @@ int sda_wino4_try(const sda_conv_desc* d, hipStream_t stream) {
 // ---------------------------------------------------------------- weight transform for this kernel (one-off per layer)
 // dst[stage][position pair p >> 1][m tile][lane = 16 kq + i][h = p & 1][k4]  <-  (G g G^T)[xi][nu] of the filter between contraction channel
 // kk = 8 stage + 2 kq + k4 and output channel mm = 16 mtile + i;  forward (transpose = 0): kk = ci, mm = co;
-// backward-data (transpose = 1): kk = co, mm = ci, filter flipped.  k_pad % 8 == 0, m_pad % 96 == 0; padding is zero.
+// backward-data (transpose = 1): kk = co, mm = ci, filter flipped.  k_pad % 8 == 0, m_pad % 96 == 0 or m_pad % 64 == 0 (the cout tile
+// the kernel then runs: W4_BM_OF; the layout itself is per 16-cout fragment and does not depend on it); padding is zero.
 __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin, int transpose, int cin_keep,
                                   float* __restrict__ dst, int k_pad, int m_pad) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -1419,7 +1454,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin
 
 extern "C" int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst,
                                           int k_pad, int m_pad, void* stream) {
-    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
+    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % 96 && m_pad % 64)) return SDA_E_BADARG;
     int64_t total = (int64_t)k_pad * m_pad;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1429,41 +1464,48 @@ extern "C" int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int
 }
 
 // ---- the zero-position packing of a w_wino4 buffer (W4_UZP above; sda_hip.h: sda_pack_conv_weight_wino4_zp): values are copied
-__global__ void pack_wino4_zp_kernel(const float* __restrict__ src, float* __restrict__ dst, int nstage, int n_ct) {
-    const int64_t total = (int64_t)nstage * n_ct * W4_UZP;
-    const int mtiles = 6 * n_ct;
+// mf: cout fragments per consumer (cout tile = 32 mf): upp = floats of a full position pair of the tile, uzp = of the packed slab
+__global__ void pack_wino4_zp_kernel(const float* __restrict__ src, float* __restrict__ dst, int nstage, int n_ct, int mf) {
+    const int upp = W4_UPP_OF(mf), uzp = W4_UZP_OF(mf);
+    const int64_t total = (int64_t)nstage * n_ct * uzp;
+    const int mtiles = 2 * mf * n_ct;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % W4_UZP);
-        const int64_t blk = i / W4_UZP;
+        const int j = (int)(i % uzp);
+        const int64_t blk = i / uzp;
         const int ct = (int)(blk % n_ct), st = (int)(blk / n_ct);
         auto at = [&](int pair, int m, int lane, int e) {
-            return src[((((int64_t)st * 8 + pair) * mtiles + 6 * ct + m) * 64 + lane) * 4 + e];
+            return src[((((int64_t)st * 8 + pair) * mtiles + 2 * mf * ct + m) * 64 + lane) * 4 + e];
         };
         float v = 0.f;
-        if (j < 4608) {                                    // full pairs 0, 2, 6
-            const int fi = j / 1536, r = j % 1536;
+        if (j < 3 * upp) {                                 // full pairs 0, 2, 6
+            const int fi = j / upp, r = j % upp;
             v = at(fi == 0 ? 0 : (fi == 1 ? 2 : 6), r / 256, (r % 256) / 4, r & 3);
-        } else if (j < 6144) {                             // positions 3 | 7: the h = 1 halves of pairs 1 and 3
-            const int r = j - 4608, e = r & 3;
+        } else if (j < 4 * upp) {                          // positions 3 | 7: the h = 1 halves of pairs 1 and 3
+            const int r = j - 3 * upp, e = r & 3;
             v = e < 2 ? at(1, r / 256, (r % 256) / 4, 2 + e) : at(3, r / 256, (r % 256) / 4, e);
-        } else if (j < 6912) {                             // position 15: the h = 1 half of pair 7
-            const int r = j - 6144;
+        } else if (j < 4 * upp + upp / 2) {                // position 15: the h = 1 half of pair 7
+            const int r = j - 4 * upp;
             v = at(7, r / 128, (r % 128) / 2, 2 + (r & 1));
         }
         dst[i] = v;
     }
 }
 
+// the cout tile a packing of m_pad output channels is made for: the kernel's own rule (sda_wino4_plan)
+static int wino4_mf_of(int m_pad) { return m_pad % 96 == 0 ? 3 : (m_pad % 64 == 0 ? 2 : 0); }
+
 extern "C" int64_t sda_wino4_zp_floats(int k_pad, int m_pad) {
-    if (k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
-    return (int64_t)(k_pad / 8) * (m_pad / W4_BM) * W4_UZP;
+    const int mf = wino4_mf_of(m_pad);
+    if (k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || !mf) return SDA_E_BADARG;
+    return (int64_t)(k_pad / 8) * (m_pad / W4_BM_OF(mf)) * W4_UZP_OF(mf);
 }
 
 extern "C" int sda_pack_conv_weight_wino4_zp(const float* w_wino4, int k_pad, int m_pad, float* dst, void* stream) {
-    if (!w_wino4 || !dst || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % W4_BM)) return SDA_E_BADARG;
+    const int mf = wino4_mf_of(m_pad);
+    if (!w_wino4 || !dst || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || !mf) return SDA_E_BADARG;
     const int64_t total = sda_wino4_zp_floats(k_pad, m_pad);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_wino4_zp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_wino4, dst, k_pad / 8, m_pad / W4_BM);
+    hipLaunchKernelGGL(pack_wino4_zp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_wino4, dst, k_pad / 8, m_pad / W4_BM_OF(mf), mf);
     return sda_launch_status();
 }

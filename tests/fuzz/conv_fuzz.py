@@ -43,10 +43,11 @@ def one_case(rng, dev, idx, large=False):
             h, w_ = rng.choice([128, 256]), rng.choice([128, 256])
         kh = kw = 3
     elif mode == 'wino4':
-        # shapes the one-wave-per-SIMD Winograd kernel tiles (height % 8 == 0, width % 16 == 0, cout % 96 == 0), incl. partial
-        # last K-stages (cin % 16 != 0), the upsampling tails and both paddings
-        cin = rng.choice([3, 8, 16, 24, 40, 96, 100, 192])
-        cout = rng.choice([96, 96, 192])
+        # shapes the one-wave-per-SIMD Winograd kernel tiles (height % 8 == 0, width % 16 == 0, cout % 96 == 0 -- or, on its 64-cout
+        # tile (round 6), cout % 64 == 0: the reference's default widths (64, 128, 256)), incl. partial last K-stages (cin % 16 != 0),
+        # the upsampling tails and both paddings
+        cin = rng.choice([3, 8, 16, 24, 40, 56, 64, 96, 100, 128, 192])
+        cout = rng.choice([96, 96, 192, 64, 64, 128, 256])
         h, w_ = rng.choice([8, 16, 24, 32, 64]), rng.choice([16, 32, 48, 64])
         if large:
             cin, cout = rng.choice([16, 24, 96]), 96
@@ -170,7 +171,7 @@ def one_case(rng, dev, idx, large=False):
     # the second-generation Winograd kernel serves the four loader configurations of the reference U-Net
     w4_cfg = (use_mod, use_ln, act == 'SiLU') in ((False, False, False), (False, False, True), (False, True, False), (True, True, False))
     # (5 = its zero-position form)
-    if mode == 'wino4' and act in (None, 'SiLU') and w4_cfg and ops.WINOGRAD4 and ops.WINOGRAD and cfg['path'] not in (2, 5):
+    if mode == 'wino4' and act in (None, 'SiLU') and w4_cfg and ops.WINOGRAD4 and ops.WINOGRAD and (cout % 96 == 0 or ops.WINO4_BM64) and cfg['path'] not in (2, 5):
         return cfg, f'expected the second-generation Winograd kernel, got path {cfg["path"]}'
     torch.cuda.synchronize()
     got = out.cpu().double()

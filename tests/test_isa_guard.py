@@ -30,10 +30,10 @@ def built():
 
 
 def _w4_params(name):
-    m = re.search(r'conv_wino4_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
+    m = re.search(r'conv_wino4_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
     assert m, name
-    mod, ln, silu, epm, var, zp = (int(v) for v in m.groups())
-    return bool(mod), bool(ln), bool(silu), epm, var, zp
+    mod, ln, silu, epm, var, zp, mf = (int(v) for v in m.groups())
+    return bool(mod), bool(ln), bool(silu), epm, var, zp, mf
 
 
 def test_conv_wino4_no_spills_and_exact_load_counts(built):
@@ -42,23 +42,26 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
     dis = G.disassemble(obj)
     kernels = [n for n in md if 'conv_wino4_kernel' in n]
     # the shipped variants: {plain, SiLU, LN} x {no operand, through the helpers, consumer loads} + mod+LN x {none, consumer}
-    # + the two zero-position kernels (up-sampled LN + skip launch of the tails, pooled-output launch of their VJP)
-    assert len(kernels) == 13, kernels
+    # + the two zero-position kernels (up-sampled LN + skip launch of the tails, pooled-output launch of their VJP); each for the
+    # 96-cout tile (MF = 3) and the 64-cout tile (MF = 2: the reference's default widths, round 6)
+    assert len(kernels) == 26, kernels
     seen = set()
     for name in kernels:
-        mod, ln, silu, epm, var, zp = _w4_params(name)
-        assert var == 0, f'tooling variant in the product library: {name}'
-        seen.add((mod, ln, silu, epm) if zp == 0 else (mod, ln, silu, epm, zp))
+        mod, ln, silu, epm, var, zp, mf = _w4_params(name)
+        assert var == 0 and mf in (2, 3), f'tooling variant in the product library: {name}'
+        seen.add(((mod, ln, silu, epm) if zp == 0 else (mod, ln, silu, epm, zp)) + (('mf2',) if mf == 2 else ()))
         k, ins = md[name], dis[name]
         h = G.histogram(ins)
         scratch_ops = sum(v for o, v in h.items() if o.startswith('scratch_'))
-        # 8 steps x 12 MFMAs x (first | later stage); zero-position kernels: 9 of the 16 positions
-        assert sum(v for o, v in h.items() if 'mfma' in o) == (192 if zp == 0 else 108), name
+        # 8 steps x 4 MF MFMAs x (first | later stage); zero-position kernels: 9 of the 16 positions
+        assert sum(v for o, v in h.items() if 'mfma' in o) == (64 * mf if zp == 0 else 36 * mf), name
         assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, (name, k)
         if epm in (0, 1):
             # the hot kernels (every launch of the reference nets): nothing spilled, no scratch segment at all
             assert k['vgpr_spill_count'] == 0 and k['sgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0 and \
                 scratch_ops == 0, (name, k, scratch_ops)
+        elif mf == 2:
+            assert k['vgpr_spill_count'] == 0 and scratch_ops == 0, (name, k, scratch_ops)       # (128 accumulators: room to spare)
         else:
             # the generic consumer-side epilogue (short tiles / two operands; no launch of the reference nets): at most the
             # two entry-time spills the helpers reload once, outside every loop
@@ -66,15 +69,17 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         # ---- the hand-counted waits.  Loads per halo set / U slab quarter / prefetch as in the kernel source:
         nsl = 1 if zp == 1 else 3                        # halo slots per lane (up-sampled source: one source pixel per lane)
         nhl = 2 * nsl + (2 * nsl if ln else 0) + (2 if mod else 0)
-        nul = 7 if zp else 12                            # zero-position kernels: the position-packed slab, seven 1-KiB pieces per helper
-        npf = 4 if epm == 1 else 1
-        npf_text = 28 if epm == 1 else 2                # EPI: 6 window slots x 4 + 4 dummies; else: the two arms of one branch
+        # zero-position kernels: the position-packed slab, seven (MF = 3) / five (MF = 2) 1-KiB pieces per helper; full: 4 MF
+        nul = (7 if mf == 3 else 5) if zp else 4 * mf
+        npf = (4 if mf == 3 else 8) if epm == 1 else 1
+        # EPI: 6 window slots x 4 + 4 dummies (MF = 3) / 2 slots x 8 + 8 dummies (MF = 2); else: the two arms of one branch
+        npf_text = (28 if mf == 3 else 24) if epm == 1 else 2
         wait_u, wait_halo = nhl + npf, min(63, 2 * (nhl + npf + nul) + nul)
         seq = G.vmem_between_waits(ins)
         if epm == 2:
             continue                                     # (compiler-visible consumer loads interleave their own waits)
         # consumer bias loads, then the helper prologue, then 4 unrolled iterations, then the drain
-        assert seq[0] == (0, 3), (name, seq[:3])
+        assert seq[0] == (0, mf), (name, seq[:3])
         body = seq[4:-1]
         assert len(body) == 8, (name, seq)
         for j in range(4):
@@ -83,11 +88,12 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         assert seq[-1][0] == 0                                                    # final drain
         # no compiler-inserted full drain anywhere else
         assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) == 3, name
-    assert seen == {(False, False, False, 0), (False, False, False, 1), (False, False, False, 2),
-                    (False, False, True, 0), (False, False, True, 1), (False, False, True, 2),
-                    (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
-                    (True, True, False, 0), (True, True, False, 2),
-                    (False, True, False, 1, 1), (False, False, False, 0, 2)}
+    shipped = {(False, False, False, 0), (False, False, False, 1), (False, False, False, 2),
+               (False, False, True, 0), (False, False, True, 1), (False, False, True, 2),
+               (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
+               (True, True, False, 0), (True, True, False, 2),
+               (False, True, False, 1, 1), (False, False, False, 0, 2)}
+    assert seen == shipped | {v + ('mf2',) for v in shipped}
 
 
 def test_fused_1d_kernels_have_no_scratch(built):

@@ -86,12 +86,20 @@ def run_case(n, cin, cout, h, w_, circular, mod, ln, silu, up, dact, res, bias, 
 
 
 def expect_path(c):
-    """the second-generation kernel serves the four loader configurations of the reference U-Net; the first generation the rest"""
+    """the second-generation kernel serves the four loader configurations of the reference U-Net; the first generation the rest --
+    where it exists: cout % 96 == 0.  Widths that are multiples of 64 only run the 64-cout tile of conv_wino4 (MF = 2) and fall
+    back to the direct kernel (0)."""
     key = (bool(c['mod']), bool(c['ln']), bool(c['silu']))
-    # (5 = its zero-position form: 2 x 2 up-sampled source with the LayerNorm loader and the skip operand through the helpers)
-    if key == (False, True, False) and c['up'] and c['res'] and not c['dact'] and c['cin'] >= 96 - 7 and os.environ.get('SDA_W4_ZP', '1') != '0':
+    mf = 3 if c['cout'] % 96 == 0 else 2
+    nstage = (c['cin'] + 7) // 8
+    epi_ok = nstage >= (12 if mf == 3 else 8)            # the epilogue operand through the helpers (wino4_epm)
+    if key not in ((False, False, False), (False, False, True), (False, True, False), (True, True, False)):
+        return 1 if mf == 3 else 0
+    # (5 = its zero-position form: 2 x 2 up-sampled source with the LayerNorm loader and ONE epilogue operand through the helpers -- the skip
+    #  tensor in the reference tails; an act'(z) operand alone selects it as well)
+    if key == (False, True, False) and c['up'] and (bool(c['res']) != bool(c['dact'])) and epi_ok and os.environ.get('SDA_W4_ZP', '1') != '0':
         return 5
-    return 2 if key in ((False, False, False), (False, False, True), (False, True, False), (True, True, False)) else 1
+    return 2
 
 
 def structured():
@@ -121,6 +129,27 @@ def structured():
     add(up=True, ln=True, cin=192, cout=96, h=32, w_=32, circular=False)
     add(n=300, cin=16, h=8, w_=16)   # more tiles than workgroups, uneven split
     add(n=33, cin=96, cout=192, h=16, w_=16, mod=True, ln=True)
+    # ---- the 64-cout tile (MF = 2): the reference's default widths (64, 128, 256) and other multiples of 64
+    add(cout=64)
+    add(cout=64, circular=False, bias=True)
+    add(cout=128, cin=24)            # two cout tiles, partial last stage
+    add(cout=256, cin=64, h=16, w_=16)
+    add(cout=320, cin=40)            # five cout tiles
+    add(cout=64, cin=64, h=64, w_=64, n=3, mod=True, ln=True, bias=True)
+    add(cout=64, cin=64, h=16, w_=32, silu=True, res=True, bias=True)          # eight stages: operand through the helpers
+    add(cout=64, cin=64, h=16, w_=32, dact=True)
+    add(cout=64, cin=56, h=16, w_=32, silu=True, res=True)                      # seven stages: consumer-side loads
+    add(cout=64, cin=56, h=16, w_=32, dact=True, circular=False)
+    add(cout=128, cin=128, h=32, w_=32, n=5, silu=True, res=True, bias=True)
+    add(cout=128, cin=128, h=32, w_=32, n=5, dact=True)
+    add(cout=256, cin=256, h=16, w_=16, n=9, dact=True, circular=False)
+    add(cout=256, cin=256, h=16, w_=16, n=9, silu=True, res=True)
+    add(cout=128, cin=100, h=16, w_=16, res=True, dact=True, bias=True)        # two operands: consumer-side loads
+    add(cout=64, cin=128, h=32, w_=32, up=True, ln=True, res=True, bias=True)  # the tail 128 -> 64: zero-position form
+    add(cout=128, cin=256, h=16, w_=32, up=True, ln=True, res=True, circular=False)
+    add(cout=64, cin=40, h=16, w_=32, up=True, ln=True, res=True)              # five stages: full kernel, consumer-side loads
+    add(cout=64, cin=16, h=8, w_=16, n=300)
+    add(cout=128, cin=64, h=16, w_=16, n=67, mod=True, ln=True)
     return cases
 
 
@@ -152,8 +181,8 @@ def main():
     rng = random.Random(0)
     worst = 0.0
     for i in range(args.cases):
-        c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 16, 24, 40, 96, 100, 192, 384]),
-                 cout=rng.choice([96, 96, 192, 384]), h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]),
+        c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 16, 24, 40, 56, 64, 96, 100, 128, 192, 256, 384]),
+                 cout=rng.choice([96, 96, 192, 384, 64, 64, 128, 256, 320]), h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]),
                  circular=rng.random() < 0.6, mod=rng.random() < 0.4, ln=rng.random() < 0.4, silu=rng.random() < 0.4,
                  up=rng.random() < 0.25, dact=rng.random() < 0.3, res=rng.random() < 0.4, bias=rng.random() < 0.6)
         if c['cin'] * c['h'] * c['w_'] * c['n'] > 4e6:
