@@ -4,7 +4,8 @@
 // convolution over g -- together the 9 taps of one 3 x 3 layer.  Round 2 ran them as four launches of the general kernel, each
 // re-reading g and writing every other pixel of every other row with 4-byte stores (0.40-0.52 of the matrix peak, the 1 x 1 class
 // latency-bound at 0.25-0.36).  Here a workgroup stages the g tile ONCE per K-stage, keeps the four class accumulators (192
-// registers: 32 macro-pixels x 96 couts x 4 classes per wave), and writes (px = 0, 1) pairs as 8-byte stores -- contiguous rows:
+// registers: 32 macro-pixels x 96 couts x 4 classes per wave; 128 on the 64-cout tile, template parameter MT), and writes
+// (px = 0, 1) pairs as 8-byte stores -- contiguous rows:
 //   * workgroup = 4 consumer waves + 4 producer waves (a wave that issues LDS-DMA itself gets a compiler-inserted vmcnt(0) in front
 //     of every LDS read: the loads must come from other waves), tile = 8 x 16 macro-pixels (16 x 32 output pixels) of one image x
 //     96 couts; consumer wave w owns macro-rows 2 w, 2 w + 1;
@@ -23,11 +24,13 @@
 #define P4_HC (P4_TW + 1)
 #define P4_NPOS (P4_HR * P4_HC)        // 153 window positions per channel
 #define P4_PLANE 176                   // >= 153, = 16 mod 32
-#define P4_BM 96
-#define P4_WSZ (9 * P4_CK * P4_BM)     // 6912 floats
-#define P4_BUF (P4_WSZ + P4_CK * P4_PLANE)
+// cout tile = 32 MT: 96 (MT = 3: the reference's training widths (96, 192, 384)) or 64 (MT = 2, round 6: its default widths
+// (64, 128, 256), experiments/kolmogorov/utils.py:52 -- 128 accumulator registers instead of 192); 128 would need 256
+#define P4_BM_OF(MT) (32 * (MT))
+#define P4_WSZ_OF(MT) (9 * P4_CK * P4_BM_OF(MT))   // 6912 | 4608 floats
+#define P4_BUF_OF(MT) (P4_WSZ_OF(MT) + P4_CK * P4_PLANE)
 #define P4_NLD ((P4_CK * P4_NPOS + 255) / 256)     // 5 input loads per thread and stage
-#define P4_NW ((P4_WSZ / 4 + 255) / 256)           // 7 16-byte weight chunks per thread and stage
+#define P4_NW_OF(MT) ((P4_WSZ_OF(MT) / 4 + 255) / 256)   // 7 | 5 16-byte weight chunks per thread and stage
 
 typedef float p4_f32x16 __attribute__((ext_vector_type(16)));
 typedef float p4_f32x2 __attribute__((ext_vector_type(2)));
@@ -37,7 +40,9 @@ __device__ constexpr int P4_CL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
 __device__ constexpr int P4_DY[9] = {0, 0, 0, 0, 1, 0, 0, 1, 1};
 __device__ constexpr int P4_DX[9] = {0, 0, 1, 0, 0, 0, 1, 0, 1};
 
+template <int MT>
 __global__ __launch_bounds__(512, 2) void conv_par4_kernel(const sda_conv_desc d, int tiles_x, int tiles_y, int n_ct) {
+    constexpr int P4_BM = P4_BM_OF(MT), P4_WSZ = P4_WSZ_OF(MT), P4_BUF = P4_BUF_OF(MT), P4_NW = P4_NW_OF(MT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,11 +115,11 @@ __global__ __launch_bounds__(512, 2) void conv_par4_kernel(const sda_conv_desc d
         return;
     }
     // ==================================================================== consumers: LDS reads + MFMA only in the loop
-    p4_f32x16 acc[4][3];
+    p4_f32x16 acc[4][MT];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.f;
     // B: channel 2 k2 + khalf at macro-pixel l31 of this wave: row 2 wave + (l31 >> 4), column l31 & 15
@@ -131,11 +136,11 @@ __global__ __launch_bounds__(512, 2) void conv_par4_kernel(const sda_conv_desc d
             for (int o = 0; o < 4; ++o) b[o] = buf[bbase + 2 * k2 * P4_PLANE + (o >> 1) * P4_HC + (o & 1)];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                float a[3];
+                float a[MT];
 #pragma unroll
-                for (int m = 0; m < 3; ++m) a[m] = buf[abase + (tap * P4_CK + 2 * k2) * P4_BM + 32 * m];
+                for (int m = 0; m < MT; ++m) a[m] = buf[abase + (tap * P4_CK + 2 * k2) * P4_BM + 32 * m];
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                for (int m = 0; m < MT; ++m)
                     acc[P4_CL[tap]][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[2 * P4_DY[tap] + P4_DX[tap]], acc[P4_CL[tap]][m], 0, 0, 0);
             }
         }
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv_par4_kernel(const sda_conv_desc d
     //  for its round trip 96 times per tile)
     const int64_t cbase = pbase + (int64_t)(co0 + 4 * khalf) * d.out_sc;
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
             p4_f32x2 rv[16];
@@ -184,7 +189,7 @@ static bool par4_ok(const sda_conv_desc* d) {
     if (d->cctx != 0 || d->mod || d->ln_mean || d->ln_rstd || d->act_in != SDA_ACT_NONE || d->dact_z || d->bias || d->n_inner != 1 ||
         d->x_n_off != 0)
         return false;
-    if (d->cout % P4_BM || d->cout_pad != d->cout || d->cin_pad % P4_CK || d->cx != d->cin_pad) return false;
+    if ((d->cout % 96 && d->cout % 64) || d->cout_pad != d->cout || d->cin_pad % P4_CK || d->cx != d->cin_pad) return false;
     if (d->ho != d->hs || d->wo != d->ws || (d->ho % P4_TR) || (d->wo % P4_TW)) return false;
     // the class-(0,0) view of a planar [n][cout][2 ho][2 wo] tensor: pixel stride 2, row stride 2 rows
     if (d->out_sx != 2 || d->out_sy != 4 * (int64_t)d->wo || d->out_sc != 4 * (int64_t)d->ho * d->wo ||
@@ -197,8 +202,19 @@ static bool par4_ok(const sda_conv_desc* d) {
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
     if ((int64_t)9 * d->cin_pad * d->cout_pad >= (1LL << 31)) return false;
-    const int64_t tiles = (int64_t)d->n * (d->ho / P4_TR) * (d->wo / P4_TW) * (d->cout / P4_BM);
+    const int64_t tiles = (int64_t)d->n * (d->ho / P4_TR) * (d->wo / P4_TW) * (d->cout / P4_BM_OF(d->cout % 96 == 0 ? 3 : 2));
     return tiles >= 1 && tiles <= 0x7fffffffLL;
+}
+
+template <int MT>
+static int par4_launch(const sda_conv_desc* d, hipStream_t stream) {
+    static bool attr_set[SDA_MAX_DEVICES];
+    const int lds = 2 * P4_BUF_OF(MT) * 4;
+    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_par4_kernel<MT>), lds, attr_set);
+    if (rc != SDA_OK) return rc;
+    const int tx = d->wo / P4_TW, ty = d->ho / P4_TR, n_ct = d->cout / P4_BM_OF(MT);
+    hipLaunchKernelGGL(conv_par4_kernel<MT>, dim3((unsigned)((int64_t)d->n * tx * ty * n_ct)), dim3(512), (size_t)lds, stream, *d, tx, ty, n_ct);
+    return sda_launch_status();
 }
 
 // One launch for the four parity classes of a stride-2 3 x 3 convolution's backward-data (see the header of this file).
@@ -206,12 +222,5 @@ static bool par4_ok(const sda_conv_desc* d) {
 // except that d->w holds all four classes' packings back to back.  SDA_E_UNSUPPORTED -> run the four launches.
 extern "C" int sda_conv_parity4(const sda_conv_desc* d, void* stream) {
     if (!par4_ok(d)) return SDA_E_UNSUPPORTED;
-    static bool attr_set[SDA_MAX_DEVICES];
-    const int lds = 2 * P4_BUF * 4;
-    const int rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_par4_kernel), lds, attr_set);
-    if (rc != SDA_OK) return rc;
-    const int tx = d->wo / P4_TW, ty = d->ho / P4_TR, n_ct = d->cout / P4_BM;
-    hipLaunchKernelGGL(conv_par4_kernel, dim3((unsigned)((int64_t)d->n * tx * ty * n_ct)), dim3(512), (size_t)lds, (hipStream_t)stream, *d,
-                       tx, ty, n_ct);
-    return sda_launch_status();
+    return d->cout % 96 == 0 ? par4_launch<3>(d, (hipStream_t)stream) : par4_launch<2>(d, (hipStream_t)stream);
 }

@@ -1022,6 +1022,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 } else {
+                    // (round 6, profiles/r06_mf2_sched_variants.txt: reads bunched early (1-2-1-1-1-1-5), all four behind the first MFMA,
+                    //  or one per MFMA measured within +-1 % of this spread on every layer type)
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -1287,7 +1289,7 @@ static int wino4_launch_mf(const sda_conv_desc* d, const Wino4Geom& g, int grid,
 // (the 64-cout tile ships for the product variants only: the tooling variants VAR != 0 study the 96-cout kernel)
 template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
-    if constexpr (VAR == 0 && !W4_UDMA) {
+    if constexpr ((VAR == 0 || VAR == 11) && !W4_UDMA) {   // (11: the phase trace of tools/wino4_check.py, tooling builds)
         if (g.mf == 2) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 2>(d, g, grid, stream);
     }
     if (g.mf != 3) return SDA_E_UNSUPPORTED;

@@ -121,11 +121,14 @@ def test_fused_1d_kernels_have_no_scratch(built):
     # the four-class accumulators of conv_par4 (192 registers) must leave room for two waves per SIMD; the multiply loop of a
     # consumer wave issues no vector-memory instruction (a wave that does gets a vmcnt(0) in front of every LDS read)
     md = G.kernel_metadata(os.path.join(built, 'conv_par4.o'))
-    (name, k), = [(n, v) for n, v in md.items() if 'conv_par4_kernel' in n]
-    assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, k
-    ins = G.disassemble(os.path.join(built, 'conv_par4.o'))[name]
-    assert sum(1 for i in ins if 'mfma' in i) == 108                       # 4 two-channel steps x 27 MFMAs, one stage body
-    assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) <= 16, 'vmcnt(0) crept into conv_par4'
+    par4 = sorted((n, v) for n, v in md.items() if 'conv_par4_kernel' in n)
+    assert len(par4) == 2, [n for n, _ in par4]          # cout tile 64 (MT = 2: the reference's default widths) and 96 (MT = 3)
+    for name, k in par4:
+        mt = int(re.search(r'conv_par4_kernelILi(\d)E', name).group(1))
+        assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, k
+        ins = G.disassemble(os.path.join(built, 'conv_par4.o'))[name]
+        assert sum(1 for i in ins if 'mfma' in i) == 36 * mt               # 4 two-channel steps x 9 taps x MT MFMAs, one stage body
+        assert sum(1 for i in ins if i.startswith('s_waitcnt') and 'vmcnt(0)' in i) <= 16, 'vmcnt(0) crept into conv_par4'
 
 
 def test_product_library_has_no_ablation_switches(built):

@@ -8,9 +8,15 @@ from sda_amd import ops
 from sda_amd.engine import launch_conv, planar_source
 dev = torch.device('cuda:0')
 res = []
-for name, cin, cout, h, n, fz in (('plain96', 96, 96, 64, 896, {}), ('modLN96', 96, 96, 64, 896, dict(ln=True, mod=True)), ('silu+res96', 96, 96, 64, 896, dict(silu=True, res=True)),
+CASES = (('plain96', 96, 96, 64, 896, {}), ('modLN96', 96, 96, 64, 896, dict(ln=True, mod=True)), ('silu+res96', 96, 96, 64, 896, dict(silu=True, res=True)),
                                   ('dact96', 96, 96, 64, 896, dict(dact=True)), ('plain384', 384, 384, 16, 896, {}),
-                                  ('uptail192', 192, 96, 64, 896, dict(ln=True, res=True, up=True)), ('pooled96', 96, 192, 64, 896, dict(pool=True))):
+                                  ('uptail192', 192, 96, 64, 896, dict(ln=True, res=True, up=True)), ('pooled96', 96, 192, 64, 896, dict(pool=True)))
+if os.environ.get('W4Q_BM64'):          # the 64-cout tile: the reference's default widths (64, 128, 256)
+    CASES = (('plain64', 64, 64, 64, 960, {}), ('modLN64', 64, 64, 64, 960, dict(ln=True, mod=True)), ('silu+res64', 64, 64, 64, 960, dict(silu=True, res=True)),
+             ('dact64', 64, 64, 64, 960, dict(dact=True)), ('plain128', 128, 128, 32, 960, {}), ('modLN128', 128, 128, 32, 960, dict(ln=True, mod=True)),
+             ('plain256', 256, 256, 16, 960, {}), ('silu+res256', 256, 256, 16, 960, dict(silu=True, res=True)),
+             ('uptail128', 128, 64, 64, 960, dict(ln=True, res=True, up=True)), ('pooled64', 64, 128, 64, 960, dict(pool=True)))
+for name, cin, cout, h, n, fz in CASES:
     hs = h // 2 if fz.get('up') else h
     x = torch.randn(n, cin, hs, hs, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     pk = ops.PackedConv(w, torch.randn(cout, device=dev))

@@ -300,6 +300,10 @@ def trace():
       cases = (('96->96 @64', 96, 96, 64, 896, ''), ('96->96 @64 +dact', 96, 96, 64, 896, 'dact'),
                ('96->96 @64 +res', 96, 96, 64, 896, 'res'), ('384->384 @16', 384, 384, 16, 896, ''),
                ('pooled 96->192 @64 (ZP 2)', 96, 192, 64, 896, 'pool'), ('up-sampled LN tail 192->96 @32->64 +res (ZP 1)', 192, 96, 64, 896, 'up'))
+      if os.environ.get('W4_TRACE_BM64'):               # the 64-cout tile (MF = 2): the reference's default widths
+          cases = (('64->64 @64', 64, 64, 64, 960, ''), ('64->64 @64 +dact', 64, 64, 64, 960, 'dact'), ('64->64 @64 +res', 64, 64, 64, 960, 'res'),
+                   ('128->128 @32', 128, 128, 32, 960, ''), ('256->256 @16', 256, 256, 16, 960, ''),
+                   ('pooled 64->128 @64 (ZP 2)', 64, 128, 64, 960, 'pool'), ('up-sampled LN tail 128->64 @32->64 +res (ZP 1)', 128, 64, 64, 960, 'up'))
       if os.environ.get('W4_TRACE_CASES'):
           cases = [c for c in cases if any(k in c[0] for k in os.environ['W4_TRACE_CASES'].split(','))]
       for name, cin, cout, h, n, epi in cases:
@@ -332,7 +336,7 @@ def trace():
         lib.sda_w4_trace_read.argtypes = [ctypes.c_void_p]
         rc = lib.sda_w4_trace_read(ctypes.cast(buf, ctypes.c_void_p))
         v = [buf[i] for i in range(64)]
-        tiles = n * (h // 8) * (h // 16) * (cout // 96)
+        tiles = n * (h // 8) * (h // 16) * (cout // (96 if cout % 96 == 0 else 64))
         stages = tiles * (cin // 8) / 256
         print(f'--- trace {name}: rc={rc}, ~{stages:.0f} stages per workgroup; cycles per stage by wave and phase; '
               f'launch {wall_ms:.3f} ms -> shader clock {v[7] / (wall_ms * 1e-3) / 1e9:.2f} GHz')
