@@ -79,6 +79,24 @@ class KeyedNoise:
                               draw_add=correction)
 
 
+class TableNoise:
+    """Corrector noise replayed from a recorded table ``(steps * corrections, batch, *event)`` on the device: the injected-noise form of
+    the reference's parity protocol (SURVEY 8c tiers 2 / 3: both sides of a free-running comparison consume the SAME draws), made
+    graph-safe -- the row is selected by the device step counter, so a captured step replays it (``KeyedNoise`` generates its draws in
+    the kernel; this source plays back draws made elsewhere, e.g. by the host generator a committed oracle fixture was made with)."""
+
+    graph_safe = True
+
+    def __init__(self, table: Tensor, corrections: int):
+        self.table, self.corrections = table, max(int(corrections), 1)
+
+    def __call__(self, step: int, correction: int) -> Tensor:
+        return self.table[step * self.corrections + correction]
+
+    def draw_dev(self, step_dev: Tensor, correction: int) -> Tensor:
+        return self.table.index_select(0, step_dev.reshape(1) * self.corrections + correction)[0]
+
+
 def all_gather_samples(local: Tensor, batch: int, always_collective: bool = False) -> Tensor:
     """Concatenate every rank's samples along dim 0 (ranks may hold unequal shares).  One collective, after the loop.
 

@@ -353,3 +353,23 @@ def test_h2_stride2_head_and_its_vjp_vs_float64(dev, f16x2, cin, cout, hs, ws, n
     gerr32 = ((gx32.double().cpu() - gref).abs().max() / gref.abs().max()).item()
     print(f'stride-2 head {cin}->{cout} @{hs}x{ws}: forward f16x2 {err:.2e} (fp32 kernel {err32:.2e}); VJP f16x2 {gerr:.2e} (fp32 kernel {gerr32:.2e})')
     assert err < 3e-6 and gerr < 3e-6
+
+
+@pytest.mark.parametrize('cin,cout,hw,n', [(96, 96, 32, 2), (192, 192, 32, 2), (384, 384, 16, 2)])
+def test_h2_trained_checkpoint_like_operands(dev, cin, cout, hw, n):
+    """what a per-tensor power-of-two scale sees in a TRAINED net -- weights whose output channels carry scales spread
+    log-uniformly over 1e-3 .. 1e1 (input channels 1e-1 .. 1e1: the small channels' `lo` halves land in f16's subnormal range) and
+    activations with a 1 % heavy tail (cubed Gaussians, max |x| ~ 1e3 x typical).  Against float64: over the whole tensor (the suite's
+    criterion, <= 3e-6 of max |ref|) AND per output channel relative to THAT channel's max |ref| (<= 4e-6: what the per-tensor scale
+    could hide; the fp32 kernels on the same launches reach 0.6 - 2.3e-6, tools/h2_trained_like.py -> profiles/r06_h2_trained_like.txt)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('h2_trained_like', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                 'tools', 'h2_trained_like.py'))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    for kw in (dict(chan=False), dict(tail=False), {}):
+        r = probe.run(cin, cout, hw, n, 11 + cin, **kw)
+        served, whole, worst, _ = r['f16x2']
+        assert served, 'the f16 x 2 kernel did not serve the launch'
+        assert whole <= 3e-6 and worst <= 4e-6, (kw, r)
+        assert worst <= 2.5 * r['f32'][2] + 1e-6, (kw, r)          # and in the fp32 kernels' class channel by channel

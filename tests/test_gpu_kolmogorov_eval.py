@@ -28,7 +28,8 @@ pytestmark = pytest.mark.gpu
 # The oracle runs on the host: one guided K64 evaluation at 64 x 64 costs it ~2.5 s in fp32 and ~5 s in fp64, so the routine suite keeps
 # the chains short (8 free-running steps = 16 guided evaluations deep; 64 trajectories x 128 steps for the statistics: ~3 min in all).
 # SDA_LONG_TESTS=1 runs the long forms (32 steps, B = 1 and 2; 256 trajectories x 128 steps: ~25 min of host time) -- green on the
-# round-5 build, profiles/r05_gputest_237_long_variants.log.
+# round-5 build, profiles/r05_gputest_237_long_variants.log.  Round 6: the 32-step chains run in EVERY `-m gpu` pass against oracle
+# trajectories committed as data (test_k64_32_step_chain_vs_committed_oracle_trajectories; tests/golden/make_golden_k64_chain.py).
 LONG = os.environ.get('SDA_LONG_TESTS', '0') == '1'
 K64 = dict(window=5, embedding=64, hidden_channels=(96, 192, 384), hidden_blocks=(3, 3, 3))
 
@@ -108,6 +109,75 @@ def test_k64_free_running_guided_hipgraph_vs_oracle(dev, k64, batch):
                                        f'is {own:.2e} from the fp64 oracle (bound: max(1e-4, 3x that))')
 
 
+def _digest(t):
+    d = t.detach().double().reshape(-1)
+    w = torch.arange(1, d.numel() + 1, dtype=torch.float64) % 8191 + 1
+    return torch.tensor([d.sum().item(), d.abs().sum().item(), (d * w).sum().item()], dtype=torch.float64)
+
+
+def _chain_inputs(batch, steps, corr=1, event=(6, 2, 64, 64)):
+    """Exactly tests/golden/make_golden_k64_chain.py::chain_inputs: everything from seeds, the corrector noise from a HOST generator."""
+    torch.manual_seed(71 + batch)
+    x1 = torch.randn((batch,) + event)
+    y = torch.randn(x1[0][..., ::4, ::4].shape)
+    g = torch.Generator().manual_seed(7700 + batch)
+    zs = torch.randn((steps * corr, batch) + event, generator=g)
+    return x1, y, zs
+
+
+@pytest.mark.parametrize('batch', [2, 1])
+def test_k64_32_step_chain_vs_committed_oracle_trajectories(dev, k64, batch):
+    """The LONG form of the test above in every routine run: 32 free-running guided PC steps (64 guided K64
+    evaluations deep) replayed from the hipGraph, against the oracle's fp32 and fp64 final samples of the SAME chain computed in the
+    build container and committed as data (tests/golden/k64_chain_b*.npz, made by make_golden_k64_chain.py from oracle/ alone: ~20 min
+    of host time per trajectory that the GPU box no longer spends).  Net, x(1), y and the recorded corrector noise are regenerated
+    from the seeds here; their float64 digests must equal the fixture's, else the fixture is stale and the test says so."""
+    import bench
+    import numpy as np
+    from sda_amd import observe as Ob
+    from sda_amd.parallel import TableNoise
+    from sda_amd.score import GaussianScore, VPSDE
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'k64_chain_b{batch}.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{os.path.basename(path)} not generated (python3 -B tests/golden/make_golden_k64_chain.py --batches {batch})')
+    fx = np.load(path)
+    steps, corr, tau, std, gamma = int(fx['steps']), 1, 0.5, 0.1, 1e-2
+    net, _ = k64
+    x1, y, zs = _chain_inputs(batch, steps, corr)
+    params = torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()])
+    for name, t in (('params', params), ('x1', x1), ('y', y), ('zs', zs)):
+        want, got_d = torch.from_numpy(fx[name + '_digest']), _digest(t)
+        assert torch.allclose(got_d, want, rtol=1e-12, atol=0), \
+            (f'stale fixture {os.path.basename(path)}: {name} regenerated from its seed differs from what the oracle ran on '
+             f'(torch {torch.__version__} here, {fx["torch_version"]} there) -- regenerate the fixture')
+    net.to(dev)
+    event = (6, 2, 64, 64)
+    score = bench.SyntheticScore(net)
+    inner = VPSDE(score, shape=())
+    object.__setattr__(score, '_sched', inner)
+    gs = GaussianScore(y, A=Ob.Subsample.space(4), std=std, sde=inner, gamma=gamma)
+    sde = VPSDE(gs, shape=event).to(dev)
+    sde.initial_noise, sde.noise_source = x1, TableNoise(zs.to(dev), corr)
+    sampler = sde.sampler((batch,), steps=steps, corrections=corr, tau=tau).capture()
+    assert sampler._graph is not None
+    mid = None
+    for i in range(steps):
+        sampler.step()
+        if i == 7:
+            mid = sampler.result().cpu().clone()
+    got = sampler.result().cpu()
+    assert torch.isfinite(got).all()
+    ref32, ref64 = torch.from_numpy(fx['ref32']), torch.from_numpy(fx['ref64'])
+    own = float(fx['own_fp32_vs_fp64'])
+    err, err32 = rel_err(got.double(), ref64), rel_err(got.double(), ref32.double())
+    err8 = rel_err(mid.double(), torch.from_numpy(fx['ref32_step8']).double())
+    print(f'K64 @ 64^2, B = {batch}, L = 6, {steps} guided PC steps (C = 1) through the hipGraph vs the committed oracle trajectories: '
+          f'HIP vs fp64 oracle {err:.2e}, vs fp32 oracle {err32:.2e} (after 8 steps {err8:.2e}), fp32 oracle vs fp64 oracle {own:.2e}')
+    assert own < 2e-3, f'the oracle disagrees with itself across precisions by {own:.2e}: the chain is too ill-conditioned to test anything'
+    assert err8 <= 1e-4 and err32 <= 1e-4, f'HIP path vs the fp32 oracle: {err8:.2e} after 8 steps, {err32:.2e} after {steps} (> 1e-4)'
+    assert err <= max(1e-4, 3 * own), f'HIP path vs fp64 oracle {err:.2e}; the fp32 oracle itself is {own:.2e} away (bound max(1e-4, 3x))'
+
+
 _ORACLE_RUNS = {}
 
 
@@ -136,14 +206,25 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     import bench
     from sda_amd import observe as Ob
     from sda_amd.score import GaussianScore, VPSDE
+    import numpy as np
     net, _ = k64
     net.to(dev)
-    B, L, steps, corr, tau, std, gamma = (256 if LONG else 64), 6, 128, 1, 0.5, 0.1, 1e-2      # (128 steps: at 64 the reference ALGORITHM's own slope is 0.986, not 0.990)
+    # round 6: the oracle side of the 256-trajectory form is committed as data (tests/golden/k64_stats_b256.npz: the per-trajectory
+    # log-spreads and the two scalars of the two oracle runs, made by make_golden_k64_chain.py --stats 256), so every routine run
+    # has the long form's statistical power; without the fixture: 64 trajectories, oracle runs on this host (256 with SDA_LONG_TESTS)
+    fpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'k64_stats_b256.npz')
+    fx = np.load(fpath) if os.path.exists(fpath) else None
+    long_form = LONG or fx is not None
+    B, L, steps, corr, tau, std, gamma = (256 if long_form else 64), 6, 128, 1, 0.5, 0.1, 1e-2      # (128 steps: at 64 the reference ALGORITHM's own slope is 0.986, not 0.990)
     event = (L, 2, 64, 64)
     torch.manual_seed(80)
     y = torch.randn(_sub4(torch.empty(event)).shape) * math.sqrt(1 + std ** 2)        # y = A x + noise, x ~ N(0, I)
-    ref_a = _oracle_samples(y, std, gamma, 81, (B,) + event, steps, corr, tau)
-    ref_b = _oracle_samples(y, std, gamma, 82, (B,) + event, steps, corr, tau)
+    if fx is not None:
+        assert torch.allclose(_digest(y), torch.from_numpy(fx['y_digest']), rtol=1e-12, atol=0), 'stale fixture k64_stats_b256.npz (y)'
+        ref_a = ref_b = None
+    else:
+        ref_a = _oracle_samples(y, std, gamma, 81, (B,) + event, steps, corr, tau)
+        ref_b = _oracle_samples(y, std, gamma, 82, (B,) + event, steps, corr, tau)
 
     score = bench.SyntheticScore(net, scale=0.0)                          # the net still runs (forward + VJP) at every evaluation
     inner = VPSDE(score, shape=())
@@ -156,7 +237,7 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     assert torch.isfinite(x).all()
 
     zcrit = 4.5
-    obs, oa, ob = _sub4(x), _sub4(ref_a), _sub4(ref_b)                    # (B, L, 2, 16, 16)
+    obs = _sub4(x)                                                        # (B, L, 2, 16, 16)
     n = obs.numel()
     pm = y / (1 + std ** 2)
     # (a) analytic posterior mean on the observed pixels (the corrector inflates their variance, not their mean): pooled z-score
@@ -173,21 +254,28 @@ def test_kolmogorov_assimilation_statistical_end_to_end(dev, k64, graph):
     #     to 0.1 std), and the per-trajectory spread is log-normal-ish with sd(log) ~ 0.44, because each trajectory adapts its own
     #     Langevin step (score.py:259).  So: same order as std, and the per-trajectory log-spreads of the GPU run against those of
     #     an oracle run by a two-sample z-test -- with the second oracle run as a check that the test is calibrated
-    spread, spread_a = (obs - y).std().item(), (oa - y).std().item()
+    mask = torch.ones(64, 64, dtype=torch.bool)
+    mask[::4, ::4] = False
+    if fx is not None:
+        spread_a, un_var_a = float(fx['spread_a']), float(fx['unobserved_var_a'])
+        la, lb = torch.from_numpy(fx['log_spread_a']), torch.from_numpy(fx['log_spread_b'])
+    else:
+        oa, ob = _sub4(ref_a), _sub4(ref_b)
+        spread_a, un_var_a = (oa - y).std().item(), ref_a[..., mask].var().item()
+        la, lb = _per_sample_log_spread(oa, y), _per_sample_log_spread(ob, y)
+    spread = (obs - y).std().item()
     assert 0.5 * std < spread < 6 * std, f'(A(x) - y).std() = {spread:.4f} is not of the order of std = {std}'
-    lg, la, lb = (_per_sample_log_spread(v, y) for v in (obs, oa, ob))
+    lg = _per_sample_log_spread(obs, y)
     two = lambda p, q: ((p.mean() - q.mean()) / (p.var() / B + q.var() / B).sqrt()).abs().item()
     z_s, z_cal = two(lg, la), two(lb, la)
     assert z_cal < zcrit, f'oracle run vs oracle run: {z_cal:.1f} sigma -- the yardstick itself is off'
     assert z_s < zcrit, (f'per-trajectory log (A(x) - y).std(): GPU {lg.mean():.3f} vs oracle {la.mean():.3f} ({z_s:.1f} sigma; oracle pair '
                          f'{z_cal:.1f} sigma)')
-    assert abs(lg.std().item() / la.std().item() - 1) < (0.25 if LONG else 0.4)               # and the same dispersion (sd of the ratio ~ 1 / sqrt(B))
+    assert abs(lg.std().item() / la.std().item() - 1) < (0.25 if long_form else 0.4)          # and the same dispersion (sd of the ratio ~ 1 / sqrt(B))
     # (c) unobserved pixels keep the prior N(0, 1): mean, and variance as the oracle's loop leaves it
-    mask = torch.ones(64, 64, dtype=torch.bool)
-    mask[::4, ::4] = False
-    un, un_a = x[..., mask], ref_a[..., mask]
+    un = x[..., mask]
     assert abs(un.mean().item()) < zcrit / math.sqrt(un.numel())
-    assert abs(un.var().item() / un_a.var().item() - 1) < 0.01
+    assert abs(un.var().item() / un_var_a - 1) < 0.01
     print(f'kolmogorov assimilation (graph={graph}): (A(x)-y).std() {spread:.4f} (oracle {spread_a:.4f}; std {std}), mean z {z:.2f}, '
           f'slope {slope:.5f} (closed form {1 / (1 + std ** 2):.5f}), log-spread {lg.mean():.3f} +- {lg.std():.3f} (oracle '
           f'{la.mean():.3f} +- {la.std():.3f}; z {z_s:.2f}, oracle pair {z_cal:.2f})')
