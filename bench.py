@@ -288,7 +288,7 @@ def roofline_report(prof, prof_steps, step_s, args, root, clock_probe=None):
     dom = max(conv, key=lambda k: conv[k]['ms_per_step']) if conv else None
     traffic, tfile, tracked = None, None, {}
     suffix = '' if args.multiply == 'f32' else '_' + args.multiply
-    for rnd in ('r05', 'r04', 'r03', 'r02'):      # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):      # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         tfile = os.path.join(root, 'profiles', f'{rnd}_{args.workload}_g{int(bool(args.guided))}c{args.corrections}{suffix}_traffic.json')
         if os.path.exists(tfile):
             tracked = json.load(open(tfile))
