@@ -86,6 +86,9 @@ __device__ __forceinline__ int n1_col(const N1Ctx& c, int nf) { return nf < NF -
 // (one batch of loads: a per-lane offset against wave-uniform bases)
 __device__ __forceinline__ void n1_load_w(const float* w, int conv, const N1Ctx& c, float (&wreg)[3][16]) {
     const float* wb = w + (size_t)conv * (3 * 64 * 64);
+#ifdef SDA_N1_NOW                      // (tooling, tools/net1d_trace.py N1_FLAGS=-DSDA_N1_NOW: what the weight loads of convolutions >= 2 cost -- results wrong)
+    if (conv > 1) return;
+#endif
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
@@ -167,6 +170,20 @@ __device__ __forceinline__ void n1_store_tile(const n1_f32x4 (&v)[NF], const boo
     }
 }
 
+// Predicated 4-byte stores without branches (round 6).  `if (own && rok) p[off] = v` compiled to an exec-mask save / and / branch /
+// restore around every store, the sixteen lane masks of a (fragment, channel row) grid living in SGPR pairs spilled to VGPR lanes
+// (v_readlane per use): ~10 instructions and a branch per store, 1 000 cycles per block and saved tensor (tools/net1d_trace.py).  A
+// raw buffer store whose offset lies beyond the descriptor's num_records is DROPPED by the hardware: the predicate goes into the
+// offset (N1_OOB for lanes that must not write; channel rows >= c fall beyond a [c][len] plane by themselves).
+#define N1_OOB 0x80000000u
+typedef unsigned n1_u32;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t n1_rsrc(const float* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000);
+}
+__device__ __forceinline__ void n1_bstore(float v, __amdgpu_buffer_rsrc_t rs, n1_u32 byte_off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 0);
+}
+
 // sum over the channels of every column: lane-local over r, across the 4 lane groups, across the 4 waves (LDS; one barrier)
 template <int NF, int NFA>
 __device__ __forceinline__ void n1_colsum(float (&s)[NF], float* red, const N1Ctx& c) {
@@ -182,6 +199,28 @@ __device__ __forceinline__ void n1_colsum(float (&s)[NF], float* red, const N1Ct
     for (int nf = 0; nf < NFA; ++nf) {
         const int m = 16 * nf + c.li;
         s[nf] = (red[m] + red[NC + m]) + (red[2 * NC + m] + red[3 * NC + m]);
+    }
+}
+
+// two independent column sums with ONE exchange (the LayerNorm backward's mean_c(gh) and mean_c(gh xh)): the same partial sums in the
+// same order as two n1_colsum calls -- bit-identical -- and one barrier + LDS round trip fewer per block
+template <int NF, int NFA>
+__device__ __forceinline__ void n1_colsum2(float (&s)[NF], float (&t)[NF], float* red, const N1Ctx& c) {
+    constexpr int NC = 16 * NF;
+#pragma unroll
+    for (int nf = 0; nf < NFA; ++nf) {
+        s[nf] += __shfl_xor(s[nf], 16, 64);
+        t[nf] += __shfl_xor(t[nf], 16, 64);
+        s[nf] += __shfl_xor(s[nf], 32, 64);
+        t[nf] += __shfl_xor(t[nf], 32, 64);
+        if (c.kq == 0) { red[c.wave * NC + 16 * nf + c.li] = s[nf]; red[4 * NC + c.wave * NC + 16 * nf + c.li] = t[nf]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nf = 0; nf < NFA; ++nf) {
+        const int m = 16 * nf + c.li;
+        s[nf] = (red[m] + red[NC + m]) + (red[2 * NC + m] + red[3 * NC + m]);
+        t[nf] = (red[4 * NC + m] + red[5 * NC + m]) + (red[6 * NC + m] + red[7 * NC + m]);
     }
 }
 
@@ -270,6 +309,15 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         ooff[nf] = (unsigned)(cbase * (int)d.out_sc + ps * (int)d.out_sx);
         boff[nf] = (unsigned)(j * N1_LD + 16 * c.kq);
     }
+    // byte offsets of this lane's (fragment nf, channel row cbase) element in a planar [c][len] save / in a [len] statistics row, N1_OOB
+    // where the column is not this tile's: the store predicates live in the offsets (see n1_bstore)
+    n1_u32 svoff[NF], stoff[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        svoff[nf] = own[nf] ? soff[nf] * 4u : N1_OOB;
+        stoff[nf] = (own[nf] && c.wave == 0 && c.kq == 0) ? (soff[nf] - (unsigned)(cbase * d.len)) * 4u : N1_OOB;
+    }
+    const n1_u32 row_b = (n1_u32)d.len * 4u;
     n1_load_tile<NF>(d.x, d.x_sn, d.x_sc, d.x_sx, d.cin, c, tin);
     n1_stage_vectors(d, c, sb, smod);
     n1_load_w(d.w, 1, c, wB);
@@ -298,14 +346,11 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         const n1_f32x4 b2 = *reinterpret_cast<const n1_f32x4*>(sb + (2 + 2 * k) * 64 + cbase);
         // ---- the block input is what the VJP differentiates through: save the own columns
         if (d.a_save) {
-            float* as = d.a_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane;
+            const auto ras = n1_rsrc(d.a_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane, plane * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* asr = as + r * d.len;               // (uniform)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int nf = 0; nf < NFL; ++nf)
-                    if (own[nf] && rok[r]) asr[soff[nf]] = a[nf][r];
-            }
+                for (int nf = 0; nf < NFL; ++nf) n1_bstore(a[nf][r], ras, svoff[nf] + r * row_b);       // (rows >= c: beyond the plane)
         }
         // ---- LayerNorm over channels of u = a + mod (two passes over registers: mean, then centred sum of squares)
         n1_f32x4 u[NF];
@@ -339,12 +384,11 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[nf][r] = (u[nf][r] - mean[nf]) * rstd[nf];
         }
-        if (d.mean_save && c.wave == 0 && c.kq == 0) {
-            float* ms = d.mean_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
-            float* rs = d.rstd_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len;
+        if (d.mean_save) {
+            const auto rms = n1_rsrc(d.mean_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len, (int64_t)d.len * 4);
+            const auto rrs = n1_rsrc(d.rstd_save + (int64_t)k * d.stat_stride + (int64_t)c.n * d.len, (int64_t)d.len * 4);
 #pragma unroll
-            for (int nf = 0; nf < NFL; ++nf)
-                if (own[nf]) { const unsigned p = soff[nf] - (unsigned)(cbase * d.len); ms[p] = mean[nf]; rs[p] = rstd[nf]; }
+            for (int nf = 0; nf < NFL; ++nf) { n1_bstore(mean[nf], rms, stoff[nf]); n1_bstore(rstd[nf], rrs, stoff[nf]); }
         }
         n1_store_tile<NF, NFL>(u, inside, rok, c, tin);
         n1_load_w(d.w, 2 + 2 * k, c, wA);                  // conv2 of this block (set A is free: the previous conv2 / the head is done)
@@ -354,15 +398,15 @@ __global__ __launch_bounds__(256) void net1d_fwd_kernel(const sda_net1d_desc d, 
         n1_f32x4 z[NF];
         n1_mm<NF, NFC>(wB, tin, boff, z);
         N1_STAMP(5);                                       // conv1 multiply
-        float* zs = d.z_save ? d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane : nullptr;
+        // (no z_save: a descriptor of zero records drops every store)
+        const auto rzs = n1_rsrc(d.z_save ? d.z_save + (int64_t)k * d.save_stride + (int64_t)c.n * plane : d.x, d.z_save ? plane * 4 : 0);
         auto conv1_epilogue = [&](auto SILU_) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float* zsr = zs + r * d.len;
 #pragma unroll
                 for (int nf = 0; nf < NFC; ++nf) {
                     const float zv = z[nf][r] + b1[r];
-                    if (zs && own[nf] && rok[r]) zsr[soff[nf]] = zv;
+                    n1_bstore(zv, rzs, svoff[nf] + r * row_b);
                     z[nf][r] = decltype(SILU_)::value ? sda_act(SDA_ACT_SILU, zv) : sda_act(d.act, zv);
                 }
             }
@@ -587,8 +631,7 @@ __global__ __launch_bounds__(256) void net1d_bwd_kernel(const sda_net1d_desc d, 
                 s1[nf] += gv; s2[nf] += gv * xh[nf][r];
             }
         }
-        n1_colsum<NF, NFC>(s1, red, c);
-        n1_colsum<NF, NFC>(s2, red + 4 * NC, c);
+        n1_colsum2<NF, NFC>(s1, s2, red, c);
 #pragma unroll
         for (int nf = 0; nf < NFC; ++nf) {
             const float av = s1[nf] * inv_c, bv = s2[nf] * inv_v;

@@ -10,7 +10,7 @@ import torch.nn as nn
 from sda_amd import _lib, ops
 from sda_amd.nn import UNet
 so = '/tmp/libn1trace.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DSDA_N1_TRACE',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-DSDA_N1_TRACE'] + os.environ.get('N1_FLAGS', '').split() + [
                        '-shared', os.path.join(R, 'sda_amd/csrc/net1d.hip'), '-o', so])
 _lib.load()
 tl = ctypes.CDLL(so)
