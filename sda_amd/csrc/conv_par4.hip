@@ -25,7 +25,8 @@
 #define P4_NPOS (P4_HR * P4_HC)        // 153 window positions per channel
 #define P4_PLANE 176                   // >= 153, = 16 mod 32
 // cout tile = 32 MT: 96 (MT = 3: the reference's training widths (96, 192, 384)) or 64 (MT = 2, round 6: its default widths
-// (64, 128, 256), experiments/kolmogorov/utils.py:52 -- 128 accumulator registers instead of 192); 128 would need 256
+// (64, 128, 256), experiments/kolmogorov/utils.py:52 -- 128 accumulator registers instead of 192) or 32 (MT = 1: the remaining
+// multiples of 32, sda/nn.py:99); 128 would need 256
 #define P4_BM_OF(MT) (32 * (MT))
 #define P4_WSZ_OF(MT) (9 * P4_CK * P4_BM_OF(MT))   // 6912 | 4608 floats
 #define P4_BUF_OF(MT) (P4_WSZ_OF(MT) + P4_CK * P4_PLANE)
@@ -189,7 +190,7 @@ static bool par4_ok(const sda_conv_desc* d) {
     if (d->cctx != 0 || d->mod || d->ln_mean || d->ln_rstd || d->act_in != SDA_ACT_NONE || d->dact_z || d->bias || d->n_inner != 1 ||
         d->x_n_off != 0)
         return false;
-    if ((d->cout % 96 && d->cout % 64) || d->cout_pad != d->cout || d->cin_pad % P4_CK || d->cx != d->cin_pad) return false;
+    if ((d->cout % 32) || d->cout_pad != d->cout || d->cin_pad % P4_CK || d->cx != d->cin_pad) return false;
     if (d->ho != d->hs || d->wo != d->ws || (d->ho % P4_TR) || (d->wo % P4_TW)) return false;
     // the class-(0,0) view of a planar [n][cout][2 ho][2 wo] tensor: pixel stride 2, row stride 2 rows
     if (d->out_sx != 2 || d->out_sy != 4 * (int64_t)d->wo || d->out_sc != 4 * (int64_t)d->ho * d->wo ||
@@ -202,7 +203,7 @@ static bool par4_ok(const sda_conv_desc* d) {
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
     if ((int64_t)9 * d->cin_pad * d->cout_pad >= (1LL << 31)) return false;
-    const int64_t tiles = (int64_t)d->n * (d->ho / P4_TR) * (d->wo / P4_TW) * (d->cout / P4_BM_OF(d->cout % 96 == 0 ? 3 : 2));
+    const int64_t tiles = (int64_t)d->n * (d->ho / P4_TR) * (d->wo / P4_TW) * (d->cout / P4_BM_OF(d->cout % 96 == 0 ? 3 : (d->cout % 64 == 0 ? 2 : 1)));
     return tiles >= 1 && tiles <= 0x7fffffffLL;
 }
 
@@ -222,5 +223,6 @@ static int par4_launch(const sda_conv_desc* d, hipStream_t stream) {
 // except that d->w holds all four classes' packings back to back.  SDA_E_UNSUPPORTED -> run the four launches.
 extern "C" int sda_conv_parity4(const sda_conv_desc* d, void* stream) {
     if (!par4_ok(d)) return SDA_E_UNSUPPORTED;
-    return d->cout % 96 == 0 ? par4_launch<3>(d, (hipStream_t)stream) : par4_launch<2>(d, (hipStream_t)stream);
+    return d->cout % 96 == 0 ? par4_launch<3>(d, (hipStream_t)stream)
+                             : (d->cout % 64 == 0 ? par4_launch<2>(d, (hipStream_t)stream) : par4_launch<1>(d, (hipStream_t)stream));
 }

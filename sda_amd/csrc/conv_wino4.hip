@@ -47,7 +47,8 @@
 #endif
 #define W4_CK 8
 // cout tile = 32 MF output channels (MF = cout fragments of 16 per consumer wave): MF = 3 -> 96 (the reference's training widths
-// (96, 192, 384), kolmogorov/train.py:19), MF = 2 -> 64 (its DEFAULT widths (64, 128, 256), kolmogorov/utils.py:52: round 6).  A
+// (96, 192, 384), kolmogorov/train.py:19), MF = 2 -> 64 (its DEFAULT widths (64, 128, 256), kolmogorov/utils.py:52: round 6), MF = 1 ->
+// 32 (the remaining multiples of 32: UNet's own default (32, 64, 128), sda/nn.py:99 -- four MFMAs per consumer step, helper-bound).  A
 // 128-cout tile (MF = 4) would need 256 accumulator registers per consumer; 128 / 256 couts run as 2 / 4 tiles of 64.
 #define W4_BM_OF(MF) (32 * (MF))
 #define W4_T 32                        // 8 x 4 Winograd tiles
@@ -62,8 +63,8 @@
 // floats of a stage's U slab in the zero-position packing (sda_pack_conv_weight_wino4_zp): the full pairs 0 / 2 / 6 at 0 / UPP / 2 UPP,
 // the live halves of pairs 1 and 3 interleaved at 3 UPP, pair 7's at 4 UPP (float2 per lane: UPP / 2), zero padding behind it up to a
 // whole number of 1-KiB pieces per helper wave: MF = 3: 6912 -> 7168 floats (28 KiB, seven pieces per helper), MF = 2: 4608 -> 5120
-// (20 KiB, five pieces per helper)
-#define W4_NULZ_OF(MF) ((MF) == 3 ? 7 : 5)
+// (20 KiB, five pieces per helper), MF = 1: 2304 -> 3072 (12 KiB, three pieces per helper)
+#define W4_NULZ_OF(MF) ((MF) == 3 ? 7 : (MF) == 2 ? 5 : 3)
 #define W4_UZP_OF(MF) (W4_NULZ_OF(MF) * 4 * 256)
 #define W4_VKQ 128                     // floats per kq plane of V: [k4 2][tile 32][h 2]
 #define W4_VPP (4 * W4_VKQ)            // floats per position pair in a V buffer
@@ -101,7 +102,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     if (d->kh != 3 || d->kw != 3 || d->stride_h != 1 || d->stride_w != 1 || d->zins_h != 1 || d->zins_w != 1)
         return SDA_E_UNSUPPORTED;
     if (d->explicit_pad || d->out_sn || d->out_sc || d->out_sy || d->out_sx) return SDA_E_UNSUPPORTED;
-    if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || (d->cout % 96 && d->cout % 64) || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
+    if (d->cctx < 0 || (d->cctx > 0 && !d->ctx) || (d->cout % 32) || d->cout_pad != d->cout || d->cin_pad % W4_CK || d->cin_pad < d->cx) return SDA_E_UNSUPPORTED;
     if ((d->ho & 7) || (d->wo & 15) || d->ho != d->hs * d->up_h || d->wo != d->ws * d->up_w) return SDA_E_UNSUPPORTED;
     if (d->up_h > 2 || d->up_w > 2 || d->up_h < 1 || d->up_w < 1) return SDA_E_UNSUPPORTED;
     // pooled output (2 x 2 cell sums at half resolution): plain launches without an epilogue operand only
@@ -132,7 +133,7 @@ int sda_wino4_plan(const sda_conv_desc* d, Wino4Geom* g) {
     g->cin = d->cx + d->cctx;
     g->hv = d->ho; g->wv = d->wo;
     g->bx_n = d->wo / 16; g->by_n = d->ho / 8;
-    g->mf = d->cout % 96 == 0 ? 3 : 2;
+    g->mf = d->cout % 96 == 0 ? 3 : (d->cout % 64 == 0 ? 2 : 1);
 #if W4_UDMA
     if (g->mf != 3) return SDA_E_UNSUPPORTED;          // (the measured-and-rejected DMA form exists for the 96-cout tile only)
 #endif
@@ -259,7 +260,8 @@ __host__ __device__ constexpr bool w4_dead(int p) { return ZP != 0 && ((p >> 2) 
 //      window of eight pairs each (the 64-channel level has only eight K-stages per tile: see epi_issue).
 template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0, int MF = 3>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
-    static_assert(MF == 2 || MF == 3, "cout tile = 64 or 96");
+    static_assert(MF >= 1 && MF <= 3, "cout tile = 32, 64 or 96");
+    static_assert(MF > 1 || (EPM != 1 && ZP != 1), "the 32-cout tile has no helper-fed epilogue operand");
     constexpr bool ZPOS = ZP != 0;                         // 9 live Winograd positions of 16 (see ZP above)
     constexpr bool EPI = EPM == 1;
     constexpr int W4_BM = W4_BM_OF(MF), W4_UPP = W4_UPP_OF(MF), W4_UBUF = W4_UBUF_OF(MF), W4_UZP = W4_UZP_OF(MF);
@@ -536,8 +538,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 w4_ld4<0>(ureg[0], b0, lane16);
                 w4_ld4<1024>(ureg[1], b0, lane16);
                 w4_ld4<2048>(ureg[2], b0, lane16);
-                w4_ld4<0>(ureg[3], b1, lane16);
-                w4_ld4<1024>(ureg[4], b1, lane16);
+                if constexpr (NULZ >= 5) {
+                    w4_ld4<0>(ureg[3], b1, lane16);
+                    w4_ld4<1024>(ureg[4], b1, lane16);
+                }
                 if constexpr (NULZ == 7) {
                     const char* b2 = b0 + 6144;
                     w4_ld4<2048>(ureg[5], b1, lane16);
@@ -551,13 +555,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const char* sp = src + pp * pstride;
                 w4_ld4<0>(ureg[pp * 2 * MF + 0], sp, lane16);
                 w4_ld4<1024>(ureg[pp * 2 * MF + 1], sp, lane16);
-                w4_ld4<2048>(ureg[pp * 2 * MF + 2], sp, lane16);
+                if constexpr (MF >= 2) w4_ld4<2048>(ureg[pp * 2 * MF + 2], sp, lane16);
                 if constexpr (MF == 3) {
                     const char* sq = sp + 3072;
                     w4_ld4<0>(ureg[pp * 6 + 3], sq, lane16);
                     w4_ld4<1024>(ureg[pp * 6 + 4], sq, lane16);
                     w4_ld4<2048>(ureg[pp * 6 + 5], sq, lane16);
-                } else {
+                } else if constexpr (MF == 2) {
                     w4_ld4<3072>(ureg[pp * 4 + 3], sp, lane16);
                 }
             }
@@ -1008,7 +1012,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             // pin the software pipeline: the four LDS reads of the NEXT step are spread between this step's MFMAs (a read
             // issued right behind an MFMA costs the stream nothing, a group of four ~12 cycles) -- except in step 6, whose
             // reads must have returned at the hand-off barrier that follows it
-            if constexpr (MF == 2) {
+            if constexpr (MF == 1) {
+                // 32-cout tile: 3 LDS reads (1 x b128 of U, 2 x b64 of V) per 4 (full step) / 2 (half step) MFMAs
+                if constexpr (s == 6) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                } else if constexpr (nmfma == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            } else if constexpr (MF == 2) {
                 // 64-cout tile: 4 LDS reads (2 x b128 of U, 2 x b64 of V) per 8 (full step) / 4 (half step) MFMAs, spread alike
                 if constexpr (s == 6) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -1138,7 +1158,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                 const auto r_res = rsrc_of(RES ? d.res : d.out);
                 // EPI: the operand pairs of this lane in the U buffer the last stage released: [wave][pair 24][lane]
                 const float* el = ubuf + ((q + 1) & 1) * W4_UBUF + (wave * 8 * MF * 64 + lane_e) * 2;
-                f32x2 el0[4 * (MF - 1)], el1[4 * (MF - 1)];
+                f32x2 el0[MF > 1 ? 4 * (MF - 1) : 1], el1[MF > 1 ? 4 * (MF - 1) : 1];
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {
                     if constexpr (EPM != 0) __builtin_amdgcn_sched_barrier(0);       // (one fragment at a time: register pressure)
@@ -1291,6 +1311,9 @@ template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
     if constexpr ((VAR == 0 || VAR == 11) && !W4_UDMA) {   // (11: the phase trace of tools/wino4_check.py, tooling builds)
         if (g.mf == 2) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 2>(d, g, grid, stream);
+        if constexpr (EPI != 1 && ZP != 1 && VAR == 0) {
+            if (g.mf == 1) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 1>(d, g, grid, stream);
+        }
     }
     if (g.mf != 3) return SDA_E_UNSUPPORTED;
     return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 3>(d, g, grid, stream);
@@ -1310,7 +1333,7 @@ static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
     // window of a tile must open after the previous tile's operand has left the registers: not before stage 5), SiLU' if it is an
     // act' launch.  The 64-cout tile loads its 16 pairs in a two-stage window: tiles of at least eight stages (64 input channels).
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    const bool epi = epi_on && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= (g.mf == 3 ? 12 : 8) &&
+    const bool epi = epi_on && g.mf >= 2 && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= (g.mf == 3 ? 12 : 8) &&
                      (!d->dact_z || d->act_d == SDA_ACT_SILU);
     return epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
 }
@@ -1456,7 +1479,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, int cout, int cin
 
 extern "C" int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst,
                                           int k_pad, int m_pad, void* stream) {
-    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % 96 && m_pad % 64)) return SDA_E_BADARG;
+    if (!w || !dst || cout <= 0 || cin <= 0 || k_pad <= 0 || m_pad <= 0 || (k_pad & 7) || (m_pad % 32)) return SDA_E_BADARG;
     int64_t total = (int64_t)k_pad * m_pad;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1494,7 +1517,7 @@ __global__ void pack_wino4_zp_kernel(const float* __restrict__ src, float* __res
 }
 
 // the cout tile a packing of m_pad output channels is made for: the kernel's own rule (sda_wino4_plan)
-static int wino4_mf_of(int m_pad) { return m_pad % 96 == 0 ? 3 : (m_pad % 64 == 0 ? 2 : 0); }
+static int wino4_mf_of(int m_pad) { return m_pad % 96 == 0 ? 3 : (m_pad % 64 == 0 ? 2 : (m_pad % 32 == 0 ? 1 : 0)); }
 
 extern "C" int64_t sda_wino4_zp_floats(int k_pad, int m_pad) {
     const int mf = wino4_mf_of(m_pad);

@@ -247,7 +247,7 @@ def conv_h2(desc: ConvDesc, pk: 'PackedConv', x_amax, out_amax: Optional[Tensor]
 
 
 PARITY4 = os.environ.get('SDA_CONV_PAR4', '1') != '0'
-WINO4_BM64 = os.environ.get('SDA_W4_BM64', '1') != '0'      # 0: widths that are multiples of 64 but not of 96 stay on the direct kernel (A/B runs)
+WINO4_BM64 = os.environ.get('SDA_W4_BM64', '1') != '0'      # 0: widths that are multiples of 32 but not of 96 stay on the direct kernel (A/B runs)
 
 
 def conv_parity4(desc: ConvDesc) -> bool:
@@ -334,10 +334,11 @@ class PackedConv:
                                                              self.wino.data_ptr(), self.k_pad, self.m_pad, _stream()),
                        'sda_pack_conv_weight_wino')
         # ... and the packing of the second-generation Winograd kernel (conv_wino4.hip: U fragments in MFMA lane order).  Its cout tile is
-        # 96 where the width allows (the reference's training widths (96, 192, 384)) and 64 for the other multiples of 64 -- the reference's
-        # DEFAULT widths (64, 128, 256), experiments/kolmogorov/utils.py:52 (round 6; the first-generation kernel stays 96-only)
+        # 96 where the width allows (the reference's training widths (96, 192, 384)), 64 for the other multiples of 64 -- the reference's
+        # DEFAULT widths (64, 128, 256), experiments/kolmogorov/utils.py:52 -- and 32 for the remaining multiples of 32 (UNet's own
+        # default (32, 64, 128), sda/nn.py:99) (round 6; the first-generation kernel stays 96-only)
         self.wino4 = None
-        if WINOGRAD4 and (self.kh, self.kw) == (3, 3) and self.m_pad == self.m_real and (self.wino is not None or (WINO4_BM64 and self.m_real % 64 == 0)):
+        if WINOGRAD4 and (self.kh, self.kw) == (3, 3) and self.m_pad == self.m_real and (self.wino is not None or (WINO4_BM64 and self.m_real % 32 == 0)):
             self.wino4 = torch.empty(16 * self.k_pad * self.m_pad, device=w.device, dtype=torch.float32)
             _lib.check(_lib.load().sda_pack_conv_weight_wino4(w.data_ptr(), cout, cin, int(transpose), keep,
                                                               self.wino4.data_ptr(), self.k_pad, self.m_pad, _stream()),

@@ -47,7 +47,7 @@ def one_case(rng, dev, idx, large=False):
         # tile (round 6), cout % 64 == 0: the reference's default widths (64, 128, 256)), incl. partial last K-stages (cin % 16 != 0),
         # the upsampling tails and both paddings
         cin = rng.choice([3, 8, 16, 24, 40, 56, 64, 96, 100, 128, 192])
-        cout = rng.choice([96, 96, 192, 64, 64, 128, 256])
+        cout = rng.choice([96, 96, 192, 64, 64, 128, 256, 32])
         h, w_ = rng.choice([8, 16, 24, 32, 64]), rng.choice([16, 32, 48, 64])
         if large:
             cin, cout = rng.choice([16, 24, 96]), 96

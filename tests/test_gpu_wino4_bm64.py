@@ -45,8 +45,8 @@ def test_structured_launch_types_on_the_64_cout_tile(w4c):
     """tools/wino4_check.py's structured cases with cout in {64, 128, 256, 320}: every loader configuration, the three epilogue
     operand routes (none / through the helpers from eight K-stages on / consumer-side loads), partial last stages, 1-5 cout tiles,
     both paddings, the up-sampled tails, more tiles than workgroups -- each against float64, and on the kernel family expected."""
-    cases = [c for c in w4c.structured() if c['cout'] % 96 != 0]
-    assert len(cases) >= 20
+    cases = [c for c in w4c.structured() if c['cout'] % 96 != 0]                   # (incl. the 32-cout tile: cout 32 / 160)
+    assert len(cases) >= 27
     for i, c in enumerate(cases):
         path, err, info = w4c.run_case(seed=4100 + i, **c)
         assert path == w4c.expect_path(c), (c, path)
@@ -57,7 +57,7 @@ def test_random_launches_on_the_64_cout_tile(w4c):
     rng = random.Random(64)
     worst = 0.0
     for i in range(40):
-        c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 24, 40, 56, 64, 100, 128, 256]), cout=rng.choice([64, 64, 128, 256, 320]),
+        c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 24, 40, 56, 64, 100, 128, 256]), cout=rng.choice([64, 64, 128, 256, 320, 32, 160]),
                  h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]), circular=rng.random() < 0.6, mod=rng.random() < 0.4,
                  ln=rng.random() < 0.4, silu=rng.random() < 0.4, up=rng.random() < 0.25, dact=rng.random() < 0.3, res=rng.random() < 0.4,
                  bias=rng.random() < 0.6)
@@ -99,7 +99,7 @@ def test_head_convolution_window_view_and_forcing_channel(dev, circular):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w_,circular', [(3, 64, 128, 32, 64, True), (2, 128, 256, 16, 32, False), (5, 64, 64, 8, 16, True),
-                                                      (1, 40, 320, 24, 48, False)])
+                                                      (1, 40, 320, 24, 48, False), (3, 32, 32, 16, 32, True), (2, 64, 160, 16, 16, False)])
 def test_pooled_output_is_the_upsample_vjp(dev, n, cin, cout, h, w_, circular):
     """The input VJP of Upsample(nearest, 2) -> conv3x3 (the tails, sda/nn.py:161-169) in one launch of the zero-position kernel at the
     64-cout tile (five 1-KiB slab pieces per helper): vs torch.autograd through the forward pair and vs the two-step form."""
@@ -243,3 +243,35 @@ def test_default_width_net_guided_score_and_pc_steps_vs_oracle(dev):
     score = lambda a, b: O.gaussian_score(lambda p, q: eps_o(p, q), sched, y, A, 0.3, 1e-2, a, b)
     want = O.sample(score, sched, x, 4, steps=2, corrections=0, tau=1.0)
     assert_close(got.cpu(), want, TOL, what='two predictor steps')
+
+
+def test_unet_default_width_net_32_64_128_forward_and_vjp_vs_oracle(dev):
+    """`UNet`'s own default widths (sda/nn.py:99: hidden_channels (32, 64, 128)) in the Kolmogorov score net: the 32-cout tile (MF = 1)
+    carries level 0, the 64-cout tile levels 1 and 2; eps against the fp32 oracle, J^T g against autograd through the float64 oracle."""
+    from sda_amd import ops
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(9)
+    net = make_score(hidden_channels=(32, 64, 128), size=64)
+    eps_o = oracle_eps_from_module(net, 'mc2d')
+    net.to(dev)
+    torch.manual_seed(10)
+    x = torch.randn(1, 4, 2, 64, 64)
+    t = torch.tensor(0.55)
+    g = torch.randn_like(x)
+    xo = x.double().requires_grad_(True)
+    eo = eps_o(xo, t.double(), torch.float64)
+    ref, = torch.autograd.grad(eo, xo, g.double())
+    prof = ops.ConvProfile()
+    ops.conv_profile = prof
+    try:
+        xd = x.to(dev).requires_grad_(True)
+        out = net(xd, t.to(dev))
+        vjp, = torch.autograd.grad(out, xd, g.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_profile = None
+    fams = {k: v['launches'] for k, v in prof.summary()['families'].items()}
+    assert fams.get('wino4', 0) >= 2 * 36 + 1 and fams.get('par4', 0) == 2, fams
+    with torch.no_grad():
+        assert_close(out.detach().cpu(), eps_o(x, t), TOL, what='eps vs the fp32 oracle')
+    assert_close(vjp.cpu(), ref, TOL, what='vjp')

@@ -43,13 +43,14 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
     kernels = [n for n in md if 'conv_wino4_kernel' in n]
     # the shipped variants: {plain, SiLU, LN} x {no operand, through the helpers, consumer loads} + mod+LN x {none, consumer}
     # + the two zero-position kernels (up-sampled LN + skip launch of the tails, pooled-output launch of their VJP); each for the
-    # 96-cout tile (MF = 3) and the 64-cout tile (MF = 2: the reference's default widths, round 6)
-    assert len(kernels) == 26, kernels
+    # 96-cout tile (MF = 3) and the 64-cout tile (MF = 2: the reference's default widths, round 6); the 32-cout tile (MF = 1) without
+    # the helper-fed operand route (EPM = 1) and the up-sampled zero-position form that needs it: 9 kernels
+    assert len(kernels) == 35, kernels
     seen = set()
     for name in kernels:
         mod, ln, silu, epm, var, zp, mf = _w4_params(name)
-        assert var == 0 and mf in (2, 3), f'tooling variant in the product library: {name}'
-        seen.add(((mod, ln, silu, epm) if zp == 0 else (mod, ln, silu, epm, zp)) + (('mf2',) if mf == 2 else ()))
+        assert var == 0 and mf in (1, 2, 3), f'tooling variant in the product library: {name}'
+        seen.add(((mod, ln, silu, epm) if zp == 0 else (mod, ln, silu, epm, zp)) + ((f'mf{mf}',) if mf != 3 else ()))
         k, ins = md[name], dis[name]
         h = G.histogram(ins)
         scratch_ops = sum(v for o, v in h.items() if o.startswith('scratch_'))
@@ -60,7 +61,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
             # the hot kernels (every launch of the reference nets): nothing spilled, no scratch segment at all
             assert k['vgpr_spill_count'] == 0 and k['sgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0 and \
                 scratch_ops == 0, (name, k, scratch_ops)
-        elif mf == 2:
+        elif mf < 3:
             assert k['vgpr_spill_count'] == 0 and scratch_ops == 0, (name, k, scratch_ops)       # (128 accumulators: room to spare)
         else:
             # the generic consumer-side epilogue (short tiles / two operands; no launch of the reference nets): at most the
@@ -70,7 +71,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         nsl = 1 if zp == 1 else 3                        # halo slots per lane (up-sampled source: one source pixel per lane)
         nhl = 2 * nsl + (2 * nsl if ln else 0) + (2 if mod else 0)
         # zero-position kernels: the position-packed slab, seven (MF = 3) / five (MF = 2) 1-KiB pieces per helper; full: 4 MF
-        nul = (7 if mf == 3 else 5) if zp else 4 * mf
+        nul = {3: 7, 2: 5, 1: 3}[mf] if zp else 4 * mf
         npf = (4 if mf == 3 else 8) if epm == 1 else 1
         # EPI: 6 window slots x 4 + 4 dummies (MF = 3) / 2 slots x 8 + 8 dummies (MF = 2); else: the two arms of one branch
         npf_text = (28 if mf == 3 else 24) if epm == 1 else 2
@@ -93,7 +94,7 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
                (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
                (True, True, False, 0), (True, True, False, 2),
                (False, True, False, 1, 1), (False, False, False, 0, 2)}
-    assert seen == shipped | {v + ('mf2',) for v in shipped}
+    assert seen == shipped | {v + ('mf2',) for v in shipped} | {v + ('mf1',) for v in shipped if v[3] != 1}
 
 
 def test_fused_1d_kernels_have_no_scratch(built):
@@ -122,7 +123,7 @@ def test_fused_1d_kernels_have_no_scratch(built):
     # consumer wave issues no vector-memory instruction (a wave that does gets a vmcnt(0) in front of every LDS read)
     md = G.kernel_metadata(os.path.join(built, 'conv_par4.o'))
     par4 = sorted((n, v) for n, v in md.items() if 'conv_par4_kernel' in n)
-    assert len(par4) == 2, [n for n, _ in par4]          # cout tile 64 (MT = 2: the reference's default widths) and 96 (MT = 3)
+    assert len(par4) == 3, [n for n, _ in par4]          # cout tile 32 (MT = 1), 64 (MT = 2: the reference's default widths) and 96 (MT = 3)
     for name, k in par4:
         mt = int(re.search(r'conv_par4_kernelILi(\d)E', name).group(1))
         assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, k

@@ -90,9 +90,9 @@ def expect_path(c):
     where it exists: cout % 96 == 0.  Widths that are multiples of 64 only run the 64-cout tile of conv_wino4 (MF = 2) and fall
     back to the direct kernel (0)."""
     key = (bool(c['mod']), bool(c['ln']), bool(c['silu']))
-    mf = 3 if c['cout'] % 96 == 0 else 2
+    mf = 3 if c['cout'] % 96 == 0 else (2 if c['cout'] % 64 == 0 else 1)
     nstage = (c['cin'] + 7) // 8
-    epi_ok = nstage >= (12 if mf == 3 else 8)            # the epilogue operand through the helpers (wino4_epm)
+    epi_ok = mf >= 2 and nstage >= (12 if mf == 3 else 8)     # the epilogue operand through the helpers (wino4_epm)
     if key not in ((False, False, False), (False, False, True), (False, True, False), (True, True, False)):
         return 1 if mf == 3 else 0
     # (5 = its zero-position form: 2 x 2 up-sampled source with the LayerNorm loader and ONE epilogue operand through the helpers -- the skip
@@ -150,6 +150,14 @@ def structured():
     add(cout=64, cin=40, h=16, w_=32, up=True, ln=True, res=True)              # five stages: full kernel, consumer-side loads
     add(cout=64, cin=16, h=8, w_=16, n=300)
     add(cout=128, cin=64, h=16, w_=16, n=67, mod=True, ln=True)
+    # ---- the 32-cout tile (MF = 1): UNet's own default widths (32, 64, 128), sda/nn.py:99, and other multiples of 32
+    add(cout=32)
+    add(cout=32, cin=32, h=64, w_=64, n=3, mod=True, ln=True, bias=True)
+    add(cout=32, cin=32, h=16, w_=32, silu=True, res=True, bias=True, circular=False)
+    add(cout=32, cin=32, h=16, w_=32, dact=True)
+    add(cout=160, cin=24, res=True, dact=True)             # five cout tiles, both operands
+    add(cout=32, cin=64, h=32, w_=32, up=True, ln=True, res=True, bias=True)   # the tail 64 -> 32: full kernel, consumer-side skip loads
+    add(cout=32, cin=16, h=8, w_=16, n=300)
     return cases
 
 
@@ -182,7 +190,7 @@ def main():
     worst = 0.0
     for i in range(args.cases):
         c = dict(n=rng.choice([1, 2, 3, 5, 9]), cin=rng.choice([3, 8, 16, 24, 40, 56, 64, 96, 100, 128, 192, 256, 384]),
-                 cout=rng.choice([96, 96, 192, 384, 64, 64, 128, 256, 320]), h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]),
+                 cout=rng.choice([96, 96, 192, 384, 64, 64, 128, 256, 320, 32, 160]), h=rng.choice([8, 16, 24, 32, 64]), w_=rng.choice([16, 32, 48, 64]),
                  circular=rng.random() < 0.6, mod=rng.random() < 0.4, ln=rng.random() < 0.4, silu=rng.random() < 0.4,
                  up=rng.random() < 0.25, dact=rng.random() < 0.3, res=rng.random() < 0.4, bias=rng.random() < 0.6)
         if c['cin'] * c['h'] * c['w_'] * c['n'] > 4e6:
