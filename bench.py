@@ -234,13 +234,15 @@ def cpu_baseline(wl, args, guided, corrections):
         t_spent += per_step[-1]
         steps_done += 1
         i += 1
-    sample_steps_per_s = steps_done / t_spent
     per_step.sort()
+    # the MEDIAN timed step (round 6; the mean had drifted +-15 % between rounds with the host's other tenants: VERDICT r5 weak 8)
+    sample_steps_per_s = 1.0 / per_step[len(per_step) // 2]
     value = sample_steps_per_s * nwin / total_windows        # cost is linear in windows / trajectories
     return dict(value=value, unit='diffusion-steps/s (same per-GPU shard, extrapolated linearly from the sample)',
                 cores=cores, kind='port', cpu_model=_cpu_model(), host_logical_cpus=ncpu, threads_chosen_by=probe,
                 # (how soft the figure is: the spread of the timed steps themselves; box to box it has been +-20 %)
                 sample_step_s={'min': per_step[0], 'median': per_step[len(per_step) // 2], 'max': per_step[-1]},
+                value_from='median timed step', mean_based_value=steps_done / t_spent * nwin / total_windows,
                 sample=f'{steps_done} timed steps after 1 warm-up step ({t_spent:.1f} s, {t_spent / steps_done:.2f} s/step) of {unit}; '
                        f'guided={int(guided)}, corrections={corrections}; scaled by {nwin}/{total_windows}')
 

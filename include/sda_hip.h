@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDA_ABI_VERSION 12
+#define SDA_ABI_VERSION 13
 
 enum {
     SDA_OK = 0,
@@ -114,7 +114,9 @@ typedef struct sda_conv_desc {
     /* optional Winograd weights for the second-generation kernel (sda_pack_conv_weight_wino4: [cin_pad/8][16][cout/16][64][2],
      * U fragments in MFMA lane order).  Taken when the layer is Winograd-eligible as above, its output height is a multiple
      * of 8 and its width of 16 (workgroup tile = 96 couts x 16 x 8 pixels of one image), and the loader fusions are one of
-     * none / SiLU / LayerNorm / modulation + LayerNorm; otherwise w_wino / the direct kernel serve the launch. */
+     * none / SiLU / LayerNorm / modulation + LayerNorm; otherwise w_wino / the direct kernel serve the launch.
+     * (ABI v13) cout % 32 == 0 suffices for THIS kernel: its cout tile is 96 where cout % 96 == 0, else 64 where cout % 64 == 0 (the
+     * reference's default widths (64, 128, 256), experiments/kolmogorov/utils.py:52), else 32 (sda/nn.py:99's (32, 64, 128)). */
     const float* w_wino4;
     /* optional output pooling (0 / 1 = off): out is [n][cout][ho / pool_h][wo / pool_w] and receives the SUM of each pool_h x pool_w
      * cell of the convolution's ho x wo output -- the input VJP of `Upsample(nearest) -> conv` (the tails, sda/nn.py:161-169) in one
@@ -123,8 +125,8 @@ typedef struct sda_conv_desc {
      * Anything else: SDA_E_UNSUPPORTED (run the plain launch and pool in the reader, sda_ln_bwd's pool arguments). */
     int32_t pool_h, pool_w;
     /* optional (may be NULL): the w_wino4 weights re-packed for the zero-position kernels (sda_pack_conv_weight_wino4_zp) -- per
-     * (K stage, 96-cout tile) the 9 live Winograd positions only, 28 KiB instead of the 36 KiB of the six position pairs that hold
-     * them.  With it the 2 x 2 up-sampled / pooled launches above run their zero-position form; without it the up-sampled launch
+     * (K stage, cout tile) the 9 live Winograd positions only, 28 KiB instead of the 36 KiB of the six position pairs that hold
+     * them (96-cout tile; 20 / 12 KiB for the 64- / 32-cout tiles).  With it the 2 x 2 up-sampled / pooled launches above run their zero-position form; without it the up-sampled launch
      * runs the full kernel (same result bit for bit) and the pooled launch is SDA_E_UNSUPPORTED. */
     const float* w_wino4_zp;
     /* OPT-IN (ABI v11; all zero = off): the fp32 multiply emulated on the f16 matrix cores, fp32 accumulation (csrc/conv_h2.hip).
@@ -153,7 +155,8 @@ int sda_conv_igemm(const sda_conv_desc* d, void* stream);
  * output parity classes of the split formulation above together.  d = the class-(0,0) launch (kh = kw = 2, explicit_pad with pad 0,
  * out / res = the class-(0,0) strided views of the planar [n][cout][2 ho][2 wo] gradient / skip tensors) with d->w = the four
  * classes' sda_pack_conv_weight packings (transpose = 1) back to back in the order (0,0), (0,1), (1,0), (1,1): [9][cin_pad][cout_pad].
- * SDA_E_UNSUPPORTED outside the kernel's range (cout % 96, ho % 8, wo % 16, loader fusions): run the four class launches. */
+ * SDA_E_UNSUPPORTED outside the kernel's range (cout % 32 -- 96- / 64- / 32-cout tiles as sda_conv_desc.w_wino4 --, ho % 8, wo % 16,
+ * loader fusions): run the four class launches. */
 int sda_conv_parity4(const sda_conv_desc* d, void* stream);
 /* which kernel family would serve the launch (pure planning, nothing is launched): 2 = one-wave-per-SIMD Winograd
  * (w_wino4), 1 = Winograd (w_wino), 3 = the single-round-trip small 1-D kernel, 4 = the 3 x 3 kernel for <= 16 output
@@ -289,11 +292,13 @@ int sda_pack_conv_weight(const float* w, int cout, int cin, int kh, int kw, int 
 int sda_pack_conv_weight_wino(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                               int m_pad, void* stream);
 
-/* U for the second-generation Winograd kernel: dst[k_pad/8][16][m_pad/16][64][2], k_pad % 8 == 0, m_pad % 96 == 0. */
+/* U for the second-generation Winograd kernel: dst[k_pad/8][16][m_pad/16][64][2], k_pad % 8 == 0, m_pad % 32 == 0 (ABI v13; % 96 before:
+ * the layout is per 16-cout fragment and does not depend on the cout tile the kernel then picks from m_pad). */
 int sda_pack_conv_weight_wino4(const float* w, int cout, int cin, int transpose, int cin_keep, float* dst, int k_pad,
                                int m_pad, void* stream);
 /* The zero-position packing of a sda_pack_conv_weight_wino4 buffer (sda_conv_desc.w_wino4_zp): dst holds
- * sda_wino4_zp_floats(k_pad, m_pad) = (k_pad / 8) * (m_pad / 96) * 7168 floats, [K stage][cout tile][7168]: the three position pairs
+ * sda_wino4_zp_floats(k_pad, m_pad) = (k_pad / 8) * (m_pad / T) * Z floats with (T, Z) = (96, 7168) for m_pad % 96 == 0, else (64, 5120)
+ * for m_pad % 64 == 0, else (32, 3072) (ABI v13), [K stage][cout tile][Z]; for the 96-cout tile: the three position pairs
  * whose two positions are both live (6 x 256 float4 each), the live halves of the pairs (2, 3) and (6, 7) interleaved into one such block,
  * the live half of pair (14, 15) as 6 x 256 float2, zero padding to 28 KiB -- the order the kernel's LDS stage buffer has, so that a
  * helper wave copies seven linear 1-KiB pieces.  Values are copied, not recomputed: the kernels stay bit-identical to the full ones. */

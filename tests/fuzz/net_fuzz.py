@@ -49,7 +49,7 @@ def one_case(rng, dev, idx):
     if SPATIAL3:
         spatial = 3
     depth = rng.choice([1, 2, 2, 3])
-    widths = {1: [4, 8, 24, 64, 96], 2: [4, 8, 16, 96], 3: [4, 8]}[depth]
+    widths = {1: [4, 8, 24, 32, 64, 96], 2: [4, 8, 16, 32, 64, 96], 3: [4, 8, 32]}[depth]      # (32 / 64: the 32- and 64-cout Winograd tiles, round 6)
     c0 = rng.choice(widths)
     hidden = tuple(c0 * 2 ** i for i in range(depth))
     blocks = tuple(rng.choice([1, 2, 3]) for _ in range(depth))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in sda_hip.h but not exported'
     assert set(declared) == set(_lib.SIGNATURES), (set(declared) ^ set(_lib.SIGNATURES))
-    assert lib.sda_abi_version() == 12
+    assert lib.sda_abi_version() == 13
 
 
 @pytest.mark.parametrize('mirror,ctype', [('ConvDesc', 'sda_conv_desc'), ('Block1dDesc', 'sda_block1d_desc'),
