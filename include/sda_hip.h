@@ -140,7 +140,7 @@ typedef struct sda_conv_desc {
      * pool_w = 2 (their VJP summed over the cells), stride_h = stride_w = 2 (the level heads; w_h2 = the four parity classes'
      * sda_pack_conv_weight_h2_rows packings back to back, class (py, px) = taps dy in ((1), (0, 2))[py] x dx alike, rows = cout, k = cin),
      * zins_h = zins_w = 2 (the heads' input VJP: the same with rows = forward cin, k = forward cout).
-     * Served by sda_conv_h2 for 3 x 3 / stride 1 / cin % 96 == 0 / cout % 96 == 0 / 16 x 16-tileable planar launches with the loader
+     * Served by sda_conv_h2 for 3 x 3 / stride 1 / cin % 32 == 0 / cout % 96 == 0 or cout % 64 == 0 (ABI v13; % 96 both before) / 16 x 16-tileable planar launches with the loader
      * fusions none / activation / (modulation +) LayerNorm and the epilogues bias, x act'(z), + res; sda_conv_igemm ignores the
      * fields.  Error against float64 equals the fp32 Winograd kernel's (3e-7, tools/f16_split_numerics.py). */
     const void* w_h2;
@@ -577,10 +577,10 @@ int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose);
  * parity class is a 2 x 2-tap convolution of the low-resolution image with the taps that fall on one source pixel summed -- 4 / 9 of the
  * multiplies.  wsum: [4 classes (2 py + px)][cout][cin][4 taps (2 a + b)], summed in fp32 by the caller (class 0 rows: dy {0} | {1, 2};
  * class 1 rows: {0, 1} | {2}; columns alike), w_amax = max |wsum|.  A descriptor with up_h = up_w = 2 takes w_h2 = this packing;
- * served for cin % 96 == 0, cout % 96 == 0, a 16 x 16-tileable SOURCE grid, loader none / (modulation +) LayerNorm, epilogues bias / + res. */
+ * served for cin % 32 == 0, cout a multiple of 96 or of 64 (ABI v13), a 16 x 16-tileable SOURCE grid, loader none / (modulation +) LayerNorm, epilogues bias / + res. */
 int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, float w_amax, void* dst, void* stream);
 int64_t sda_conv_h2_up_packed_bytes(int cout, int cin);
-/* (ABI v12) generic form of the packing: w [rows][k][ntap] (ntap 1, 2, 4 or 9, rows % 96 == 0, k % 96 == 0).  The VJP of an up-sampled tail
+/* (ABI v12) generic form of the packing: w [rows][k][ntap] (ntap 1, 2, 4 or 9; rows a multiple of 96 or of 64 -- the cout tile the kernel runs --, k % 32 == 0: ABI v13).  The VJP of an up-sampled tail
  * summed over the 2 x 2 up-sampling cells (sda_conv_desc.pool_h = pool_w = 2) runs as a 2 x 2-tap convolution over the four parity planes
  * of the fine-resolution gradient: rows = the forward cin, k = 4 classes x the forward cout (class-major), ntap = 4,
  * w[ci][class * cout + co][tap] = wsum[class][co][ci][tap] of sda_pack_conv_weight_h2_up.  Served for a 32 x 32-tileable source, plain loader,

@@ -16,7 +16,7 @@
 // (max |err| / max |ref| 1e-7 .. 1.9e-6 over the layer shapes, the fp32 kernels 2e-7 .. 1.9e-6).
 //
 // Structure (round 5, seventh version; one PERSISTENT workgroup per CU = 4 consumer + 4 producer waves, <= 256 registers each; tile = 96
-// couts x 16 x 16 pixels of one image; csrc/conv_par4.hip is the same pattern on the fp32 pipe):
+// couts (64 for widths that are multiples of 64 only: template parameter MB, round 6) x 16 x 16 pixels of one image; csrc/conv_par4.hip is the same pattern on the fp32 pipe):
 //   * K loop in stages of 16 input channels (one K step of the MFMA).  A stage in LDS = the cout tile's weight slab for all nine taps
 //     ([tap][cout fragment][piece][lane] x 16 B = 54 KiB, the packing's own order) + the 18 x 18 halo tile as [pixel][hi: 16 halves |
 //     lo: 16 halves | 16 B pad] (26 KiB); two stage buffers = 162 432 B of the CU's 163 840; ONE barrier per stage.
@@ -53,13 +53,18 @@ typedef float h2_f16v __attribute__((ext_vector_type(16)));
 #define H2_HS (H2_TS + 2)              // halo side
 #define H2_NPX (H2_HS * H2_HS)         // 324 halo pixels
 #define H2_CK 16                       // channels per stage (one K step of the 32x32x16 MFMA)
-#define H2_KQ 96                       // the layer's contraction must be a multiple of this (stages run in sixes: 3 value sets x 2 buffers)
+#define H2_KQ 32                       // the layer's contraction must be a multiple of this: an EVEN number of stages per tile (two stage buffers;
+                                       // the consumers pick the buffer from the tile-local stage index).  Round 5 had 96 here: its producers unrolled
+                                       // (3 value sets x 2 buffers =) six stages and restarted the ring with every tile; the ring now runs ACROSS tiles
 #define H2_PXB 80                      // bytes per halo pixel in LDS: 32 hi + 32 lo + 16 pad (20 banks: any 16 consecutive pixels cover all 64)
 #define H2_BTILE (H2_NPX * H2_PXB)     // 25 920 B
 #define H2_ASLAB (9 * 3 * 2 * 1024)    // 55 296 B: a stage's weights, [tap][cout fragment][piece][lane] x 16 B
 #define H2_STAGE (H2_ASLAB + H2_BTILE) // 81 216 B
 #define H2_LDS (2 * H2_STAGE)          // 162 432 B of the CU's 163 840
-#define H2_BM 96                       // couts per workgroup
+#define H2_BM 96                       // couts per workgroup, at most (template parameter MB = 32-cout fragments per tile: 3, or 2 for widths that
+                                       // are multiples of 64 only -- the reference's default (64, 128, 256), kolmogorov/utils.py:52; round 6)
+#define H2_BM_OF(MB) (32 * (MB))
+#define H2_MB_OF(rows) ((rows) % 96 == 0 ? 3 : ((rows) % 64 == 0 ? 2 : 0))
 #define H2_PRND 3                      // loader rounds per producer wave and stage (pixels lane + 64 (2 r + half))
 #define H2_TARGET_EXP 11               // max |s x| in [2^10, 2^11]
 
@@ -109,13 +114,16 @@ struct h2_args {
 // 1 x 2, 2 x 1 and 2 x 2-tap convolutions of g (what csrc/conv_par4.hip runs on the fp32 pipe): MODE 1's structure with a per-class tap
 // count.  MODE 4 = that head's FORWARD (stride_h = stride_w = 2): the transpose -- input parity planes as in MODE 2, 1 / 2 / 2 / 4 taps
 // per stage class.  Both issue exactly the 9 taps of the layer.
-template <int LOADER, int MODE = 0, int ABL = 0>         // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
+// MB: 32-cout fragments per tile (3 = 96 couts, 2 = 64).  The LDS layout keeps the 96-cout slab's place for the weights (the halo tile sits
+// behind it either way); a tap's fragments are MB x 2 KiB, the DMA copies nt x 2 MB pieces, a tap multiplies MB x 2 x 3 MFMAs.
+template <int LOADER, int MODE = 0, int ABL = 0, int MB = 3>         // LOADER: 0 plain, 1 activation (SiLU), 2 LayerNorm (+ optional modulation)
 __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, const h2_args a) {
+    static_assert(MB == 2 || MB == 3, "cout tile = 64 or 96");
     constexpr bool PLANES = MODE == 2 || MODE == 4;                 // the producers sample input parity planes; the class changes per STAGE
     constexpr bool SCATTER = MODE == 1 || MODE == 3;                // a tile writes one output parity class; the class changes per TILE
     constexpr bool VTAPS = MODE == 3 || MODE == 4;                  // (1 + py) x (1 + px) taps per class instead of 4
     constexpr int NT = MODE == 0 ? 9 : 4;                           // (most) taps of a stage
-    constexpr int TAPB = 3 * 2 * 1024;                              // bytes of one tap's weight fragments
+    constexpr int TAPB = MB * 2 * 1024;                             // bytes of one tap's weight fragments
     const int PH = PLANES ? d.hs >> 1 : d.hs, PW = PLANES ? d.ws >> 1 : d.ws;            // the grid the tiles walk (PLANES: a parity plane)
     // taps of class c = 2 py + px, and the taps of the classes before it
     auto cls_nt = [](int c) { return VTAPS ? (1 + (c >> 1)) * (1 + (c & 1)) : NT; };
@@ -228,10 +236,10 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             const unsigned char* src = slab_of(P, chunk, nt) + lane * 16;
             const unsigned lds0 = __builtin_amdgcn_readfirstlane(
                 (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(smem + bufsel * H2_STAGE)));
-            // nt * 6 pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
-            const int npc = nt * 6;
+            // nt * 2 MB pieces of 1 KiB (one wave-instruction each): wave pw takes pieces pw, pw + 4, ...
+            const int npc = nt * 2 * MB;
 #pragma unroll
-            for (int k = 0; k < (NT * 6 + 3) / 4; ++k) {
+            for (int k = 0; k < (NT * 2 * MB + 3) / 4; ++k) {
                 const int piece = pw + 4 * k;
                 if (piece < npc) {
                     unsigned keep;
@@ -289,8 +297,26 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         launder(raw[1]);
         bool more = false;
         P1 = P0;
-        auto stage = [&](auto set_c, auto buf_c, int chunk) {
+        // The ring of (3 value sets x 2 stage buffers) runs ACROSS tiles: a tile has an even number of stages (H2_KQ), so its first stage
+        // always lands in buffer 0 -- where the consumers look for it -- but on any of the three value sets.  `chunk` is the tile-local
+        // stage; at a tile's end the plan of the next tile (made one tile ahead) takes over.  Returns false behind the last stage.
+        int chunk = 0;
+        {
+            const int Ln = tile_of(1);
+            more = Ln < a.ntiles;
+            if (more) make_plan(Ln, P1);
+        }
+        auto stage = [&](auto set_c, auto buf_c) -> bool {
             constexpr int S = decltype(set_c)::value, Bf = decltype(buf_c)::value;
+            if (chunk == a.nchunk) {                                // (wave-uniform) the tile is complete: the next one's first stage
+                if (!more) return false;
+                P0 = P1;
+                ++it;
+                const int Ln = tile_of(it + 1);
+                more = Ln < a.ntiles;
+                if (more) make_plan(Ln, P1); else P1 = P0;
+                chunk = 0;
+            }
             unsigned char* buf = smem + Bf * H2_STAGE;
             dma_weights(P0, chunk, Bf);
             asm volatile("" ::: "memory");                          // (no register load may be hoisted above the DMA: the count below)
@@ -309,25 +335,19 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             launder(raw[(S + 1) % 3]);
             H2_BARRIER_PRODUCER_LDS();
+            ++chunk;
+            return true;
         };
         using c0 = std::integral_constant<int, 0>;
         using c1 = std::integral_constant<int, 1>;
         using c2t = std::integral_constant<int, 2>;
         for (;;) {
-            const int Ln = tile_of(it + 1);
-            more = Ln < a.ntiles;
-            if (more) make_plan(Ln, P1); else P1 = P0;
-            for (int chunk = 0; chunk < a.nchunk; chunk += 6) {     // (nchunk % 6 == 0: every tile starts on set 0 / buffer 0)
-                stage(c0{}, c0{}, chunk);
-                stage(c1{}, c1{}, chunk + 1);
-                stage(c2t{}, c0{}, chunk + 2);
-                stage(c0{}, c1{}, chunk + 3);
-                stage(c1{}, c0{}, chunk + 4);
-                stage(c2t{}, c1{}, chunk + 5);
-            }
-            if (!more) break;
-            P0 = P1;
-            ++it;
+            if (!stage(c0{}, c0{})) break;
+            if (!stage(c1{}, c1{})) break;
+            if (!stage(c2t{}, c0{})) break;
+            if (!stage(c0{}, c1{})) break;
+            if (!stage(c1{}, c0{})) break;
+            if (!stage(c2t{}, c1{})) break;
         }
         return;
     }
@@ -353,11 +373,11 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
         const int nct1 = SCATTER ? a.n_ct >> 2 : a.n_ct;
         const int cls = SCATTER ? cta / nct1 : 0, ct = SCATTER ? cta - cls * nct1 : cta;
         const int cy = cls >> 1, cx = cls & 1;
-        const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM;
+        const int oy0 = by * H2_TS, ox0 = bx * H2_TS, co0 = ct * H2_BM_OF(MB);
 
-        h2_f16v acc[3][2];
+        h2_f16v acc[MB][2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -377,10 +397,10 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             const int oxb = MODE == 1 ? spx : MODE == 2 ? 2 - spx : MODE == 3 ? 1 + spx : MODE == 4 ? 1 - spx : 0;
             const int ost = (MODE == 2 || MODE == 3) ? -1 : 1;
             const int nt = cls_nt(scls);                            // (wave-uniform; VTAPS: 1, 2 or 4 of the body's 4 taps run)
-            h2_h8 A[2][3][2], B[2][2][2];                           // [set][fragment][piece]
+            h2_h8 A[2][MB][2], B[2][2][2];                          // [set][fragment][piece]
             auto stage_body = [&](auto ntc_) {
                 constexpr int NTc = decltype(ntc_)::value;
-                auto load_AB = [&](int tap, h2_h8 (&Ad)[3][2], h2_h8 (&Bd)[2][2]) {
+                auto load_AB = [&](int tap, h2_h8 (&Ad)[MB][2], h2_h8 (&Bd)[2][2]) {
                     const int ta = NTc == 9 ? tap / 3 : VTAPS ? (nx == 1 ? tap : tap >> 1) : tap >> 1;
                     const int tb = NTc == 9 ? tap - 3 * ta : VTAPS ? (nx == 1 ? 0 : tap & 1) : tap & 1;
                     const unsigned char* pa = st + a_rd + tap * TAPB;
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                         Bd[f][1] = *reinterpret_cast<const h2_h8*>(pb + 2 * f * H2_HS * H2_PXB + 32);
                     }
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
+                    for (int m = 0; m < MB; ++m) {
                         Ad[m][0] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 0) * 1024);
                         Ad[m][1] = *reinterpret_cast<const h2_h8*>(pa + (2 * m + 1) * 1024);
                     }
@@ -405,34 +425,34 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
                     if (tap < NTc - 1 && (!VTAPS || tap + 1 < nt)) load_AB(tap + 1, A[s ^ 1], B[s ^ 1]);
                     if (ABL & 4) {                                  // (keep the operands alive without multiplying)
 #pragma unroll
-                        for (int m = 0; m < 3; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
+                        for (int m = 0; m < MB; ++m) acc[m][0][0] += (float)A[s][m][0][0] + (float)A[s][m][1][0];
 #pragma unroll
                         for (int f = 0; f < 2; ++f) acc[0][f][1] += (float)B[s][f][0][0] + (float)B[s][f][1][0];
                     } else {
                         // small products first (fp32 accumulation)
 #pragma unroll
-                        for (int m = 0; m < 3; ++m)
+                        for (int m = 0; m < MB; ++m)
 #pragma unroll
                             for (int f = 0; f < 2; ++f)
                                 acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][1], acc[m][f], 0, 0, 0);
 #pragma unroll
-                        for (int m = 0; m < 3; ++m)
+                        for (int m = 0; m < MB; ++m)
 #pragma unroll
                             for (int f = 0; f < 2; ++f)
                                 acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][1], B[s][f][0], acc[m][f], 0, 0, 0);
 #pragma unroll
-                        for (int m = 0; m < 3; ++m)
+                        for (int m = 0; m < MB; ++m)
 #pragma unroll
                             for (int f = 0; f < 2; ++f)
                                 acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s][m][0], B[s][f][0], acc[m][f], 0, 0, 0);
-                        // the tap's issue order: the next tap's ten operand reads between the first MFMAs
+                        // the tap's issue order: the next tap's 2 MB + 4 operand reads (ten at MB = 3) between the first MFMAs
                         if (tap < NTc - 1) {
 #pragma unroll
-                            for (int k = 0; k < 10; ++k) {
+                            for (int k = 0; k < 2 * MB + 4; ++k) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                             }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 6 * MB - (2 * MB + 4), 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
             constexpr bool BIAS = decltype(with_bias)::value;
             const float* op = EPI == 1 ? d.dact_z : d.res;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 float bias[16], opnd[2][16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bias[r] = BIAS ? d.bias[co0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
@@ -506,19 +526,19 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(const sda_conv_desc d, con
 //                             W[co = 16 chunk + 8 (lane >> 5) + i][ci = 96 ct + 32 m + (lane & 31)][8 - tap]
 // A (cout tile, chunk) slab is 54 KiB, contiguous: the LDS image of a stage, copied by LDS-DMA.
 __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, int transpose, float scale, h2_h8* __restrict__ dst,
-                               int64_t units, int ntap) {
+                               int64_t units, int ntap, int mb) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= units) return;
     const int lane = (int)(u & 63);
     int64_t t = u >> 6;
     const int piece = (int)(t & 1); t >>= 1;
-    const int m = (int)(t % 3); t /= 3;
+    const int m = (int)(t % mb); t /= mb;                 // (mb = 32-cout fragments per tile: 3, or 2 for rows % 96 != 0)
     const int tap = (int)(t % ntap); t /= ntap;
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;     // operator rows / contraction
     const int nchunk = K / H2_CK;
     const int chunk = (int)(t % nchunk);
     const int ct = (int)(t / nchunk);
-    const int row = H2_BM * ct + 32 * m + (lane & 31);
+    const int row = 32 * mb * ct + 32 * m + (lane & 31);
     h2_h8 out;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -536,8 +556,9 @@ __global__ void pack_h2_kernel(const float* __restrict__ w, int cout, int cin, i
 
 extern "C" int64_t sda_conv_h2_packed_bytes(int cout, int cin, int transpose) {
     const int M = transpose ? cin : cout, K = transpose ? cout : cin;
-    if (M <= 0 || K <= 0 || M % H2_BM || K % H2_KQ) return 0;
-    return (int64_t)(M / H2_BM) * (K / H2_CK) * H2_ASLAB;
+    const int mb = M > 0 ? H2_MB_OF(M) : 0;
+    if (M <= 0 || K <= 0 || !mb || K % H2_KQ) return 0;
+    return (int64_t)(M / H2_BM_OF(mb)) * (K / H2_CK) * (9 * mb * 2 * 1024);
 }
 
 extern "C" float sda_conv_h2_scale(float amax) { return h2_scale_of(amax); }
@@ -547,7 +568,7 @@ extern "C" int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int tr
     if (!w || !dst || bytes == 0) return SDA_E_BADARG;
     const int64_t units = bytes / 16;
     hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transpose,
-                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 9);
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 9, H2_MB_OF(transpose ? cin : cout));
     return sda_launch_status();
 }
 
@@ -555,8 +576,9 @@ extern "C" int sda_pack_conv_weight_h2(const float* w, int cout, int cin, int tr
 // taps (dy, dx) that read source pixel (i - 1 + py + a, j - 1 + px + b) of output pixel (2 i + py, 2 j + px), summed in fp32 by the
 // caller -- packed like a convolution with 4 cout rows per class: [class * (cout / 96) + cout tile][chunk][tap][m][piece][lane].
 extern "C" int64_t sda_conv_h2_up_packed_bytes(int cout, int cin) {
-    if (cout <= 0 || cin <= 0 || cout % H2_BM || cin % H2_KQ) return 0;
-    return (int64_t)4 * (cout / H2_BM) * (cin / H2_CK) * (4 * 3 * 2 * 1024);
+    const int mb = cout > 0 ? H2_MB_OF(cout) : 0;
+    if (cout <= 0 || cin <= 0 || !mb || cin % H2_KQ) return 0;
+    return (int64_t)4 * (cout / H2_BM_OF(mb)) * (cin / H2_CK) * (4 * mb * 2 * 1024);
 }
 
 extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, float w_amax, void* dst, void* stream) {
@@ -564,7 +586,7 @@ extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, 
     if (!wsum || !dst || bytes == 0) return SDA_E_BADARG;
     const int64_t units = bytes / 16;
     hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsum, 4 * cout, cin, 0,
-                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 4);
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, 4, H2_MB_OF(cout));
     return sda_launch_status();
 }
 
@@ -572,8 +594,9 @@ extern "C" int sda_pack_conv_weight_h2_up(const float* wsum, int cout, int cin, 
 // pooled tail VJP (conv_h2_kernel<.., 2>) takes rows = the forward cin, k = 4 classes x the forward cout (class-major), 4 taps:
 // w[ci][class * cout + co][2 a + b] = wsum[class][co][ci][2 a + b] of sda_pack_conv_weight_h2_up.
 extern "C" int64_t sda_conv_h2_rows_packed_bytes(int rows, int k, int ntap) {
-    if (rows <= 0 || k <= 0 || rows % H2_BM || k % H2_KQ || (ntap != 1 && ntap != 2 && ntap != 4 && ntap != 9)) return 0;
-    return (int64_t)(rows / H2_BM) * (k / H2_CK) * ((int64_t)ntap * 3 * 2 * 1024);
+    const int mb = rows > 0 ? H2_MB_OF(rows) : 0;
+    if (rows <= 0 || k <= 0 || !mb || k % H2_KQ || (ntap != 1 && ntap != 2 && ntap != 4 && ntap != 9)) return 0;
+    return (int64_t)(rows / H2_BM_OF(mb)) * (k / H2_CK) * ((int64_t)ntap * mb * 2 * 1024);
 }
 
 extern "C" int sda_pack_conv_weight_h2_rows(const float* w, int rows, int k, int ntap, float w_amax, void* dst, void* stream) {
@@ -581,7 +604,7 @@ extern "C" int sda_pack_conv_weight_h2_rows(const float* w, int rows, int k, int
     if (!w || !dst || bytes == 0) return SDA_E_BADARG;
     const int64_t units = bytes / 16;
     hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, k, 0,
-                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, ntap);
+                       h2_scale_of(w_amax), reinterpret_cast<h2_h8*>(dst), units, ntap, H2_MB_OF(rows));
     return sda_launch_status();
 }
 
@@ -635,7 +658,8 @@ static bool h2_ok(const sda_conv_desc* d) {
         return false;
     if (d->cctx != 0 || d->n_inner != 1 || d->x_n_off != 0) return false;
     const int ts = (pool || s2) ? 2 * H2_TS : H2_TS;               // source pixels per tile side
-    if (d->cx % H2_KQ || d->cout % H2_BM || d->hs % ts || d->ws % ts) return false;
+    const int mb = d->cout > 0 ? H2_MB_OF(d->cout) : 0;
+    if (d->cx % H2_KQ || !mb || d->hs % ts || d->ws % ts) return false;
     if (s2 ? (2 * d->ho != d->hs || 2 * d->wo != d->ws) : (d->ho != ((up || zins) ? 2 : 1) * d->hs || d->wo != ((up || zins) ? 2 : 1) * d->ws)) return false;
     if (up && (d->dact_z || d->act_in != SDA_ACT_NONE)) return false;
     if (pool && (d->dact_z || d->res || d->bias || d->ln_mean || d->act_in != SDA_ACT_NONE)) return false;
@@ -650,11 +674,26 @@ static bool h2_ok(const sda_conv_desc* d) {
     if (d->x_sc < 0 || d->x_sy < 0 || d->x_sx < 0 ||
         (int64_t)d->cx * d->x_sc + (int64_t)d->hs * d->x_sy + (int64_t)d->ws * d->x_sx >= (1LL << 31))
         return false;
-    const int64_t tiles = (int64_t)d->n * (d->hs / ts) * (d->ws / ts) * (d->cout / H2_BM) * ((up || zins) ? 4 : 1);
+    const int64_t tiles = (int64_t)d->n * (d->hs / ts) * (d->ws / ts) * (d->cout / H2_BM_OF(mb)) * ((up || zins) ? 4 : 1);
     return tiles >= 1 && tiles <= 0x3fffffffLL;
 }
 
 extern "C" int sda_conv_h2_supported(const sda_conv_desc* d) { return h2_ok(d) ? 1 : 0; }
+
+// one (loader, mode) kernel at the launch's cout tile (96 or 64 couts: MB = 3 / 2)
+template <int LOADER, int MODE>
+static int h2_launch(const sda_conv_desc* d, const h2_args& a, unsigned grid, int lds, int mb, hipStream_t stream) {
+    static bool set3[SDA_MAX_DEVICES], set2[SDA_MAX_DEVICES];
+    int rc;
+    if (mb == 3) {
+        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<LOADER, MODE, 0, 3>), lds, set3)) != SDA_OK) return rc;
+        hipLaunchKernelGGL((conv_h2_kernel<LOADER, MODE, 0, 3>), dim3(grid), dim3(512), (size_t)lds, stream, *d, a);
+    } else {
+        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<LOADER, MODE, 0, 2>), lds, set2)) != SDA_OK) return rc;
+        hipLaunchKernelGGL((conv_h2_kernel<LOADER, MODE, 0, 2>), dim3(grid), dim3(512), (size_t)lds, stream, *d, a);
+    }
+    return sda_launch_status();
+}
 
 extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     if (!h2_ok(d)) return SDA_E_UNSUPPORTED;
@@ -668,7 +707,8 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     const bool planes = pool || s2;
     a.tiles_x = d->ws / (planes ? 2 * H2_TS : H2_TS);              // (tiles of the grid the kernel walks: the source grid, or one of its parity planes)
     a.tiles_y = d->hs / (planes ? 2 * H2_TS : H2_TS);
-    a.n_ct = (d->cout / H2_BM) * ((up || zins) ? 4 : 1);
+    const int mb = H2_MB_OF(d->cout);
+    a.n_ct = (d->cout / H2_BM_OF(mb)) * ((up || zins) ? 4 : 1);
     a.c16 = d->cx / H2_CK;
     a.nchunk = a.c16 * (planes ? 4 : 1);
     a.stagger = 0;
@@ -686,7 +726,8 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
     int rc = SDA_OK;
 #ifdef SDA_H2_ABLATE
     {
-        static const int abl = getenv("SDA_H2_ABL") ? atoi(getenv("SDA_H2_ABL")) : 0;
+        static const int abl_env = getenv("SDA_H2_ABL") ? atoi(getenv("SDA_H2_ABL")) : 0;
+        const int abl = mb == 3 ? abl_env : 0;               // (the ablation variants exist for the 96-cout tile)
         static bool seta[16][SDA_MAX_DEVICES];
         const void* fn = nullptr;
 #define H2_ABL_CASE(v) case v: fn = reinterpret_cast<const void*>(conv_h2_kernel<0, 0, v>); \
@@ -698,48 +739,12 @@ extern "C" int sda_conv_h2(const sda_conv_desc* d, void* stream) {
         }
     }
 #endif
-    if (zins || s2) {                                              // (the stride-2 heads and their VJP: plain loader)
-        if (zins) {
-            static bool setz[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 3>), lds, setz)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<0, 3>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-        } else {
-            static bool sets[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), lds, sets)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<0, 4>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-        }
-        return sda_launch_status();
-    }
-    if (pool) {                                                    // (the tails' VJP: plain loader, no epilogue operand)
-        static bool setp0[SDA_MAX_DEVICES];
-        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 2>), lds, setp0)) != SDA_OK) return rc;
-        hipLaunchKernelGGL((conv_h2_kernel<0, 2>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-        return sda_launch_status();
-    }
-    if (up) {                                                      // (the tails: LayerNorm or plain loader)
-        if (d->ln_mean) {
-            static bool setu2[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2, 1>), lds, setu2)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<2, 1>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-        } else {
-            static bool setu0[SDA_MAX_DEVICES];
-            if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0, 1>), lds, setu0)) != SDA_OK) return rc;
-            hipLaunchKernelGGL((conv_h2_kernel<0, 1>), dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-        }
-        return sda_launch_status();
-    }
-    if (d->ln_mean) {
-        static bool set2[SDA_MAX_DEVICES];
-        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<2>), lds, set2)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<2>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-    } else if (d->act_in != SDA_ACT_NONE) {
-        static bool set1[SDA_MAX_DEVICES];
-        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<1>), lds, set1)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<1>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-    } else {
-        static bool set0[SDA_MAX_DEVICES];
-        if ((rc = sda_raise_dyn_lds(reinterpret_cast<const void*>(conv_h2_kernel<0>), lds, set0)) != SDA_OK) return rc;
-        hipLaunchKernelGGL(conv_h2_kernel<0>, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, *d, a);
-    }
-    return sda_launch_status();
+    // (the stride-2 heads and their VJP, the tails' VJP: plain loader; the tails: LayerNorm or plain; the block convolutions: all three)
+    if (zins) return h2_launch<0, 3>(d, a, grid, lds, mb, (hipStream_t)stream);
+    if (s2) return h2_launch<0, 4>(d, a, grid, lds, mb, (hipStream_t)stream);
+    if (pool) return h2_launch<0, 2>(d, a, grid, lds, mb, (hipStream_t)stream);
+    if (up) return d->ln_mean ? h2_launch<2, 1>(d, a, grid, lds, mb, (hipStream_t)stream) : h2_launch<0, 1>(d, a, grid, lds, mb, (hipStream_t)stream);
+    if (d->ln_mean) return h2_launch<2, 0>(d, a, grid, lds, mb, (hipStream_t)stream);
+    if (d->act_in != SDA_ACT_NONE) return h2_launch<1, 0>(d, a, grid, lds, mb, (hipStream_t)stream);
+    return h2_launch<0, 0>(d, a, grid, lds, mb, (hipStream_t)stream);
 }

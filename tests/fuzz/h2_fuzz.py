@@ -3,7 +3,7 @@
 
     SDA_MULTIPLY=f16x2 python tests/fuzz/h2_fuzz.py [--cases 200] [--seed 0]
 
-Every case draws channel counts (multiples of 96 up to 384: 1 .. 4 cout tiles), a NON-SQUARE image size in multiples of 16, a batch,
+Every case draws channel counts (multiples of 96 up to 384: 1 .. 4 cout tiles -- and, round 6, multiples of 64 / 32: the 64-cout tile, K % 32), a NON-SQUARE image size in multiples of 16, a batch,
 forward / backward-data packing, the padding, one of the loader fusions of the reference's blocks (none, SiLU, LayerNorm, modulation +
 LayerNorm), one of the epilogues (none, x act'(z), + residual), bias on / off, an input magnitude between 1e-4 and 1e4 and where the
 input scale comes from (an absmax pass, a loose static bound, the LayerNorm bound), runs the launch through the C ABI and compares
@@ -121,7 +121,7 @@ def main():
     torch.manual_seed(args.seed)
     worst, worst32, fails, served = 0.0, 0.0, 0, 0
     for idx in range(args.cases):
-        cin, cout = rng.choice([96, 96, 192, 288, 384]), rng.choice([96, 96, 192, 288, 384])
+        cin, cout = rng.choice([96, 96, 192, 288, 384, 64, 128, 256, 320]), rng.choice([96, 96, 192, 288, 384, 64, 128, 256, 320])
         h, w_ = 16 * rng.choice([1, 1, 2, 3, 4, 6]), 16 * rng.choice([1, 2, 2, 3, 5])
         n = rng.choice([1, 1, 2, 3, 5, 9])
         if n * cin * cout * h * w_ > 3.5e9:

@@ -62,7 +62,9 @@ def _ref64(x, w, bias, circular, transpose, ln, mod, silu_in, dact_z, res):
 CASES = [('plain', {}), ('mod+LN', dict(ln=True, mod=True)), ('LN', dict(ln=True)), ('SiLU+res', dict(silu=True, res=True)), ('dact', dict(dact=True))]
 
 
-@pytest.mark.parametrize('cin,cout,hw,n', [(96, 96, 32, 2), (192, 96, 16, 3), (96, 192, 48, 1), (384, 384, 16, 2)])
+@pytest.mark.parametrize('cin,cout,hw,n', [(96, 96, 32, 2), (192, 96, 16, 3), (96, 192, 48, 1), (384, 384, 16, 2),
+                                           # round 6: the 64-cout tile and K % 32 (the reference's default widths (64, 128, 256), mixed with 96-multiples)
+                                           (64, 64, 32, 2), (128, 256, 16, 3), (256, 128, 32, 1), (96, 64, 16, 2), (320, 64, 16, 1)])
 @pytest.mark.parametrize('transpose', [False, True])
 def test_h2_launches_vs_float64(dev, f16x2, cin, cout, hw, n, transpose):
     from sda_amd import ops
@@ -107,7 +109,8 @@ def test_h2_scale_and_fallbacks(dev, f16x2):
     lib = _lib.load()
     for amax, want in ((1.0, 1024.0), (1.5, 1024.0), (2.0, 512.0), (1000.0, 2.0), (3e-3, 2.0 ** 19), (0.0, 1.0), (float('inf'), 1.0)):
         assert lib.sda_conv_h2_scale(amax) == want, (amax, lib.sda_conv_h2_scale(amax))
-    assert lib.sda_conv_h2_packed_bytes(96, 96, 0) == 3 * 9 * 12 * 1024 and lib.sda_conv_h2_packed_bytes(96, 11, 0) == 0
+    assert lib.sda_conv_h2_packed_bytes(96, 96, 0) == 6 * 9 * 6 * 1024 and lib.sda_conv_h2_packed_bytes(96, 11, 0) == 0
+    assert lib.sda_conv_h2_packed_bytes(64, 64, 0) == 4 * 9 * 4 * 1024 and lib.sda_conv_h2_packed_bytes(32, 64, 0) == 0 and lib.sda_conv_h2_packed_bytes(64, 48, 0) == 0
     # a 3 x 3 layer whose channels do not tile (11 -> 96, the head) and an image that does not tile by 16: the fp32 kernels serve them
     for cin, cout, hw in ((11, 96, 32), (96, 96, 24)):
         x = torch.randn(1, cin, hw, hw, device=dev)
@@ -241,7 +244,8 @@ def test_ln_bwd_reports_the_max_of_its_output(dev, c, h, w_, n, pool):
 
 
 @pytest.mark.parametrize('cin,cout,hs,ws,n,circular,ln,with_res', [(192, 96, 16, 16, 2, True, True, True), (384, 192, 16, 32, 1, False, True, True),
-                                                                   (96, 96, 32, 16, 3, True, False, False), (192, 96, 48, 16, 1, False, True, False)])
+                                                                   (96, 96, 32, 16, 3, True, False, False), (192, 96, 48, 16, 1, False, True, False),
+                                                                   (128, 64, 16, 32, 2, True, True, True), (256, 128, 16, 16, 1, False, True, True)])
 def test_h2_upsampled_tail_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular, ln, with_res):
     """The tails (LayerNorm -> Upsample(nearest, 2) -> conv 3 x 3, sda/nn.py:161-169) on conv_h2's parity-class form (four 2 x 2-tap
     convolutions of the low-resolution tile with pre-summed taps) against float64 and against the zero-position Winograd kernel."""
@@ -283,7 +287,7 @@ def test_h2_upsampled_tail_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular
 
 
 @pytest.mark.parametrize('cin,cout,hs,ws,n,circular', [(192, 96, 16, 16, 2, True), (384, 192, 16, 32, 1, False), (96, 96, 32, 16, 3, True),
-                                                       (192, 96, 48, 16, 1, False)])
+                                                       (192, 96, 48, 16, 1, False), (128, 64, 16, 32, 2, True), (256, 128, 16, 16, 1, False)])
 def test_h2_pooled_tail_vjp_vs_float64_autograd(dev, f16x2, cin, cout, hs, ws, n, circular):
     """The VJP of Upsample(nearest, 2) -> conv 3 x 3 (the tails' backward, sda/score.py:394 through sda/nn.py:161-169) on conv_h2's
     parity-plane form (a 2 x 2-tap convolution over the four parity planes of the fine-resolution gradient, K = 4 x cout) against
@@ -312,7 +316,7 @@ def test_h2_pooled_tail_vjp_vs_float64_autograd(dev, f16x2, cin, cout, hs, ws, n
 
 
 @pytest.mark.parametrize('cin,cout,hs,ws,n,circular', [(96, 192, 32, 32, 2, True), (192, 384, 32, 64, 1, False), (96, 96, 64, 32, 3, True),
-                                                       (96, 192, 96, 32, 1, False)])
+                                                       (96, 192, 96, 32, 1, False), (64, 128, 32, 64, 2, True), (128, 256, 32, 32, 1, False)])
 def test_h2_stride2_head_and_its_vjp_vs_float64(dev, f16x2, cin, cout, hs, ws, n, circular):
     """The level heads (3 x 3, stride 2: sda/nn.py:152-159) on conv_h2's per-class tap lists: forward over the four input parity planes
     (MODE 4), input VJP as four output parity classes of 1 / 2 / 2 / 4 taps with the skip gradient added (MODE 3) -- against float64
