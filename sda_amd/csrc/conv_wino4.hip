@@ -1333,8 +1333,13 @@ static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
     // window of a tile must open after the previous tile's operand has left the registers: not before stage 5), SiLU' if it is an
     // act' launch.  The 64-cout tile loads its 16 pairs in a two-stage window: tiles of at least eight stages (64 input channels).
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    const bool epi = epi_on && g.mf >= 2 && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= (g.mf == 3 ? 12 : 8) &&
-                     (!d->dact_z || d->act_d == SDA_ACT_SILU);
+    // 64-cout tile: the consumer-side loads (EPM 2) measured FASTER than the helper-fed route on the block convolutions -- equal at 64
+    // channels, -4 % at 128, -7 % at 256 (profiles/r06_mf2_epm_ab.txt: 128 accumulators leave the consumers the registers to keep their own
+    // loads in flight, and the helpers lose the eight window loads per stage) -- so there the helpers feed the operand only where the
+    // zero-position kernel needs it: the up-sampled LayerNorm + skip launch of the tails.
+    const bool mf2_tail = d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2;
+    const bool epi = epi_on && g.mf >= 2 && (g.mf == 3 || mf2_tail) && ((d->res != nullptr) != (d->dact_z != nullptr)) &&
+                     g.nstage >= (g.mf == 3 ? 12 : 8) && (!d->dact_z || d->act_d == SDA_ACT_SILU);
     return epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
 }
 

@@ -14,7 +14,8 @@ CASES = (('plain96', 96, 96, 64, 896, {}), ('modLN96', 96, 96, 64, 896, dict(ln=
 if os.environ.get('W4Q_BM64'):          # the 64-cout tile: the reference's default widths (64, 128, 256)
     CASES = (('plain64', 64, 64, 64, 960, {}), ('modLN64', 64, 64, 64, 960, dict(ln=True, mod=True)), ('silu+res64', 64, 64, 64, 960, dict(silu=True, res=True)),
              ('dact64', 64, 64, 64, 960, dict(dact=True)), ('plain128', 128, 128, 32, 960, {}), ('modLN128', 128, 128, 32, 960, dict(ln=True, mod=True)),
-             ('plain256', 256, 256, 16, 960, {}), ('silu+res256', 256, 256, 16, 960, dict(silu=True, res=True)),
+             ('silu+res128', 128, 128, 32, 960, dict(silu=True, res=True)), ('dact128', 128, 128, 32, 960, dict(dact=True)),
+             ('plain256', 256, 256, 16, 960, {}), ('silu+res256', 256, 256, 16, 960, dict(silu=True, res=True)), ('dact256', 256, 256, 16, 960, dict(dact=True)),
              ('uptail128', 128, 64, 64, 960, dict(ln=True, res=True, up=True)), ('pooled64', 64, 128, 64, 960, dict(pool=True)))
 for name, cin, cout, h, n, fz in CASES:
     hs = h // 2 if fz.get('up') else h
