@@ -9,7 +9,8 @@ from sda_amd.engine import launch_conv, planar_source
 dev = torch.device('cuda:0')
 res = []
 CASES = (('plain96', 96, 96, 64, 896, {}), ('modLN96', 96, 96, 64, 896, dict(ln=True, mod=True)), ('silu+res96', 96, 96, 64, 896, dict(silu=True, res=True)),
-                                  ('dact96', 96, 96, 64, 896, dict(dact=True)), ('plain384', 384, 384, 16, 896, {}),
+                                  ('dact96', 96, 96, 64, 896, dict(dact=True)), ('silu+res192', 192, 192, 32, 896, dict(silu=True, res=True)), ('dact192', 192, 192, 32, 896, dict(dact=True)),
+                                  ('plain384', 384, 384, 16, 896, {}), ('silu+res384', 384, 384, 16, 896, dict(silu=True, res=True)), ('dact384', 384, 384, 16, 896, dict(dact=True)),
                                   ('uptail192', 192, 96, 64, 896, dict(ln=True, res=True, up=True)), ('pooled96', 96, 192, 64, 896, dict(pool=True)))
 if os.environ.get('W4Q_BM64'):          # the 64-cout tile: the reference's default widths (64, 128, 256)
     CASES = (('plain64', 64, 64, 64, 960, {}), ('modLN64', 64, 64, 64, 960, dict(ln=True, mod=True)), ('silu+res64', 64, 64, 64, 960, dict(silu=True, res=True)),
