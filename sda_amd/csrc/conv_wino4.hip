@@ -256,12 +256,13 @@ __host__ __device__ constexpr bool w4_dead(int p) { return ZP != 0 && ((p >> 2) 
 //          the upsample fused into the epilogue): one value per (cout, tile), written at half resolution.
 // MF:  cout fragments (16 couts each) per consumer wave: the workgroup tile is 32 MF couts x 32 Winograd tiles (W4_BM_OF above).  MF = 2
 //      keeps everything of the MF = 3 design -- same helpers, same V side, same two barriers per stage -- with 8 instead of 12 MFMAs and 4
-//      instead of 5 LDS reads per consumer step, a 32-KiB U slab (8 loads per helper) and the epilogue operand loaded in a TWO-slot
-//      window of eight pairs each (the 64-channel level has only eight K-stages per tile: see epi_issue).
+//      instead of 5 LDS reads per consumer step, a 32-KiB U slab (8 loads per helper) and the epilogue operand through consumer-side
+//      loads (EPM 2; see wino4_epm for the measured-and-removed helper-fed form).
 template <bool MOD, bool LN, bool SILU, int EPM, int VAR = 0, int ZP = 0, int MF = 3>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc d, const Wino4Geom g) {
     static_assert(MF >= 1 && MF <= 3, "cout tile = 32, 64 or 96");
-    static_assert(MF > 1 || (EPM != 1 && ZP != 1), "the 32-cout tile has no helper-fed epilogue operand");
+    static_assert(MF == 3 || EPM != 1, "the helper-fed epilogue operand exists for the 96-cout tile only");
+    static_assert(MF > 1 || ZP != 1, "the 32-cout tile has no up-sampled zero-position form");
     constexpr bool ZPOS = ZP != 0;                         // 9 live Winograd positions of 16 (see ZP above)
     constexpr bool EPI = EPM == 1;
     constexpr int W4_BM = W4_BM_OF(MF), W4_UPP = W4_UPP_OF(MF), W4_UBUF = W4_UBUF_OF(MF), W4_UZP = W4_UZP_OF(MF);
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // on the weights, so that the hand-counted vmcnt values do not depend on the launch.
         const float* const pf_t = d.res ? d.res : d.dact_z;
         const unsigned pf_off = (unsigned)(((pw * 8 + (lane >> 3)) * (d.ho * d.wo) + (lane & 7) * d.wo) * 4);
-        constexpr int NPF = EPI ? (MF == 3 ? 4 : 8) : 1;   // loads per iteration: the operand window's (EPI) / one prefetch touch
+        constexpr int NPF = EPI ? 4 : 1;                   // loads per iteration: the operand window's (EPI) / one prefetch touch
         float pfreg[2 * NPF] = {0.f, 0.f};
         // EPI launches: the helpers LOAD the operand instead (wave pw for consumer wave pw, lane for lane: the 24 8-byte pairs
         // the consumer lane's epilogue needs -- plane 16 m + r, rows 0 / 1 of its 2 x 2 output block), four pairs per iteration
@@ -654,9 +655,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         // inverse transform) and X2 (operand read; the helper refills the buffer).  A consumer-side global load would queue
         // behind everything the helpers have in flight on the CU's vector-memory path: ~1 us per dependent round trip, three
         // of them per tile.  Outside the window the four loads are issued all the same (dummies on the weights: static counts).
-        // MF = 2 (64-cout tile): 16 pairs (plane 16 m + r, m < 2), loaded in a window of the tile's last TWO stages, eight pairs per
-        // iteration -- the window may only open once the previous tile's operand has left these registers (epi_store, when the
-        // consumers enter the new tile: the issue cursor is then at stage 5 of it), and a 64-channel layer has eight stages per tile.
         constexpr int NEOP = 8 * MF;
         f32x2 eop[EPI ? NEOP : 1];
 #pragma unroll
@@ -665,23 +663,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         const int e_t = 16 * (pw & 1) + (lane & 15);
         const unsigned e_lo0 = (unsigned)(((4 * (lane >> 4)) * e_hw + 2 * (e_t >> 3) * d.wo + 2 * (e_t & 7)) * 4);
         const unsigned e_lo1 = e_lo0 + (unsigned)d.wo * 4u;
-        constexpr int EWIN = MF == 3 ? 6 : 2;              // window slots (stages) of a tile's operand loads
-        const int e_first = g.nstage - EWIN;
+        const int e_first = g.nstage - 6;                  // six window slots (stages) of a tile's operand loads
 #define W4_PIN_EPI()                                                                                                           \
     do {                                                                                                                       \
-        if constexpr (EPI && MF == 3) {                                                                                        \
+        if constexpr (EPI) {                                                                                                   \
             asm volatile("" : "+v"(pfreg[2]), "+v"(pfreg[3]), "+v"(pfreg[4]), "+v"(pfreg[5]), "+v"(pfreg[6]), "+v"(pfreg[7]) :: "memory"); \
             asm volatile("" : "+v"(eop[0]), "+v"(eop[1]), "+v"(eop[2]), "+v"(eop[3]), "+v"(eop[4]), "+v"(eop[5]), "+v"(eop[6]),     \
                          "+v"(eop[7]), "+v"(eop[8]), "+v"(eop[9]), "+v"(eop[10]), "+v"(eop[11]) :: "memory");                        \
             asm volatile("" : "+v"(eop[12]), "+v"(eop[13]), "+v"(eop[14]), "+v"(eop[15]), "+v"(eop[16]), "+v"(eop[17]),            \
                          "+v"(eop[18]), "+v"(eop[19]), "+v"(eop[20]), "+v"(eop[21]), "+v"(eop[22]), "+v"(eop[23]) :: "memory");     \
-        } else if constexpr (EPI) {                                                                                            \
-            asm volatile("" : "+v"(pfreg[2]), "+v"(pfreg[3]), "+v"(pfreg[4]), "+v"(pfreg[5]), "+v"(pfreg[6]), "+v"(pfreg[7]),       \
-                         "+v"(pfreg[8]), "+v"(pfreg[9]), "+v"(pfreg[10]), "+v"(pfreg[11]), "+v"(pfreg[12]), "+v"(pfreg[13]),        \
-                         "+v"(pfreg[14]), "+v"(pfreg[15]) :: "memory");                                                             \
-            asm volatile("" : "+v"(eop[0]), "+v"(eop[1]), "+v"(eop[2]), "+v"(eop[3]), "+v"(eop[4]), "+v"(eop[5]), "+v"(eop[6]),     \
-                         "+v"(eop[7]), "+v"(eop[8]), "+v"(eop[9]), "+v"(eop[10]), "+v"(eop[11]), "+v"(eop[12]), "+v"(eop[13]),       \
-                         "+v"(eop[14]), "+v"(eop[15]) :: "memory");                                                                 \
         }                                                                                                                      \
     } while (0)
         // One straight-line statement per window slot K (its four loads are skipped INSIDE the asm text unless k == K): a C++
@@ -692,39 +682,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                  "global_load_dwordx2 %2, %5, %8\n\tglobal_load_dwordx2 %3, %6, %8\n.Lw4epi%=:"                                 \
                  : "+v"(eop[4 * K + 0]), "+v"(eop[4 * K + 1]), "+v"(eop[4 * K + 2]), "+v"(eop[4 * K + 3])                      \
                  : "s"(k), "v"(e_lo0), "v"(e_lo1), "s"(b0), "s"(b1) : "memory", "scc")
-        // MF = 2: slot K = cout fragment K of the consumer -- planes 16 K + 0 .. 3 (four scalar bases), rows 0 / 1: pairs 8 K + 2 r + row
-#define W4_EPI_SLOT8(K)                                                                                                        \
-    asm volatile("s_cmp_lg_u32 %8, " #K "\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"                                           \
-                 "global_load_dwordx2 %0, %9, %11\n\tglobal_load_dwordx2 %1, %10, %11\n\t"                                      \
-                 "global_load_dwordx2 %2, %9, %12\n\tglobal_load_dwordx2 %3, %10, %12\n\t"                                      \
-                 "global_load_dwordx2 %4, %9, %13\n\tglobal_load_dwordx2 %5, %10, %13\n\t"                                      \
-                 "global_load_dwordx2 %6, %9, %14\n\tglobal_load_dwordx2 %7, %10, %14\n.Lw4epi%=:"                               \
-                 : "+v"(eop[8 * K + 0]), "+v"(eop[8 * K + 1]), "+v"(eop[8 * K + 2]), "+v"(eop[8 * K + 3]),                      \
-                   "+v"(eop[8 * K + 4]), "+v"(eop[8 * K + 5]), "+v"(eop[8 * K + 6]), "+v"(eop[8 * K + 7])                       \
-                 : "s"(k), "v"(e_lo0), "v"(e_lo1), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : "memory", "scc")
-        auto epi_issue8 = [&](const W4Cur& t, float& dm0, float& dm1, float& dm2, float& dm3, float& dm4, float& dm5, float& dm6, float& dm7) {
-            if constexpr (EPI && MF == 2) {
-                const int k = t.st - e_first;              // window slot = cout fragment: planes 16 k + 0 .. 3
-                const int kc = k < 0 ? 0 : k;
-                const int64_t ps = (int64_t)e_hw * 4;
-                const char* b0 = reinterpret_cast<const char*>(pf_t + ((int64_t)t.n * d.cout + W4_BM * t.ct + 16 * MF * (pw >> 1)) * e_hw +
-                                                               (8 * t.by) * d.wo + 16 * t.bx) + (16 * kc) * ps;
-                const char* b1 = b0 + ps;
-                const char* b2 = b1 + ps;
-                const char* b3 = b2 + ps;
-                W4_EPI_SLOT8(0); W4_EPI_SLOT8(1);
-                // outside the window: eight dummy loads on the weights (the hand-counted vmcnt values are static)
-                asm volatile("s_cmp_lt_u32 %8, 2\n\ts_cbranch_scc1 .Lw4epi%=\n\ts_nop 4\n\t"
-                             "global_load_dword %0, %9, %10\n\tglobal_load_dword %1, %9, %10\n\t"
-                             "global_load_dword %2, %9, %10\n\tglobal_load_dword %3, %9, %10\n\t"
-                             "global_load_dword %4, %9, %10\n\tglobal_load_dword %5, %9, %10\n\t"
-                             "global_load_dword %6, %9, %10\n\tglobal_load_dword %7, %9, %10\n.Lw4epi%=:"
-                             : "+v"(dm0), "+v"(dm1), "+v"(dm2), "+v"(dm3), "+v"(dm4), "+v"(dm5), "+v"(dm6), "+v"(dm7)
-                             : "s"(k), "v"(lane16), "s"(reinterpret_cast<const char*>(d.w_wino4)) : "memory", "scc");
-            }
-        };
         auto epi_issue = [&](const W4Cur& t, float& dm0, float& dm1, float& dm2, float& dm3) {
-            if constexpr (EPI && MF == 3) {
+            if constexpr (EPI) {
                 const int k = t.st - e_first;              // window slot: planes 16 (k >> 1) + 2 (k & 1) and the next one
                 const int kc = k < 0 ? 0 : k;
                 const int64_t ps = (int64_t)e_hw * 4;
@@ -817,8 +776,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
         commit(c2, h1);
         step2();
         step_issue();
-        if constexpr (EPI && MF == 3) epi_issue(ci, pfreg[4], pfreg[5], pfreg[6], pfreg[7]);
-        else if constexpr (EPI) epi_issue8(ci, pfreg[8], pfreg[9], pfreg[10], pfreg[11], pfreg[12], pfreg[13], pfreg[14], pfreg[15]);
+        if constexpr (EPI) epi_issue(ci, pfreg[4], pfreg[5], pfreg[6], pfreg[7]);
         else prefetch(ci, pfreg[1]);
         issue(ci, h0); tag(h0);
         handoff();
@@ -896,9 +854,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             W4_MARK_ADD(0, mk0, mk1); W4_MARK_ADD(1, mk1, mk2); W4_MARK_ADD(2, mk2, mk3);
             W4_STAMP(3);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (EPI && MF == 3) epi_issue(ci, pfreg[4 * PAR], pfreg[4 * PAR + 1], pfreg[4 * PAR + 2], pfreg[4 * PAR + 3]);
-            else if constexpr (EPI) epi_issue8(ci, pfreg[8 * PAR], pfreg[8 * PAR + 1], pfreg[8 * PAR + 2], pfreg[8 * PAR + 3], pfreg[8 * PAR + 4],
-                                               pfreg[8 * PAR + 5], pfreg[8 * PAR + 6], pfreg[8 * PAR + 7]);
+            if constexpr (EPI) epi_issue(ci, pfreg[4 * PAR], pfreg[4 * PAR + 1], pfreg[4 * PAR + 2], pfreg[4 * PAR + 3]);
             else prefetch(ci, pfreg[PAR]);
             if (!W4_DBG(256)) issue(ci, hissue);
             __builtin_amdgcn_sched_barrier(0);
@@ -1309,9 +1265,9 @@ static int wino4_launch_mf(const sda_conv_desc* d, const Wino4Geom& g, int grid,
 // (the 64-cout tile ships for the product variants only: the tooling variants VAR != 0 study the 96-cout kernel)
 template <bool MOD, bool LN, bool SILU, int EPI, int VAR, int ZP = 0>
 static int wino4_launch_t(const sda_conv_desc* d, const Wino4Geom& g, int grid, hipStream_t stream) {
-    if constexpr ((VAR == 0 || VAR == 11) && !W4_UDMA) {   // (11: the phase trace of tools/wino4_check.py, tooling builds)
+    if constexpr ((VAR == 0 || VAR == 11) && !W4_UDMA && EPI != 1) {   // (11: the phase trace of tools/wino4_check.py, tooling builds)
         if (g.mf == 2) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 2>(d, g, grid, stream);
-        if constexpr (EPI != 1 && ZP != 1 && VAR == 0) {
+        if constexpr (ZP != 1 && VAR == 0) {
             if (g.mf == 1) return wino4_launch_mf<MOD, LN, SILU, EPI, VAR, ZP, 1>(d, g, grid, stream);
         }
     }
@@ -1333,13 +1289,12 @@ static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
     // window of a tile must open after the previous tile's operand has left the registers: not before stage 5), SiLU' if it is an
     // act' launch.  The 64-cout tile loads its 16 pairs in a two-stage window: tiles of at least eight stages (64 input channels).
     static const bool epi_on = !(getenv("SDA_W4_EPI") && atoi(getenv("SDA_W4_EPI")) == 0);
-    // 64-cout tile: the consumer-side loads (EPM 2) measured FASTER than the helper-fed route on the block convolutions -- equal at 64
-    // channels, -4 % at 128, -7 % at 256 (profiles/r06_mf2_epm_ab.txt: 128 accumulators leave the consumers the registers to keep their own
-    // loads in flight, and the helpers lose the eight window loads per stage) -- so there the helpers feed the operand only where the
-    // zero-position kernel needs it: the up-sampled LayerNorm + skip launch of the tails.
-    const bool mf2_tail = d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2;
-    const bool epi = epi_on && g.mf >= 2 && (g.mf == 3 || mf2_tail) && ((d->res != nullptr) != (d->dact_z != nullptr)) &&
-                     g.nstage >= (g.mf == 3 ? 12 : 8) && (!d->dact_z || d->act_d == SDA_ACT_SILU);
+    // 64- / 32-cout tiles: consumer-side loads (EPM 2) only.  The helper-fed route was built for the 64-cout tile (a two-slot window of
+    // eight loads: an eight-stage tile leaves no room for more slots) and measured SLOWER than the consumers' own loads -- equal at 64
+    // channels, +4 % at 128, +7 % at 256, +10 % on the up-sampled tail (profiles/r06_mf2_epm_ab.txt: 128 accumulators leave the consumers the
+    // registers to keep their loads in flight, and the helpers lose the window loads of every stage) -- and removed.
+    const bool epi = epi_on && g.mf == 3 && ((d->res != nullptr) != (d->dact_z != nullptr)) && g.nstage >= 12 &&
+                     (!d->dact_z || d->act_d == SDA_ACT_SILU);
     return epi ? 1 : ((d->res || d->dact_z) ? 2 : 0);
 }
 
@@ -1348,7 +1303,11 @@ static int wino4_epm(const sda_conv_desc* d, const Wino4Geom& g) {
 static int wino4_zp(const sda_conv_desc* d, const Wino4Geom& g) {
     static const bool zp_on = !(getenv("SDA_W4_ZP") && atoi(getenv("SDA_W4_ZP")) == 0);
     if (d->pool_h > 1 || d->pool_w > 1) return 2;                                               // (the plan requires w_wino4_zp)
-    return (zp_on && d->w_wino4_zp && !(reinterpret_cast<uintptr_t>(d->w_wino4_zp) & 15) && d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2 && wino4_epm(d, g) == 1) ? 1 : 0;
+    if (!(zp_on && d->w_wino4_zp && !(reinterpret_cast<uintptr_t>(d->w_wino4_zp) & 15) && d->up_h == 2 && d->up_w == 2 && wino4_config(d) == 2))
+        return 0;
+    if (g.mf == 3) return wino4_epm(d, g) == 1 ? 1 : 0;
+    // 64-cout tile: the same launch (one operand; SiLU' if it is the act' one) with consumer-side loads, any tile length
+    return (g.mf == 2 && ((d->res != nullptr) != (d->dact_z != nullptr)) && (!d->dact_z || d->act_d == SDA_ACT_SILU)) ? 1 : 0;
 }
 
 int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t stream) {
@@ -1388,7 +1347,9 @@ int sda_wino4_launch(const sda_conv_desc* d, const Wino4Geom& g_in, hipStream_t 
     }
 #endif
     if (zp == 2) return wino4_launch_t<false, false, false, 0, 0, 2>(d, g, grid, stream);      // (eligibility: the plan)
-    if (zp == 1) return wino4_launch_t<false, true, false, 1, 0, 1>(d, g, grid, stream);
+    // (64-cout tile: the tail's skip operand through consumer-side loads -- 2.07 -> 1.87 ms on the 128 -> 64 tail, neutral at 96 couts)
+    if (zp == 1) return g.mf == 2 ? wino4_launch_mf<false, true, false, 2, 0, 1, 2>(d, g, grid, stream)
+                                  : wino4_launch_t<false, true, false, 1, 0, 1>(d, g, grid, stream);
     switch (wino4_config(d)) {
         case 0: {
 #ifdef SDA_W4_VARIANTS

@@ -42,8 +42,8 @@ def ref_conv(x, w, b, circular):
 
 
 def test_structured_launch_types_on_the_64_cout_tile(w4c):
-    """tools/wino4_check.py's structured cases with cout in {64, 128, 256, 320}: every loader configuration, the three epilogue
-    operand routes (none / through the helpers from eight K-stages on / consumer-side loads), partial last stages, 1-5 cout tiles,
+    """tools/wino4_check.py's structured cases with cout in {64, 128, 256, 320}: every loader configuration, the epilogue
+    operand routes (none / consumer-side loads of one or two operands), partial last stages, 1-5 cout tiles,
     both paddings, the up-sampled tails, more tiles than workgroups -- each against float64, and on the kernel family expected."""
     cases = [c for c in w4c.structured() if c['cout'] % 96 != 0]                   # (incl. the 32-cout tile: cout 32 / 160)
     assert len(cases) >= 27

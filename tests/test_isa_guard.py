@@ -43,9 +43,10 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
     kernels = [n for n in md if 'conv_wino4_kernel' in n]
     # the shipped variants: {plain, SiLU, LN} x {no operand, through the helpers, consumer loads} + mod+LN x {none, consumer}
     # + the two zero-position kernels (up-sampled LN + skip launch of the tails, pooled-output launch of their VJP); each for the
-    # 96-cout tile (MF = 3) and the 64-cout tile (MF = 2: the reference's default widths, round 6); the 32-cout tile (MF = 1) without
-    # the helper-fed operand route (EPM = 1) and the up-sampled zero-position form that needs it: 9 kernels
-    assert len(kernels) == 35, kernels
+    # = 13 for the 96-cout tile (MF = 3).  The 64-cout tile (MF = 2: the reference's default widths, round 6) has no helper-fed operand
+    # route (EPM = 1: built, measured slower than the consumers' own loads, removed) and its up-sampled zero-position form takes the skip
+    # tensor through consumer-side loads: 10 kernels; the 32-cout tile (MF = 1) has no up-sampled form at all: 9 kernels
+    assert len(kernels) == 32, kernels
     seen = set()
     for name in kernels:
         mod, ln, silu, epm, var, zp, mf = _w4_params(name)
@@ -72,9 +73,10 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         nhl = 2 * nsl + (2 * nsl if ln else 0) + (2 if mod else 0)
         # zero-position kernels: the position-packed slab, seven (MF = 3) / five (MF = 2) 1-KiB pieces per helper; full: 4 MF
         nul = {3: 7, 2: 5, 1: 3}[mf] if zp else 4 * mf
-        npf = (4 if mf == 3 else 8) if epm == 1 else 1
-        # EPI: 6 window slots x 4 + 4 dummies (MF = 3) / 2 slots x 8 + 8 dummies (MF = 2); else: the two arms of one branch
-        npf_text = (28 if mf == 3 else 24) if epm == 1 else 2
+        npf = 4 if epm == 1 else 1
+        # EPI (MF = 3 only): 6 window slots x 4 + 4 dummies; else: the two arms of one branch
+        npf_text = 28 if epm == 1 else 2
+        assert epm != 1 or mf == 3, name
         wait_u, wait_halo = nhl + npf, min(63, 2 * (nhl + npf + nul) + nul)
         seq = G.vmem_between_waits(ins)
         if epm == 2:
@@ -94,7 +96,8 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
                (False, True, False, 0), (False, True, False, 1), (False, True, False, 2),
                (True, True, False, 0), (True, True, False, 2),
                (False, True, False, 1, 1), (False, False, False, 0, 2)}
-    assert seen == shipped | {v + ('mf2',) for v in shipped} | {v + ('mf1',) for v in shipped if v[3] != 1}
+    assert seen == shipped | {v + ('mf2',) for v in shipped if v[3] != 1} | {(False, True, False, 2, 1, 'mf2')} | \
+        {v + ('mf1',) for v in shipped if v[3] != 1}
 
 
 def test_fused_1d_kernels_have_no_scratch(built):

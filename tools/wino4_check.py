@@ -92,7 +92,9 @@ def expect_path(c):
     key = (bool(c['mod']), bool(c['ln']), bool(c['silu']))
     mf = 3 if c['cout'] % 96 == 0 else (2 if c['cout'] % 64 == 0 else 1)
     nstage = (c['cin'] + 7) // 8
-    epi_ok = mf >= 2 and nstage >= (12 if mf == 3 else 8)     # the epilogue operand through the helpers (wino4_epm)
+    # the up-sampled zero-position form: at 96 couts where the operand goes through the helpers (twelve stages on), at 64 couts always
+    # (consumer-side loads), never at 32
+    epi_ok = (mf == 3 and nstage >= 12) or mf == 2
     if key not in ((False, False, False), (False, False, True), (False, True, False), (True, True, False)):
         return 1 if mf == 3 else 0
     # (5 = its zero-position form: 2 x 2 up-sampled source with the LayerNorm loader and ONE epilogue operand through the helpers -- the skip
@@ -147,7 +149,7 @@ def structured():
     add(cout=128, cin=100, h=16, w_=16, res=True, dact=True, bias=True)        # two operands: consumer-side loads
     add(cout=64, cin=128, h=32, w_=32, up=True, ln=True, res=True, bias=True)  # the tail 128 -> 64: zero-position form
     add(cout=128, cin=256, h=16, w_=32, up=True, ln=True, res=True, circular=False)
-    add(cout=64, cin=40, h=16, w_=32, up=True, ln=True, res=True)              # five stages: full kernel, consumer-side loads
+    add(cout=64, cin=40, h=16, w_=32, up=True, ln=True, res=True)              # five stages: the zero-position form all the same (consumer-side loads)
     add(cout=64, cin=16, h=8, w_=16, n=300)
     add(cout=128, cin=64, h=16, w_=16, n=67, mod=True, ln=True)
     # ---- the 32-cout tile (MF = 1): UNet's own default widths (32, 64, 128), sda/nn.py:99, and other multiples of 32
