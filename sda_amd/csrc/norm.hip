@@ -247,7 +247,13 @@ extern "C" int sda_ln_stats(const float* x, int n, int c, int hw, const float* m
         const int64_t nquad = npix / 4;
         hipStream_t st = (hipStream_t)stream;
         dim3 bl(LN_THREADS);
-        if (c <= 96) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        // round 6: exact-fit layouts for the 64 / 128 / 256-channel levels of the reference's default widths (the 96 / 192 / 384 layouts
+        // served them with a third of every lane's channel slots empty -- loads of channel 0 that are thrown away).  SDA_LN_FIT=0: A/B
+        static const bool fit = !(getenv("SDA_LN_FIT") && atoi(getenv("SDA_LN_FIT")) == 0);
+        if (fit && c <= 64) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 8>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else if (fit && c > 96 && c <= 128 && quad_mode != 3 && quad_mode != 4) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 16>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else if (fit && c > 192 && c <= 256 && quad_mode != 3) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 8, 4>), dim3((unsigned)((nquad + 7) / 8)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
+        else if (c <= 96) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12>), dim3((unsigned)((nquad + 31) / 32)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
         // 192 channels as 8 lanes x 24 channels (128-byte runs, non-temporal): 0.298 -> 0.233 ms at 120 windows, 5.1 -> 6.5 TB/s
         // (SDA_LN_STATS_QUAD=3: the 16 x 12 layout, for A/B); 384 channels as 8 x 48 (297 registers) lose: 4.65 vs 5.1 TB/s
         else if (c <= 192 && quad_mode == 4) hipLaunchKernelGGL((ln_stats_quad_kernel<8, 12, 2>), dim3((unsigned)((nquad + 15) / 16)), bl, 0, st, x, nquad, c, hw, mod, mod_sn, eps, unbiased, mean, rstd);
@@ -643,7 +649,17 @@ static int ln_bwd_launch(const float* gh, const float* x, int n, int c, int h, i
         const int hw = h * w;
         const int64_t nquad = npix / 4;
         // (lanes per quad x channels per lane: c = 96: 8 x 12, 128-byte runs; c = 192 / 384: 16 x 12 / 16 x 24, 64-byte runs)
-        if (c <= 96) {
+        static const bool fit = !(getenv("SDA_LN_FIT") && atoi(getenv("SDA_LN_FIT")) == 0);      // (exact-fit layouts: see sda_ln_stats)
+        if (fit && c <= 64) {
+            dim3 gr((unsigned)((nquad + 31) / 32));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 8>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
+        } else if (fit && c > 96 && c <= 128 && quad_mode != 3 && quad_mode != 4) {
+            dim3 gr((unsigned)((nquad + 31) / 32));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 16>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
+        } else if (fit && c > 192 && c <= 256 && quad_mode != 4) {
+            dim3 gr((unsigned)((nquad + 15) / 16));
+            hipLaunchKernelGGL((ln_bwd_quad_kernel<16, 16>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
+        } else if (c <= 96) {
             dim3 gr((unsigned)((nquad + 31) / 32));         // 8 quads per wavefront, 4 wavefronts per workgroup
             hipLaunchKernelGGL((ln_bwd_quad_kernel<8, 12>), gr, block, 0, s, gh, x, nquad, c, hw, w, mod, mod_sn, mean, rstd, unbiased, res, gx, amax); *amax_served = amax != nullptr;
         } else if (c <= 192 && quad_mode == 4) {            // (A/B: two cooperating wavefronts, 8 lanes x 12 channels each)

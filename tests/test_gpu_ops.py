@@ -157,7 +157,10 @@ def test_ln_stats_apply_bwd(dev):
                               ((5, 24, 64, 64), (1, 1)), ((3, 12, 64, 128), (2, 2)),
                               # register-resident statistics kernels: 1, 2 and 4 lanes per pixel (c <= 96, 192, 384)
                               ((5, 96, 64, 64), (1, 1)), ((5, 70, 64, 64), (1, 1)), ((3, 192, 64, 96), (1, 1)), ((3, 130, 64, 96), (2, 2)),
-                              ((2, 384, 64, 65), (1, 1)), ((2, 300, 64, 65), (1, 1)), ((2, 96, 96, 96), (2, 2)), ((1, 384, 128, 130), (2, 2)), ((2, 6, 1, 9000), (1, 2)), ((2, 6, 1, 9000), (2, 2))):
+                              ((2, 384, 64, 65), (1, 1)), ((2, 300, 64, 65), (1, 1)), ((2, 96, 96, 96), (2, 2)), ((1, 384, 128, 130), (2, 2)), ((2, 6, 1, 9000), (1, 2)), ((2, 6, 1, 9000), (2, 2)),
+                              # round 6: the exact-fit layouts of the 64 / 128 / 256-channel levels (c <= 64; 96 < c <= 128; 192 < c <= 256), full and ragged
+                              ((5, 64, 64, 64), (1, 1)), ((5, 50, 64, 64), (1, 1)), ((3, 128, 64, 96), (1, 1)), ((3, 100, 64, 96), (1, 1)), ((2, 256, 64, 66), (1, 1)), ((2, 200, 64, 68), (1, 1)),
+                              ((3, 128, 64, 96), (2, 2)), ((2, 64, 96, 96), (2, 2))):
         x = (torch.randn(n, c, h, w_) * 3 + 1).requires_grad_(True)
         mod = torch.randn(n, c)
         xd, md = x.detach().to(dev), mod.to(dev)

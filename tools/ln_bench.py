@@ -1,8 +1,11 @@
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sda_amd import ops
 dev = torch.device('cuda:0')
-for c, hw_, n in ((96, 256, int(os.environ.get("LN_N", "16"))), (192, 128, int(os.environ.get("LN_N", "16"))), (384, 64, int(os.environ.get("LN_N", "16"))), (96, 64, 128)):
+SHAPES = ((96, 256, int(os.environ.get("LN_N", "16"))), (192, 128, int(os.environ.get("LN_N", "16"))), (384, 64, int(os.environ.get("LN_N", "16"))), (96, 64, 128))
+if os.environ.get('LN_BM64'):           # the reference's default widths (64, 128, 256) at the kolmogorov64_default sizes
+    SHAPES = ((64, 64, 960), (128, 32, 960), (256, 16, 960))
+for c, hw_, n in SHAPES:
     h = w = hw_
     x = torch.randn(n, c, h, w, device=dev); gh = torch.randn_like(x); res = torch.randn_like(x)
     mod = torch.randn(1, c, device=dev)
