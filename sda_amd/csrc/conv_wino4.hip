@@ -1081,8 +1081,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
             if (d.bias) binit[m] = *reinterpret_cast<const f32x4*>(d.bias + W4_BM * c0.ct + 16 * MF * wm + 16 * m + 4 * (lane_b >> 4));
         }
         stage(std::true_type{}, binit);
-        for (int st = 1; st < g.nstage; ++st) {
+        // 64- / 32-cout tiles (EPM 2): the epilogue operand -- one value per output element, act'(z)'s z if there is one, else the residual
+        // -- is REQUESTED IN FRONT OF THE TILE'S LAST STAGE into registers this tile size has to spare (16 MF of them), so that its
+        // round trips (two dependent ones per tile, ~1 us each behind the helpers' traffic: the whole cost of a residual on a 64-channel
+        // layer, 16 %) run under that stage's multiplies.  The 96-cout tile has no registers for it (and feeds the operand through the
+        // helpers instead).
+        constexpr bool PRE = EPM == 2 && MF < 3;
+        f32x2 pre0[PRE ? MF : 1][4], pre1[PRE ? MF : 1][4];
+        for (int st = 1; st < g.nstage - (PRE ? 1 : 0); ++st) {
             stage(std::false_type{}, binit);               // (advances c0: it ends on the tile's last stage, the epilogue's tile)
+        }
+        if constexpr (PRE) {
+            // (c0 names this tile already: only its stage index moves inside a tile)
+            const int hw_p = d.ho * d.wo;
+            int lane_p;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+            const int tp_ = 16 * wn + (lane_p & 15);
+            const int lo0p = ((4 * (lane_p >> 4)) * hw_p + (8 * c0.by + 2 * (tp_ >> 3)) * d.wo + 16 * c0.bx + 2 * (tp_ & 7)) * 4, lo1p = lo0p + d.wo * 4;
+            const float* pp = d.dact_z ? d.dact_z : d.res;
+            const auto r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pp + ((int64_t)c0.n * d.cout + W4_BM * c0.ct + 16 * MF * wm) * hw_p),
+                                                                 (short)0, 16 * MF * hw_p * 4, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pre0[m][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_pre, lo0p, (16 * m + r) * hw_p * 4, 0));
+                    pre1[m][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_pre, lo1p, (16 * m + r) * hw_p * 4, 0));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g.nstage > 1) stage(std::false_type{}, binit);  // the tile's last stage
         }
         {
             // ---- epilogue of tile c0: Y = A^T M A per (cout, tile), lane local.  acc[4 xi + nu][m][r]:
@@ -1167,6 +1194,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                         if constexpr (DACT) {
                             f32x2 q0, q1;
                             if constexpr (EPI) { q0 = e0; q1 = e1; }
+                            else if constexpr (PRE) { q0 = pre0[m][r]; q1 = pre1[m][r]; }
                             else {
                                 q0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo0, so, 0));
                                 q1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_z, lo1, so, 0));
@@ -1181,6 +1209,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(const sda_conv_desc 
                         }
                         if constexpr (RES) {
                             if constexpr (EPI) { y0 += e0; y1 += e1; }
+                            else if constexpr (PRE && !DACT) { y0 += pre0[m][r]; y1 += pre1[m][r]; }     // (with act'(z): z was the prefetched one)
                             else {
                                 y0 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo0, so, 0));
                                 y1 += __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_res, lo1, so, 0));

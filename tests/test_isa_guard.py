@@ -55,8 +55,10 @@ def test_conv_wino4_no_spills_and_exact_load_counts(built):
         k, ins = md[name], dis[name]
         h = G.histogram(ins)
         scratch_ops = sum(v for o, v in h.items() if o.startswith('scratch_'))
-        # 8 steps x 4 MF MFMAs x (first | later stage); zero-position kernels: 9 of the 16 positions
-        assert sum(v for o, v in h.items() if 'mfma' in o) == (64 * mf if zp == 0 else 36 * mf), name
+        # 8 steps x 4 MF MFMAs x (first | later stage); zero-position kernels: 9 of the 16 positions.  The 64- / 32-cout tiles with an
+        # epilogue operand (EPM 2) carry the tile's LAST stage as a third copy: the operand's loads are issued in front of it
+        bodies = 3 if (epm == 2 and mf < 3) else 2
+        assert sum(v for o, v in h.items() if 'mfma' in o) == bodies * (32 * mf if zp == 0 else 18 * mf), name
         assert k['vgpr_count'] <= 256 and k['agpr_count'] == 0, (name, k)
         if epm in (0, 1):
             # the hot kernels (every launch of the reference nets): nothing spilled, no scratch segment at all
