@@ -137,13 +137,25 @@ def k64(dev):
 
 
 def test_h2_k64_score_guided_and_vjp_vs_oracle(dev, k64):
+    _score_guided_and_vjp_check(dev, *k64, length=6, label='K64')
+
+
+def test_h2_default_width_net_score_guided_and_vjp_vs_oracle(dev):
+    """Round 6: the opt-in route on the reference's DEFAULT widths -- `make_score()` as experiments/kolmogorov/utils.py:49-57 builds it
+    (window 3, (64, 128, 256)): conv_h2's 64-cout tile (MB = 2), contractions of 64 / 128 / 256 channels (K % 32; the ring across tiles)."""
+    from sda_amd.experiments.kolmogorov import make_score
+    torch.manual_seed(95)
+    net = make_score(size=64)
+    _score_guided_and_vjp_check(dev, net, oracle_eps_from_module(net, 'mc2d'), length=4, label='default widths (64, 128, 256)')
+
+
+def _score_guided_and_vjp_check(dev, net, eps_o, length, label):
     from sda_amd import observe as Ob
     from sda_amd import ops
     from sda_amd.score import GaussianScore, VPSDE
-    net, eps_o = k64
     net.to(dev)
     torch.manual_seed(91)
-    x = torch.randn(2, 6, 2, 64, 64)
+    x = torch.randn(2, length, 2, 64, 64)
     t = torch.tensor(0.37)
     sub4 = lambda v: v[..., ::4, ::4]
     y = torch.randn(sub4(x).shape)
@@ -179,7 +191,7 @@ def test_h2_k64_score_guided_and_vjp_vs_oracle(dev, k64):
     e = [rel_err(res['f16x2'][i], res['f32'][i].double()) for i in range(3)]
     r32 = [rel_err(res['f32'][0], ref.double()), rel_err(res['f32'][1], ref_v), rel_err(res['f32'][2], ref_g.double())]
     r16 = [rel_err(res['f16x2'][0], ref.double()), rel_err(res['f16x2'][1], ref_v), rel_err(res['f16x2'][2], ref_g.double())]
-    print(f'K64 @ 64^2 (eps, vjp, guided): f16x2 vs f32 kernels {e[0]:.1e} {e[1]:.1e} {e[2]:.1e}; vs oracle f32 {r32[0]:.1e} {r32[1]:.1e} {r32[2]:.1e}, '
+    print(f'{label} @ 64^2 (eps, vjp, guided): f16x2 vs f32 kernels {e[0]:.1e} {e[1]:.1e} {e[2]:.1e}; vs oracle f32 {r32[0]:.1e} {r32[1]:.1e} {r32[2]:.1e}, '
           f'f16x2 {r16[0]:.1e} {r16[1]:.1e} {r16[2]:.1e}')
     assert max(e) < 2e-5
 
